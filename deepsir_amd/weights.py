@@ -1,0 +1,65 @@
+"""Seeded state-dict generator.
+
+The trained checkpoint of the reference is not available
+(reference .MISSING_LARGE_BLOBS:1), so parity is established on generated
+weights: this generator produces the full 370-entry state-dict on both sides
+(the imported reference in ``oracle/gen_golden.py``, the oracle and the HIP
+engine) from a seed alone.  Every tensor is randomised, not only the ones the
+reference initialises randomly, so that biases, GroupNorm affine terms and
+BatchNorm running statistics are all exercised by the parity tests.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import Dict
+
+import numpy as np
+
+from .arch import NetConfig, network_specs
+
+
+def generate_state_dict(cfg: NetConfig, seed: int = 0, variant: str = "plain") -> "OrderedDict[str, np.ndarray]":
+    """Return ``{key: ndarray}`` in reference key order.
+
+    variant "plain": He-normal conv weights (as RandLANet.py:83), small random
+    biases / affine terms / running stats.
+    variant "separated": same stream, but the descriptor head (``mlp_proj``)
+    and the last ``mlp_feat`` layer are scaled up so that aggregated
+    descriptors of distinct points are far apart relative to fp32 rounding —
+    a well-conditioned arg-min regime.
+    """
+    rng = np.random.Generator(np.random.Philox(key=int(seed) + 0x5EED))
+    out: "OrderedDict[str, np.ndarray]" = OrderedDict()
+    for spec in network_specs(cfg):
+        k = spec.kind
+        if k in ("conv_w", "conv1d_w"):
+            std = np.sqrt(2.0 / max(spec.fan_in, 1))
+            a = rng.standard_normal(spec.shape) * std
+        elif k == "bias":
+            a = rng.standard_normal(spec.shape) * 0.1
+        elif k in ("gn_w", "bn_w"):
+            a = rng.uniform(0.5, 1.5, spec.shape)
+        elif k in ("gn_b", "bn_b"):
+            a = rng.standard_normal(spec.shape) * 0.1
+        elif k == "bn_mean":
+            a = rng.standard_normal(spec.shape) * 0.1
+        elif k == "bn_var":
+            a = rng.uniform(0.5, 1.5, spec.shape)
+        elif k == "bn_count":
+            out[spec.name] = np.asarray(1, dtype=np.int64)
+            continue
+        else:  # pragma: no cover
+            raise ValueError(k)
+        out[spec.name] = np.ascontiguousarray(a, dtype=np.float32)
+    if variant == "separated":
+        out["mlp_feat.6.weight"] = out["mlp_feat.6.weight"] * np.float32(4.0)
+        out["mlp_proj.0.weight"] = out["mlp_proj.0.weight"] * np.float32(4.0)
+    elif variant != "plain":
+        raise ValueError(f"unknown weight variant {variant!r}")
+    return out
+
+
+def to_torch_state_dict(sd: Dict[str, np.ndarray]):
+    import torch
+
+    return OrderedDict((k, torch.from_numpy(np.array(v))) for k, v in sd.items())
