@@ -1,0 +1,97 @@
+"""ctypes binding of libdsir.so (the C ABI declared in include/dsir.h).
+
+There is no CPU fallback: if the shared library is missing or does not load,
+importing the engine fails loudly.  Build it with ``python -c "import
+__graft_entry__ as g; g.build()"`` or ``python deepsir_amd/csrc/build.py``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdsir.so")
+
+c_float_p = C.POINTER(C.c_float)
+c_i32_p = C.POINTER(C.c_int32)
+c_i64_p = C.POINTER(C.c_int64)
+
+
+class dsir_cfg(C.Structure):
+    _fields_ = [
+        ("feat_len", C.c_int32),
+        ("num_knn", C.c_int32),
+        ("num_layers", C.c_int32),
+        ("sub_sampling_ratio", C.c_int32 * 4),
+        ("d_out", C.c_int32 * 4),
+        ("out_feat_dim", C.c_int32),
+        ("num_classes", C.c_int32),
+        ("max_points", C.c_int32),
+        ("max_pairs", C.c_int32),
+    ]
+
+
+class dsir_pair_batch(C.Structure):
+    _fields_ = [
+        ("pairs", C.c_int32), ("n_src", C.c_int32), ("n_ref", C.c_int32),
+        ("points_src", C.c_void_p), ("points_ref", C.c_void_p),
+        ("src_xyz", C.c_void_p), ("src_neigh", C.c_void_p), ("src_sub", C.c_void_p), ("src_interp", C.c_void_p),
+        ("ref_xyz", C.c_void_p), ("ref_neigh", C.c_void_p), ("ref_sub", C.c_void_p), ("ref_interp", C.c_void_p),
+        ("forced_idx", C.c_void_p),
+    ]
+
+
+class dsir_pair_result(C.Structure):
+    _fields_ = [
+        ("transforms", C.c_void_p), ("idx", C.c_void_p), ("logits", C.c_void_p), ("pt_ref_new", C.c_void_p),
+        ("invalid", C.c_void_p),
+    ]
+
+
+# every symbol include/dsir.h declares: (restype, argtypes)
+SYMBOLS = {
+    "dsir_create": (C.c_int, [C.c_int, C.POINTER(dsir_cfg), C.POINTER(C.c_void_p)]),
+    "dsir_destroy": (None, [C.c_void_p]),
+    "dsir_last_error": (C.c_char_p, [C.c_void_p]),
+    "dsir_stream": (C.c_void_p, [C.c_void_p]),
+    "dsir_sync": (C.c_int, [C.c_void_p]),
+    "dsir_num_weights": (C.c_int, [C.c_void_p]),
+    "dsir_weight_name": (C.c_char_p, [C.c_void_p, C.c_int, c_i64_p]),
+    "dsir_load_weight": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, c_i64_p, C.c_int]),
+    "dsir_finalize_weights": (C.c_int, [C.c_void_p]),
+    "dsir_narrow_i64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
+    "dsir_knn_pyramid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p]),
+    "dsir_randla_forward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dsir_score": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                             C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "dsir_aggregate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                 C.c_void_p]),
+    "dsir_nn_match": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "dsir_kabsch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                              C.c_void_p]),
+    "dsir_register": (C.c_int, [C.c_void_p, C.POINTER(dsir_pair_batch), C.c_int, C.POINTER(dsir_pair_result)]),
+    "dsir_match_timer": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), c_i64_p]),
+    "dsir_enable_match_timer": (C.c_int, [C.c_void_p, C.c_int]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libdsir.so and bind every declared entry point; raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP engine is not built.  Run `python deepsir_amd/csrc/build.py` "
+            "(needs hipcc; cross-compiles gfx950 without a GPU).  There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

@@ -1,0 +1,266 @@
+// Weighted Kabsch pose solve, entirely on device (reference network/model.py:22-66
+// compute_rigid_transform_2 — which round-trips to the CPU for a float64 LAPACK
+// SVD every iteration — plus the SE(3) bookkeeping of forward_align_4,
+// model.py:586-595, common/math/se3_torch.py:28-77).
+//
+// One 1024-thread block per pair.  Three passes over the (L2-resident) points:
+//   S = sum |w|;  c_s = sum s*wn, c_t = sum t*wn (wn = w/(S+1e-16));
+//   H = sum (s-c_s) ((t-c_t)*wn)^T.
+// Every product is rounded to fp32 exactly as the reference's element-wise ops
+// produce it; the sums are accumulated in fp64 (wave shuffles + LDS), i.e. the
+// exact value the reference's fp32 reductions approximate in some order.
+// Thread 0 then runs a one-sided Jacobi SVD of H in fp64, R = V diag(1,1,d) U^T
+// with d = sign(det(V U^T)), casts R to fp32 and forms t = -R c_s + c_t in fp32
+// (model.py:53,57).  Non-finite H => identity + invalid flag (model.py:61-64).
+// The same launch applies the transform to the src points, gathers the matched
+// ref points and composes the cumulative transform.
+#include "kernels.h"
+#include "device_utils.h"
+
+namespace dsir {
+
+namespace {
+
+constexpr int NTHR = 1024;
+constexpr int NWAVE = NTHR / 64;
+
+template <int NV>
+__device__ __forceinline__ void block_sum(double (&v)[NV], double* sh /* [NWAVE][NV] + [NV] */) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = wave_sum(v[i]);
+  __syncthreads();
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) sh[w * NV + i] = v[i];
+  }
+  __syncthreads();
+  if (threadIdx.x < NV) {
+    double s = 0.0;
+    for (int ww = 0; ww < NWAVE; ++ww) s += sh[ww * NV + threadIdx.x];
+    sh[NWAVE * NV + threadIdx.x] = s;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = sh[NWAVE * NV + i];
+}
+
+// One-sided (Hestenes) Jacobi SVD of a 3x3 matrix in fp64: A = U diag(s) V^T, s sorted descending.
+__device__ void svd3(const double A[3][3], double U[3][3], double S[3], double V[3][3]) {
+  double G[3][3];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) { G[i][j] = A[i][j]; V[i][j] = (i == j) ? 1.0 : 0.0; }
+  for (int sweep = 0; sweep < 30; ++sweep) {
+    double off = 0.0;
+    for (int p = 0; p < 2; ++p)
+      for (int q = p + 1; q < 3; ++q) {
+        double al = 0, be = 0, ga = 0;
+        for (int i = 0; i < 3; ++i) { al += G[i][p] * G[i][p]; be += G[i][q] * G[i][q]; ga += G[i][p] * G[i][q]; }
+        const double lim = 1e-300 + 1e-32 * al * be;
+        if (ga * ga <= lim) continue;
+        off = fmax(off, ga * ga / (al * be));
+        const double zeta = (be - al) / (2.0 * ga);
+        const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+        for (int i = 0; i < 3; ++i) {
+          const double gp = G[i][p], gq = G[i][q];
+          G[i][p] = c * gp - s * gq; G[i][q] = s * gp + c * gq;
+          const double vp = V[i][p], vq = V[i][q];
+          V[i][p] = c * vp - s * vq; V[i][q] = s * vp + c * vq;
+        }
+      }
+    if (off < 1e-30) break;
+  }
+  double nrm[3];
+  for (int j = 0; j < 3; ++j) nrm[j] = sqrt(G[0][j] * G[0][j] + G[1][j] * G[1][j] + G[2][j] * G[2][j]);
+  int o[3] = {0, 1, 2};
+  for (int a = 0; a < 2; ++a)
+    for (int b = 0; b < 2 - a; ++b)
+      if (nrm[o[b]] < nrm[o[b + 1]]) { int t = o[b]; o[b] = o[b + 1]; o[b + 1] = t; }
+  double Vs[3][3];
+  const double tiny = 1e-280;
+  for (int j = 0; j < 3; ++j) {
+    S[j] = nrm[o[j]];
+    for (int i = 0; i < 3; ++i) { Vs[i][j] = V[i][o[j]]; U[i][j] = S[j] > tiny ? G[i][o[j]] / S[j] : 0.0; }
+  }
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) V[i][j] = Vs[i][j];
+  // complete U for (numerically) rank-deficient input; R is unique iff rank >= 2
+  const double thr = S[0] * 1e-14;
+  if (!(S[0] > tiny)) {
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) U[i][j] = (i == j) ? 1.0 : 0.0;
+  } else {
+    if (!(S[1] > thr)) {  // pick any unit vector orthogonal to u0
+      int m = 0;
+      if (fabs(U[1][0]) < fabs(U[m][0])) m = 1;
+      if (fabs(U[2][0]) < fabs(U[m][0])) m = 2;
+      double e[3] = {0, 0, 0};
+      e[m] = 1.0;
+      const double dot = U[m][0];
+      double n2 = 0;
+      for (int i = 0; i < 3; ++i) { U[i][1] = e[i] - dot * U[i][0]; n2 += U[i][1] * U[i][1]; }
+      n2 = sqrt(n2);
+      for (int i = 0; i < 3; ++i) U[i][1] /= n2;
+    }
+    if (!(S[2] > thr)) {
+      U[0][2] = U[1][0] * U[2][1] - U[2][0] * U[1][1];
+      U[1][2] = U[2][0] * U[0][1] - U[0][0] * U[2][1];
+      U[2][2] = U[0][0] * U[1][1] - U[1][0] * U[0][1];
+    }
+  }
+}
+
+__device__ __forceinline__ double det3(const double M[3][3]) {
+  return M[0][0] * (M[1][1] * M[2][2] - M[1][2] * M[2][1]) - M[0][1] * (M[1][0] * M[2][2] - M[1][2] * M[2][0]) +
+         M[0][2] * (M[1][0] * M[2][1] - M[1][1] * M[2][0]);
+}
+
+__global__ __launch_bounds__(NTHR) void kabsch_kernel(const KabschArgs a) {
+  __shared__ double sh[NWAVE * 9 + 9];
+  __shared__ float sT[12];
+  __shared__ int s_bad;
+  const int pair = blockIdx.x;
+  const int m = a.m;
+  const float* src = a.src + pair * a.src_stride;
+  const float* ref = a.ref + pair * a.ref_stride;
+  const int32_t* idx = a.idx ? a.idx + (int64_t)pair * m : nullptr;
+  const float* wl = a.w + (int64_t)pair * m;
+  auto weight = [&](int i) -> float {
+    const float x = wl[i];
+    return a.sigmoid ? 1.f / (1.f + expf(-x)) : x;
+  };
+  auto target = [&](int i, float& x, float& y, float& z) {
+    const int64_t j = idx ? idx[i] : i;
+    x = ref[j * 3]; y = ref[j * 3 + 1]; z = ref[j * 3 + 2];
+  };
+
+  // pass 1: S = sum |w|
+  double v1[1] = {0.0};
+  for (int i = threadIdx.x; i < m; i += NTHR) v1[0] += (double)fabsf(weight(i));
+  block_sum<1>(v1, sh);
+  const float den = (float)v1[0] + 1e-16f;   // model.py:35 (fp32 sum + _EPS)
+
+  // pass 2: weighted centroids
+  double v6[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = threadIdx.x; i < m; i += NTHR) {
+    const float wn = weight(i) / den;
+    float tx, ty, tz;
+    target(i, tx, ty, tz);
+    v6[0] += (double)__fmul_rn(src[(int64_t)i * 3], wn);
+    v6[1] += (double)__fmul_rn(src[(int64_t)i * 3 + 1], wn);
+    v6[2] += (double)__fmul_rn(src[(int64_t)i * 3 + 2], wn);
+    v6[3] += (double)__fmul_rn(tx, wn);
+    v6[4] += (double)__fmul_rn(ty, wn);
+    v6[5] += (double)__fmul_rn(tz, wn);
+  }
+  block_sum<6>(v6, sh);
+  const float cs[3] = {(float)v6[0], (float)v6[1], (float)v6[2]};
+  const float ct[3] = {(float)v6[3], (float)v6[4], (float)v6[5]};
+
+  // pass 3: covariance H[a][b] = sum (s_a - cs_a) * ((t_b - ct_b) * wn)
+  double v9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = threadIdx.x; i < m; i += NTHR) {
+    const float wn = weight(i) / den;
+    float t[3];
+    target(i, t[0], t[1], t[2]);
+    float sc[3], tw[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      sc[k] = __fsub_rn(src[(int64_t)i * 3 + k], cs[k]);
+      tw[k] = __fmul_rn(__fsub_rn(t[k], ct[k]), wn);
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) v9[r * 3 + c] += (double)__fmul_rn(sc[r], tw[c]);
+  }
+  block_sum<9>(v9, sh);
+
+  if (threadIdx.x == 0) {
+    bool finite = true;
+    double H[3][3];
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) {
+        const float h = (float)v9[r * 3 + c];   // the reference's H is fp32, then .double()
+        H[r][c] = (double)h;
+        finite = finite && isfinite(h);
+      }
+    float T[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    int bad = 1;
+    if (finite) {
+      double U[3][3], S[3], V[3][3];
+      svd3(H, U, S, V);
+      double Rp[3][3];
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) Rp[r][c] = V[r][0] * U[c][0] + V[r][1] * U[c][1] + V[r][2] * U[c][2];
+      const double d = det3(Rp) > 0 ? 1.0 : -1.0;
+      float R[3][3];
+      bool ok = true;
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+          R[r][c] = (float)(V[r][0] * U[c][0] + V[r][1] * U[c][1] + d * V[r][2] * U[c][2]);
+          ok = ok && isfinite(R[r][c]);
+        }
+      if (ok) {
+        bad = 0;
+        for (int r = 0; r < 3; ++r) {
+          T[r * 4 + 0] = R[r][0]; T[r * 4 + 1] = R[r][1]; T[r * 4 + 2] = R[r][2];
+          float acc = __fmul_rn(-R[r][0], cs[0]);
+          acc = fmaf(-R[r][1], cs[1], acc);
+          acc = fmaf(-R[r][2], cs[2], acc);
+          T[r * 4 + 3] = __fadd_rn(acc, ct[r]);
+        }
+      }
+    }
+    for (int k = 0; k < 12; ++k) { sT[k] = T[k]; a.T[(int64_t)pair * 12 + k] = T[k]; }
+    s_bad = bad;
+    if (a.invalid && bad) a.invalid[pair] = 1;
+    if (a.T_cum) {   // concatenate(R_t, T_prev): (R1 R2, R1 t2 + t1)   se3_torch.py:34-57
+      float* out = a.T_cum + pair * a.T_stride;
+      if (!a.T_prev) {
+        for (int k = 0; k < 12; ++k) out[k] = T[k];
+      } else {
+        const float* P = a.T_prev + pair * a.T_stride;
+        float C[12];
+        for (int r = 0; r < 3; ++r) {
+          for (int c = 0; c < 3; ++c)
+            C[r * 4 + c] = fmaf(T[r * 4 + 2], P[2 * 4 + c], fmaf(T[r * 4 + 1], P[1 * 4 + c], __fmul_rn(T[r * 4 + 0], P[c])));
+          const float rt = fmaf(T[r * 4 + 2], P[2 * 4 + 3], fmaf(T[r * 4 + 1], P[1 * 4 + 3], __fmul_rn(T[r * 4 + 0], P[3])));
+          C[r * 4 + 3] = __fadd_rn(rt, T[r * 4 + 3]);
+        }
+        for (int k = 0; k < 12; ++k) out[k] = C[k];
+      }
+    }
+  }
+  __syncthreads();
+  // apply: p' = p R^T + t (se3_torch.py:60-77); gather the matched ref points
+  if (a.src_out || a.matched_out) {
+    float* so = a.src_out ? a.src_out + pair * a.src_out_stride : nullptr;
+    float* mo = a.matched_out ? a.matched_out + (int64_t)pair * m * 3 : nullptr;
+    for (int i = threadIdx.x; i < m; i += NTHR) {
+      if (mo) {
+        float tx, ty, tz;
+        target(i, tx, ty, tz);
+        mo[(int64_t)i * 3] = tx; mo[(int64_t)i * 3 + 1] = ty; mo[(int64_t)i * 3 + 2] = tz;
+      }
+      if (so) {
+        const float x = src[(int64_t)i * 3], y = src[(int64_t)i * 3 + 1], z = src[(int64_t)i * 3 + 2];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          const float d = fmaf(z, sT[r * 4 + 2], fmaf(y, sT[r * 4 + 1], __fmul_rn(x, sT[r * 4 + 0])));
+          so[(int64_t)i * 3 + r] = __fadd_rn(d, sT[r * 4 + 3]);
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+void launch_kabsch(const KabschArgs& a, hipStream_t st) {
+  if (a.pairs <= 0) return;
+  hipLaunchKernelGGL(kabsch_kernel, dim3(a.pairs), dim3(NTHR), 0, st, a);
+}
+
+}  // namespace dsir

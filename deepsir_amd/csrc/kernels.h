@@ -1,0 +1,119 @@
+// Internal host-side launch API of the HIP kernels (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dsir {
+
+constexpr int kKnn = 16;  // neighbours per point (args.num_knn; one MFMA row tile)
+
+// GroupNorm of the PRODUCER, applied lazily in the consumer's prologue:
+// the producer wrote raw conv outputs plus per-(cloud,group) sum / sum-of-squares.
+struct GnRef {
+  const double* stats;   // [clouds][groups][2]; nullptr => no normalisation
+  const float* gamma;    // [C]
+  const float* beta;     // [C]
+  int groups;
+  double inv_count;      // 1 / ((C/groups) * rows_per_cloud)
+};
+
+// One channel segment of the A operand (rows = points or (point,neighbour) pairs).
+struct Seg {
+  const float* x;        // [clouds][rows_src][ld]
+  int64_t cloud_stride;  // floats
+  int C;                 // channels taken from this segment
+  int ld;                // row stride in floats
+  const int32_t* idx;    // optional row gather index [clouds][M]
+  int64_t idx_cloud_stride;
+  int row_div;           // source row = idx ? idx[r] : r / row_div
+  GnRef gn;
+  int act;               // 1 => LeakyReLU(0.2) after the normalisation
+};
+
+enum AMode { A_SEGS = 0, A_LSE = 1 };
+enum Epilogue { EPI_GN = 0, EPI_ACT = 1, EPI_LINEAR = 2, EPI_L2NORM = 3, EPI_ATT = 4 };
+
+struct GemmArgs {
+  int amode = A_SEGS;
+  int nseg = 1;
+  Seg seg[2] = {};
+  // A_LSE: relative position encoding from xyz + neighbour index (RandLANet.py:197-212)
+  const float* xyz = nullptr;   // [clouds][n][3]
+  int64_t xyz_cloud_stride = 0;
+  const int32_t* neigh = nullptr;  // [clouds][n][16]
+  int64_t neigh_cloud_stride = 0;
+
+  const float* W = nullptr;     // [Cout][Cin] row-major
+  const float* bias = nullptr;  // [Cout] or nullptr
+  int Cin = 0, Cout = 0;
+  int M = 0;                    // rows per cloud
+  int clouds = 1;
+  int epi = EPI_GN;
+  float* Y = nullptr;           // [clouds][M (or M/16 for EPI_ATT)][ldy]
+  int64_t y_cloud_stride = 0;
+  int ldy = 0;
+  double* stats_out = nullptr;  // EPI_GN: [clouds][groups_out][2]
+  int groups_out = 0;
+  const float* residual = nullptr;  // EPI_LINEAR: added before the store
+  int64_t res_cloud_stride = 0;
+  int ldres = 0;
+};
+
+void launch_pw_gemm(const GemmArgs& a, hipStream_t st);
+
+// y = LeakyReLU(GN_a(a) + GN_b(b))   (RandLANet.py:228-230)
+void launch_residual_combine(const float* a, GnRef ga, const float* b, GnRef gb, int C, int rows, int clouds,
+                             float* y, hipStream_t st);
+// out[i][c] = max_k in[idx[i][k]][c]   (RandLANet.py:374-391)
+void launch_gather_max(const float* in, int64_t in_cloud_stride, const int32_t* idx, int64_t idx_cloud_stride, int C,
+                       int rows_out, int clouds, float* out, hipStream_t st);
+
+void launch_narrow_i64(const int64_t* src, int32_t* dst, int64_t n, hipStream_t st);
+
+// KNN (data_base.py:153-183): one level.  support = first n_support points of `pts`.
+void launch_knn16(const float* pts, int64_t cloud_stride, int stride, int n, int clouds, int32_t* out,
+                  int64_t out_cloud_stride, hipStream_t st);
+void launch_nn1(const float* pts, int64_t cloud_stride, int stride, int n_query, int n_support, int clouds,
+                int32_t* out, int64_t out_cloud_stride, hipStream_t st);
+void launch_copy_xyz(const float* pts, int64_t cloud_stride, int stride, int n, int clouds, float* out,
+                     int64_t out_cloud_stride, hipStream_t st);
+void launch_copy_rows_i32(const int32_t* src, int64_t src_cloud_stride, int rows, int width, int clouds, int32_t* dst,
+                          int64_t dst_cloud_stride, hipStream_t st);
+
+// score_fun (model.py:701-757)
+struct ScoreScratch {  // per cloud: [0]=max feat, [1]=max label weight, [2]=max prob   (float bits, atomics)
+  float* red;          // [clouds][4]
+  float* prob;         // [clouds][n]
+  int32_t* label;      // [clouds][n]
+};
+void launch_score(const float* feat, const float* logits, int ncls, const float* xyz, int64_t xyz_cloud_stride,
+                  const int32_t* neigh, int64_t neigh_cloud_stride, int clouds, int n, ScoreScratch s, float* score,
+                  int32_t* label_out, hipStream_t st);
+
+// fused distance GEMM + row arg-min (matchnet.py:96-113 + model.py:566); ev0/ev1 (optional) bracket the main kernel
+size_t nn_match_scratch_bytes(int pairs, int J, int K);
+void launch_nn_match_ws(const float* a, const float* b, int pairs, int J, int K, int32_t* idx, void* scratch,
+                        hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
+
+// weighted Kabsch + SE(3) bookkeeping (model.py:22-66, :586-595; se3_torch.py:28-77)
+struct KabschArgs {
+  const float* src;      // [pairs][m][3]  current (transformed) src points
+  const float* ref;      // [pairs][K][3]  ref points
+  const int32_t* idx;    // [pairs][m] correspondences (nullptr => ref is already matched, [pairs][m][3])
+  const float* w;        // [pairs][m] weights, or logits when sigmoid != 0
+  int64_t src_stride, ref_stride;  // floats between pairs
+  int sigmoid;
+  int pairs, m;
+  float* T;              // [pairs][3][4] this iteration's transform
+  int32_t* invalid;      // [pairs], OR-ed
+  // optional SE(3) bookkeeping
+  float* src_out;        // transformed src [pairs][m][3] (may alias src)
+  int64_t src_out_stride;
+  const float* T_prev;   // [pairs][.][3][4] previous cumulative (nullptr on iteration 0)
+  float* T_cum;          // cumulative out
+  int64_t T_stride;      // floats between pairs in T_prev / T_cum
+  float* matched_out;    // [pairs][m][3] gathered ref points (or nullptr)
+};
+void launch_kabsch(const KabschArgs& a, hipStream_t st);
+
+}  // namespace dsir

@@ -1,0 +1,153 @@
+// Brute-force KNN for the pyramid (reference dataloader/data_base.py:153-183;
+// the reference delegates to torch_points_kernels.knn on the CPU).
+//
+// One block = 64 queries x 4 waves.  Wave w scans the w-th quarter of the
+// support set, staged through a wave-private LDS tile (xyz padded to float4,
+// broadcast ds_read_b128), and keeps a sorted top-16 (distance, index) list in
+// registers (fully unrolled compare-exchange chain, static indexing).  The four
+// partial lists are merged through LDS by wave 0.  Tie rule = oracle/knn.py:
+// fp32 d = (dx*dx + dy*dy) + dz*dz without FMA contraction, ties to the lower
+// support index (scan order is ascending and every comparison is strict).
+#include "kernels.h"
+#include "device_utils.h"
+
+namespace dsir {
+
+namespace {
+
+constexpr int QB = 64;      // queries per block (one per lane)
+constexpr int NW = 4;       // waves per block = support slices
+constexpr int TILE = 256;   // support points staged per wave per step
+
+__device__ __forceinline__ float sqdist(float qx, float qy, float qz, const float4& s) {
+  const float dx = __fsub_rn(s.x, qx), dy = __fsub_rn(s.y, qy), dz = __fsub_rn(s.z, qz);
+  return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+}
+
+struct Top16 {
+  float d[kKnn];
+  int i[kKnn];
+  __device__ __forceinline__ void init() {
+#pragma unroll
+    for (int t = 0; t < kKnn; ++t) { d[t] = INFINITY; i[t] = -1; }
+  }
+  __device__ __forceinline__ void insert(float dist, int idx) {
+    if (dist < d[kKnn - 1]) {
+      d[kKnn - 1] = dist; i[kKnn - 1] = idx;
+#pragma unroll
+      for (int t = kKnn - 1; t > 0; --t) {
+        const bool sw = d[t] < d[t - 1];
+        const float dl = sw ? d[t] : d[t - 1], dh = sw ? d[t - 1] : d[t];
+        const int il = sw ? i[t] : i[t - 1], ih = sw ? i[t - 1] : i[t];
+        d[t - 1] = dl; d[t] = dh; i[t - 1] = il; i[t] = ih;
+      }
+    }
+  }
+};
+
+__global__ __launch_bounds__(QB * NW) void knn16_kernel(const float* __restrict__ pts, int64_t cs, int stride, int n,
+                                                        int32_t* __restrict__ out, int64_t ocs) {
+  __shared__ float4 tile[NW][TILE];
+  __shared__ float md[NW - 1][kKnn][QB];
+  __shared__ int mi[NW - 1][kKnn][QB];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int cloud = blockIdx.y;
+  const float* P = pts + cloud * cs;
+  const int q = blockIdx.x * QB + lane;
+  float qx = 0.f, qy = 0.f, qz = 0.f;
+  if (q < n) { qx = P[(int64_t)q * stride]; qy = P[(int64_t)q * stride + 1]; qz = P[(int64_t)q * stride + 2]; }
+  const int slice = (n + NW - 1) / NW;
+  const int s_begin = w * slice;
+  const int s_end = min(n, s_begin + slice);
+  Top16 top;
+  top.init();
+  for (int t0 = 0; t0 < slice; t0 += TILE) {
+    // stage: each lane loads TILE/64 support points of this wave's slice
+#pragma unroll
+    for (int r = 0; r < TILE / 64; ++r) {
+      const int j = s_begin + t0 + r * 64 + lane;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (j < s_end) { v.x = P[(int64_t)j * stride]; v.y = P[(int64_t)j * stride + 1]; v.z = P[(int64_t)j * stride + 2]; }
+      tile[w][r * 64 + lane] = v;
+    }
+    __syncthreads();
+    const int cnt = max(0, min(TILE, s_end - (s_begin + t0)));
+    for (int j = 0; j < cnt; ++j) top.insert(sqdist(qx, qy, qz, tile[w][j]), s_begin + t0 + j);
+    __syncthreads();
+  }
+  if (w > 0) {
+#pragma unroll
+    for (int t = 0; t < kKnn; ++t) { md[w - 1][t][lane] = top.d[t]; mi[w - 1][t][lane] = top.i[t]; }
+  }
+  __syncthreads();
+  if (w == 0 && q < n) {
+#pragma unroll
+    for (int s = 0; s < NW - 1; ++s) {
+#pragma unroll
+      for (int t = 0; t < kKnn; ++t) top.insert(md[s][t][lane], mi[s][t][lane]);
+    }
+    int32_t* o = out + cloud * ocs + (int64_t)q * kKnn;
+#pragma unroll
+    for (int t = 0; t < kKnn; t += 4) *reinterpret_cast<int4*>(o + t) = make_int4(top.i[t], top.i[t + 1], top.i[t + 2], top.i[t + 3]);
+  }
+}
+
+// nearest support point (support = first n_support points) of every query point
+__global__ __launch_bounds__(QB * NW) void nn1_kernel(const float* __restrict__ pts, int64_t cs, int stride, int n_query,
+                                                      int n_support, int32_t* __restrict__ out, int64_t ocs) {
+  __shared__ float4 tile[NW][TILE];
+  __shared__ float md[NW][QB];
+  __shared__ int mi[NW][QB];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int cloud = blockIdx.y;
+  const float* P = pts + cloud * cs;
+  const int q = blockIdx.x * QB + lane;
+  float qx = 0.f, qy = 0.f, qz = 0.f;
+  if (q < n_query) { qx = P[(int64_t)q * stride]; qy = P[(int64_t)q * stride + 1]; qz = P[(int64_t)q * stride + 2]; }
+  const int slice = (n_support + NW - 1) / NW;
+  const int s_begin = w * slice;
+  const int s_end = min(n_support, s_begin + slice);
+  float bd = INFINITY;
+  int bi = -1;
+  for (int t0 = 0; t0 < slice; t0 += TILE) {
+#pragma unroll
+    for (int r = 0; r < TILE / 64; ++r) {
+      const int j = s_begin + t0 + r * 64 + lane;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (j < s_end) { v.x = P[(int64_t)j * stride]; v.y = P[(int64_t)j * stride + 1]; v.z = P[(int64_t)j * stride + 2]; }
+      tile[w][r * 64 + lane] = v;
+    }
+    __syncthreads();
+    const int cnt = max(0, min(TILE, s_end - (s_begin + t0)));
+    for (int j = 0; j < cnt; ++j) {
+      const float d = sqdist(qx, qy, qz, tile[w][j]);
+      if (d < bd) { bd = d; bi = s_begin + t0 + j; }
+    }
+    __syncthreads();
+  }
+  md[w][lane] = bd; mi[w][lane] = bi;
+  __syncthreads();
+  if (w == 0 && q < n_query) {
+#pragma unroll
+    for (int s = 1; s < NW; ++s) {
+      const float d = md[s][lane];
+      if (d < bd) { bd = d; bi = mi[s][lane]; }
+    }
+    out[cloud * ocs + q] = bi;
+  }
+}
+
+}  // namespace
+
+void launch_knn16(const float* pts, int64_t cs, int stride, int n, int clouds, int32_t* out, int64_t ocs, hipStream_t st) {
+  dim3 grid((n + QB - 1) / QB, clouds);
+  hipLaunchKernelGGL(knn16_kernel, grid, dim3(QB * NW), 0, st, pts, cs, stride, n, out, ocs);
+}
+
+void launch_nn1(const float* pts, int64_t cs, int stride, int n_query, int n_support, int clouds, int32_t* out,
+                int64_t ocs, hipStream_t st) {
+  dim3 grid((n_query + QB - 1) / QB, clouds);
+  hipLaunchKernelGGL(nn1_kernel, grid, dim3(QB * NW), 0, st, pts, cs, stride, n_query, n_support, out, ocs);
+}
+
+}  // namespace dsir

@@ -1,0 +1,114 @@
+// Element-wise / gather helpers of the RandLA encoder.
+#include "kernels.h"
+#include "device_utils.h"
+
+namespace dsir {
+
+namespace {
+
+__device__ __forceinline__ void gn_scale_shift(const GnRef& g, int cloud, int c, int C, float& scale, float& shift) {
+  const int grp = c / (C / g.groups);
+  const double* st = g.stats + ((int64_t)cloud * g.groups + grp) * 2;
+  const double mean = st[0] * g.inv_count;
+  double var = st[1] * g.inv_count - mean * mean;
+  var = var > 0.0 ? var : 0.0;
+  const double rstd = 1.0 / sqrt(var + 1e-5);
+  const double sc = (double)g.gamma[c] * rstd;
+  scale = (float)sc;
+  shift = (float)((double)g.beta[c] - mean * sc);
+}
+
+// y = LeakyReLU(GN(a) + GN(b)) ; one thread per element, channels fastest (coalesced).
+__global__ __launch_bounds__(256) void residual_combine_kernel(const float* __restrict__ a, GnRef ga,
+                                                               const float* __restrict__ b, GnRef gb, int C, int rows,
+                                                               float* __restrict__ y) {
+  __shared__ float sa[512], ha[512], sb[512], hb[512];
+  const int cloud = blockIdx.y;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    gn_scale_shift(ga, cloud, c, C, sa[c], ha[c]);
+    gn_scale_shift(gb, cloud, c, C, sb[c], hb[c]);
+  }
+  __syncthreads();
+  const int64_t total = (int64_t)rows * C;
+  const int64_t base = (int64_t)cloud * total;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(e % C);
+    const float v = fmaf(a[base + e], sa[c], ha[c]) + fmaf(b[base + e], sb[c], hb[c]);
+    y[base + e] = v < 0.f ? 0.2f * v : v;
+  }
+}
+
+// out[i][c] = max over the 16 pooled neighbours ("random sampling", RandLANet.py:374-391)
+__global__ __launch_bounds__(256) void gather_max_kernel(const float* __restrict__ in, int64_t in_cs,
+                                                         const int32_t* __restrict__ idx, int64_t idx_cs, int C,
+                                                         int rows_out, float* __restrict__ out) {
+  const int cloud = blockIdx.y;
+  const int64_t total = (int64_t)rows_out * C;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int i = (int)(e / C), c = (int)(e % C);
+    const int32_t* nb = idx + cloud * idx_cs + (int64_t)i * kKnn;
+    float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < kKnn; ++k) m = fmaxf(m, in[cloud * in_cs + (int64_t)nb[k] * C + c]);
+    out[(int64_t)cloud * total + e] = m;
+  }
+}
+
+__global__ void narrow_i64_kernel(const int64_t* __restrict__ src, int32_t* __restrict__ dst, int64_t n) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
+    dst[e] = (int32_t)src[e];
+}
+
+__global__ void copy_xyz_kernel(const float* __restrict__ pts, int64_t cs, int stride, int n, float* __restrict__ out,
+                                int64_t ocs) {
+  const int cloud = blockIdx.y;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n * 3; e += gridDim.x * blockDim.x)
+    out[cloud * ocs + e] = pts[cloud * cs + (int64_t)(e / 3) * stride + (e % 3)];
+}
+
+__global__ void copy_rows_i32_kernel(const int32_t* __restrict__ src, int64_t scs, int count, int32_t* __restrict__ dst,
+                                     int64_t dcs) {
+  const int cloud = blockIdx.y;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < count; e += gridDim.x * blockDim.x)
+    dst[cloud * dcs + e] = src[cloud * scs + e];
+}
+
+inline int grid_for(int64_t total, int block = 256, int cap = 2048) {
+  int64_t g = (total + block - 1) / block;
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace
+
+void launch_residual_combine(const float* a, GnRef ga, const float* b, GnRef gb, int C, int rows, int clouds, float* y,
+                             hipStream_t st) {
+  dim3 grid(grid_for((int64_t)rows * C), clouds);
+  hipLaunchKernelGGL(residual_combine_kernel, grid, dim3(256), 0, st, a, ga, b, gb, C, rows, y);
+}
+
+void launch_gather_max(const float* in, int64_t in_cs, const int32_t* idx, int64_t idx_cs, int C, int rows_out,
+                       int clouds, float* out, hipStream_t st) {
+  if (rows_out <= 0) return;
+  dim3 grid(grid_for((int64_t)rows_out * C), clouds);
+  hipLaunchKernelGGL(gather_max_kernel, grid, dim3(256), 0, st, in, in_cs, idx, idx_cs, C, rows_out, out);
+}
+
+void launch_narrow_i64(const int64_t* src, int32_t* dst, int64_t n, hipStream_t st) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(narrow_i64_kernel, dim3(grid_for(n)), dim3(256), 0, st, src, dst, n);
+}
+
+void launch_copy_xyz(const float* pts, int64_t cs, int stride, int n, int clouds, float* out, int64_t ocs,
+                     hipStream_t st) {
+  dim3 grid(grid_for((int64_t)n * 3), clouds);
+  hipLaunchKernelGGL(copy_xyz_kernel, grid, dim3(256), 0, st, pts, cs, stride, n, out, ocs);
+}
+
+void launch_copy_rows_i32(const int32_t* src, int64_t scs, int rows, int width, int clouds, int32_t* dst, int64_t dcs,
+                          hipStream_t st) {
+  if (rows <= 0) return;
+  dim3 grid(grid_for((int64_t)rows * width), clouds);
+  hipLaunchKernelGGL(copy_rows_i32_kernel, grid, dim3(256), 0, st, src, scs, rows * width, dst, dcs);
+}
+
+}  // namespace dsir

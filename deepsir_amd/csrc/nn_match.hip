@@ -1,0 +1,185 @@
+// Fused nearest-descriptor search: for every src descriptor a_j the index of the
+// ref descriptor b_k minimising  ((-2 a_j.b_k) + |a_j|^2) + |b_k|^2  in fp32
+// (reference network/matchnet.py:96-113 square_distance_V2 + .min(dim=2)[1] at
+// network/model.py:558-569).  The reference materialises the [J,K] matrix in
+// 6000-row chunks; here it never leaves the MFMA accumulators.
+//
+// Block = 4 waves; wave w owns RT row tiles (16 src rows each) whose A fragments
+// (64 channels = 16 k-steps) stay in registers for the whole kernel.  Ref
+// descriptors stream through LDS in tiles of 64 columns ([col][64+2], the pad
+// makes fragment reads conflict free).  Per 16x16 tile: 16 exact-fp32 MFMAs
+// (v_mfma_f32_16x16x4_f32: a k-ordered fmaf chain, channels 0..63 ascending),
+// then 4 running (min, argmin) updates per lane.  The ref range is split over
+// blockIdx.y; partial results meet in a packed 64-bit atomicMin
+// (order-preserving distance bits << 32 | index), so ties go to the lower
+// index regardless of arrival order (deterministic).
+#include "kernels.h"
+#include "device_utils.h"
+
+namespace dsir {
+
+namespace {
+
+constexpr int BC = 64;        // ref columns per LDS tile
+constexpr int LDB = 64 + 2;   // padded row (floats)
+
+__device__ __forceinline__ unsigned int order_bits(float f) {
+  const unsigned int u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// |x|^2 of every descriptor row: one wave per 4 rows... (16 lanes per row, float4 each)
+__global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ x, int64_t rows, float* __restrict__ out) {
+  const int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int l = threadIdx.x & 15;
+  float s = 0.f;
+  if (row < rows) {
+    const float4 v = *reinterpret_cast<const float4*>(x + row * 64 + l * 4);
+    s = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
+  if (row < rows && l == 0) out[row] = s;
+}
+
+template <int RT>
+__global__ __launch_bounds__(256) void nn_match_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                       const float* __restrict__ sa, const float* __restrict__ sb,
+                                                       int J, int K, int cols_per_split,
+                                                       unsigned long long* __restrict__ packed) {
+  __shared__ float Bs[BC * LDB];
+  __shared__ float sbs[BC];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int pair = blockIdx.z;
+  const float* Ap = A + (int64_t)pair * J * 64;
+  const float* Bp = B + (int64_t)pair * K * 64;
+  const int row0 = (blockIdx.x * 4 + w) * (16 * RT);
+
+  // A fragments: lane holds A[row = fr][k = 4 s + fq]
+  float af[RT][16];
+  float san[RT][4];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    const int row = row0 + rt * 16 + fr;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) af[rt][s] = row < J ? Ap[(int64_t)row * 64 + 4 * s + fq] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int rr = row0 + rt * 16 + 4 * fq + r;
+      san[rt][r] = rr < J ? sa[(int64_t)pair * J + rr] : 0.f;
+    }
+  }
+  float best[RT][4];
+  int bidx[RT][4];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { best[rt][r] = INFINITY; bidx[rt][r] = 0x7fffffff; }
+
+  const int c_begin = blockIdx.y * cols_per_split;
+  const int c_end = min(K, c_begin + cols_per_split);
+  for (int c0 = c_begin; c0 < c_end; c0 += BC) {
+    // stage 64 ref rows: 1024 float4, 4 per thread, coalesced
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int f = tid + 256 * i;
+      const int r = f >> 4, c4 = f & 15;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c0 + r < c_end) v = *reinterpret_cast<const float4*>(Bp + (int64_t)(c0 + r) * 64 + c4 * 4);
+      float2* dst = reinterpret_cast<float2*>(&Bs[r * LDB + c4 * 4]);
+      dst[0] = make_float2(v.x, v.y);
+      dst[1] = make_float2(v.z, v.w);
+    }
+    if (tid < BC) sbs[tid] = (c0 + tid < c_end) ? sb[(int64_t)pair * K + c0 + tid] : 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < BC / 16; ++t) {
+      f32x4 acc[RT];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const float b = Bs[(16 * t + fr) * LDB + 4 * s + fq];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[rt][s], b, acc[rt], 0, 0, 0);
+      }
+      const int col = c0 + 16 * t + fr;
+      const float sbv = sbs[16 * t + fr];
+      if (col < c_end) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float d = __fadd_rn(__fadd_rn(-2.f * acc[rt][r], san[rt][r]), sbv);
+            if (d < best[rt][r]) { best[rt][r] = d; bidx[rt][r] = col; }
+          }
+      }
+    }
+    __syncthreads();
+  }
+  // reduce over the 16 lanes that share a row; ties -> lower column
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float d = best[rt][r];
+      int ix = bidx[rt][r];
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {
+        const float d2 = __shfl_xor(d, o);
+        const int i2 = __shfl_xor(ix, o);
+        if (d2 < d || (d2 == d && i2 < ix)) { d = d2; ix = i2; }
+      }
+      const int row = row0 + rt * 16 + 4 * fq + r;
+      if (fr == 0 && row < J && ix != 0x7fffffff) {
+        const unsigned long long key = ((unsigned long long)order_bits(d) << 32) | (unsigned int)ix;
+        atomicMin(packed + (int64_t)pair * J + row, key);
+      }
+    }
+}
+
+__global__ void unpack_idx_kernel(const unsigned long long* __restrict__ packed, int64_t n, int32_t* __restrict__ idx) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
+    idx[e] = (int32_t)(packed[e] & 0xffffffffull);
+}
+
+}  // namespace
+
+// scratch layout (floats): sa[pairs*J] | sb[pairs*K] | packed (u64)[pairs*J]
+size_t nn_match_scratch_bytes(int pairs, int J, int K) {
+  size_t f = ((size_t)pairs * J + (size_t)pairs * K + 3) & ~(size_t)3;
+  return f * 4 + (size_t)pairs * J * 8;
+}
+
+void launch_nn_match_ws(const float* a, const float* b, int pairs, int J, int K, int32_t* idx, void* scratch,
+                        hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
+  float* sa = reinterpret_cast<float*>(scratch);
+  float* sb = sa + (size_t)pairs * J;
+  size_t f = ((size_t)pairs * J + (size_t)pairs * K + 3) & ~(size_t)3;
+  unsigned long long* packed = reinterpret_cast<unsigned long long*>(sa + f);
+  const int64_t ra = (int64_t)pairs * J, rb = (int64_t)pairs * K;
+  hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)((ra + 15) / 16)), dim3(256), 0, st, a, ra, sa);
+  hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)((rb + 15) / 16)), dim3(256), 0, st, b, rb, sb);
+  hipMemsetAsync(packed, 0xff, (size_t)pairs * J * 8, st);
+  // geometry: 2 row tiles per wave once there is enough work to fill the chip
+  const int rows_small = 64, rows_big = 128;
+  const bool big = (int64_t)pairs * ((J + rows_big - 1) / rows_big) >= 512;
+  const int rows_per_block = big ? rows_big : rows_small;
+  const int rb_count = (J + rows_per_block - 1) / rows_per_block;
+  int splits = (int)((768 + (int64_t)pairs * rb_count - 1) / ((int64_t)pairs * rb_count));
+  const int max_splits = (K + BC - 1) / BC;
+  if (splits < 1) splits = 1;
+  if (splits > 16) splits = 16;
+  if (splits > max_splits) splits = max_splits;
+  int cols = (K + splits - 1) / splits;
+  cols = (cols + BC - 1) / BC * BC;
+  splits = (K + cols - 1) / cols;
+  dim3 grid(rb_count, splits, pairs);
+  if (ev0) hipEventRecord(ev0, st);
+  if (big) hipLaunchKernelGGL((nn_match_kernel<2>), grid, dim3(256), 0, st, a, b, sa, sb, J, K, cols, packed);
+  else     hipLaunchKernelGGL((nn_match_kernel<1>), grid, dim3(256), 0, st, a, b, sa, sb, J, K, cols, packed);
+  if (ev1) hipEventRecord(ev1, st);
+  hipLaunchKernelGGL(unpack_idx_kernel, dim3(256), dim3(256), 0, st, packed, ra, idx);
+}
+
+}  // namespace dsir

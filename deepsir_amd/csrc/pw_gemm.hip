@@ -1,0 +1,328 @@
+// Point-wise (1x1 conv) GEMM on exact-fp32 MFMA with fused prologue / epilogue.
+//
+//   Y[row][co] = sum_ci  A[row][ci] * W[co][ci]  (+ bias)
+//
+// rows are points (k = 1 layers) or (point, neighbour) pairs (k = 16 layers).
+// The A operand is never materialised in its final form:
+//   * the PRODUCER's GroupNorm (+LeakyReLU) is applied while staging A into LDS
+//     (producer wrote raw conv outputs + per-(cloud,group) sum / sum-sq),
+//   * channel concatenation, neighbour gather (torch.gather in the reference:
+//     tools.py:197-221, RandLANet.py:393-408) and the 10-channel relative
+//     position encoding (RandLANet.py:197-212) are address arithmetic in the loader.
+// Epilogues: raw store + GroupNorm statistics (MLP2D, RandLANet.py:58-107),
+// bias+LeakyReLU (Conv1d with folded eval-BatchNorm, RandLANet.py:34-55),
+// linear (+residual), row L2-normalise (model.py:233), and attentive pooling
+// (softmax over the 16 neighbours of a point + weighted sum, RandLANet.py:148-155).
+//
+// Tiling: 256 threads = 4 waves; block tile 64 rows x BN columns; wave w owns
+// rows [16w,16w+16) and all BN/16 column tiles (v_mfma_f32_16x16x4_f32, one A
+// fragment feeds BN/16 MFMAs).  K is walked in chunks of 16 channels staged in
+// LDS as [row][16+2] (the +2 pad makes the fragment reads bank-conflict free:
+// 18*r mod 32 is a permutation of the even banks for r = 0..15); the next
+// chunk's global loads are issued before the MFMAs of the current one.
+#include "kernels.h"
+#include "device_utils.h"
+
+namespace dsir {
+
+namespace {
+
+constexpr int BM = 64;
+constexpr int BK = 16;
+constexpr int LDT = BK + 2;
+constexpr int MAXC = 768;
+
+struct RowSrc {
+  int64_t o0, o1;  // element offsets of the source rows in seg0 / seg1 (-1: row out of range)
+};
+
+__device__ __forceinline__ RowSrc row_source(const GemmArgs& p, int cloud, int row) {
+  RowSrc r;
+  if (row >= p.M) { r.o0 = r.o1 = -1; return r; }
+  {
+    const Seg& s = p.seg[0];
+    int sr = s.idx ? s.idx[cloud * s.idx_cloud_stride + row] : row / s.row_div;
+    r.o0 = cloud * s.cloud_stride + (int64_t)sr * s.ld;
+  }
+  if (p.nseg > 1) {
+    const Seg& s = p.seg[1];
+    int sr = s.idx ? s.idx[cloud * s.idx_cloud_stride + row] : row / s.row_div;
+    r.o1 = cloud * s.cloud_stride + (int64_t)sr * s.ld;
+  } else {
+    r.o1 = -1;
+  }
+  return r;
+}
+
+// A[row][c] for A_SEGS with the producer's GroupNorm/activation applied.
+__device__ __forceinline__ float seg_elem(const GemmArgs& p, const RowSrc& r, int c, const float* sc, const float* sh) {
+  if (r.o0 < 0 || c >= p.Cin) return 0.f;
+  const int C0 = p.seg[0].C;
+  float x;
+  int act;
+  if (c < C0) { x = p.seg[0].x[r.o0 + c]; act = p.seg[0].act; }
+  else        { x = p.seg[1].x[r.o1 + (c - C0)]; act = p.seg[1].act; }
+  float v = fmaf(x, sc[c], sh[c]);
+  return (act && v < 0.f) ? 0.2f * v : v;
+}
+
+// Relative position encoding [|pj-pi|, pj-pi, pi, pj] (RandLANet.py:205-211).
+__device__ __forceinline__ float lse_elem(const GemmArgs& p, int cloud, int row, int c) {
+  if (row >= p.M || c >= 10) return 0.f;
+  const int i = row >> 4;
+  const int j = p.neigh[cloud * p.neigh_cloud_stride + row];
+  const float* pi = p.xyz + cloud * p.xyz_cloud_stride + (int64_t)i * 3;
+  const float* pj = p.xyz + cloud * p.xyz_cloud_stride + (int64_t)j * 3;
+  if (c >= 7) return pj[c - 7];
+  if (c >= 4) return pi[c - 4];
+  if (c >= 1) return __fsub_rn(pj[c - 1], pi[c - 1]);
+  float dx = __fsub_rn(pj[0], pi[0]), dy = __fsub_rn(pj[1], pi[1]), dz = __fsub_rn(pj[2], pi[2]);
+  float s = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+  return __fsqrt_rn(s);
+}
+
+template <int BN, int EPI, int AMODE>
+__global__ __launch_bounds__(256) void pw_gemm_kernel(const GemmArgs p) {
+  constexpr int NT = BN / 16;
+  __shared__ float As[BM * LDT];
+  __shared__ float Ws[BN * LDT];
+  __shared__ float s_sc[AMODE == A_SEGS ? MAXC : 1];
+  __shared__ float s_sh[AMODE == A_SEGS ? MAXC : 1];
+  __shared__ float s_red[EPI == EPI_GN ? 4 * BN * 2 : 1];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = tid >> 6;
+  const int cloud = blockIdx.z;
+  const int m0 = blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+
+  // ---- per-channel scale/shift of the producer's GroupNorm (consumer-side finalise)
+  if (AMODE == A_SEGS) {
+    for (int c = tid; c < p.Cin; c += 256) {
+      const Seg& s = (c < p.seg[0].C) ? p.seg[0] : p.seg[1];
+      const int lc = (c < p.seg[0].C) ? c : c - p.seg[0].C;
+      float scale = 1.f, shift = 0.f;
+      if (s.gn.stats) {
+        const int g = lc / (s.C / s.gn.groups);
+        const double* st = s.gn.stats + ((int64_t)cloud * s.gn.groups + g) * 2;
+        const double mean = st[0] * s.gn.inv_count;
+        double var = st[1] * s.gn.inv_count - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        const double rstd = 1.0 / sqrt(var + 1e-5);
+        const double sc = (double)s.gn.gamma[lc] * rstd;
+        scale = (float)sc;
+        shift = (float)((double)s.gn.beta[lc] - mean * sc);
+      }
+      s_sc[c] = scale;
+      s_sh[c] = shift;
+    }
+    __syncthreads();
+  }
+
+  // ---- staging assignment: thread -> channel (tid & 15) of rows (tid >> 4) + 16 i
+  const int kk = tid & 15;
+  const int r0 = tid >> 4;
+  RowSrc rs[4];
+  if (AMODE == A_SEGS) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rs[i] = row_source(p, cloud, m0 + r0 + 16 * i);
+  }
+
+  float ra[4];
+  float rw[NT];
+  auto load_chunk = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (AMODE == A_SEGS) ra[i] = seg_elem(p, rs[i], k0 + kk, s_sc, s_sh);
+      else                 ra[i] = lse_elem(p, cloud, m0 + r0 + 16 * i, k0 + kk);
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const int col = n0 + r0 + 16 * i;
+      const int k = k0 + kk;
+      rw[i] = (col < p.Cout && k < p.Cin) ? p.W[(int64_t)col * p.Cin + k] : 0.f;
+    }
+  };
+
+  f32x4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nchunks = (p.Cin + BK - 1) / BK;
+  load_chunk(0);
+  const int fr = lane & 15;   // fragment row / col
+  const int fq = lane >> 4;   // fragment k
+  for (int kc = 0; kc < nchunks; ++kc) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) As[(r0 + 16 * i) * LDT + kk] = ra[i];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) Ws[(r0 + 16 * i) * LDT + kk] = rw[i];
+    __syncthreads();
+    if (kc + 1 < nchunks) load_chunk((kc + 1) * BK);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const float a = As[(16 * w + fr) * LDT + 4 * s + fq];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const float b = Ws[(16 * t + fr) * LDT + 4 * s + fq];
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[t], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogues.  C layout: col = lane & 15, row = 4 * (lane >> 4) + reg.
+  const int rbase = m0 + 16 * w + 4 * fq;
+
+  if (EPI == EPI_GN) {
+    float* Y = p.Y + cloud * p.y_cloud_stride;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int col = n0 + 16 * t + fr;
+      const float bv = (p.bias && col < p.Cout) ? p.bias[col] : 0.f;
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = rbase + r;
+        if (row < p.M && col < p.Cout) {
+          const float v = acc[t][r] + bv;
+          Y[(int64_t)row * p.ldy + col] = v;
+          s1 += v;
+          s2 += v * v;
+        }
+      }
+      s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
+      s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
+      if (lane < 16) {
+        s_red[(w * BN + 16 * t + lane) * 2 + 0] = s1;
+        s_red[(w * BN + 16 * t + lane) * 2 + 1] = s2;
+      }
+    }
+    __syncthreads();
+    // column sums over the 4 waves, then one fp64 atomic per (group, block)
+    const int gw = p.Cout / p.groups_out;  // channels per group
+    if (tid < BN) {
+      float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+      for (int ww = 0; ww < 4; ++ww) { c1 += s_red[(ww * BN + tid) * 2]; c2 += s_red[(ww * BN + tid) * 2 + 1]; }
+      s_red[tid * 2] = c1;       // wave 0's slots are re-used (each thread touches only its own column)
+      s_red[tid * 2 + 1] = c2;
+    }
+    __syncthreads();
+    if (tid < BN && (tid % gw) == 0 && n0 + tid < p.Cout) {
+      double g1 = 0.0, g2 = 0.0;
+      for (int c = 0; c < gw && tid + c < BN; ++c) { g1 += (double)s_red[(tid + c) * 2]; g2 += (double)s_red[(tid + c) * 2 + 1]; }
+      double* st = p.stats_out + ((int64_t)cloud * p.groups_out + (n0 + tid) / gw) * 2;
+      atomicAdd(st, g1);
+      atomicAdd(st + 1, g2);
+    }
+  } else if (EPI == EPI_ACT || EPI == EPI_LINEAR) {
+    float* Y = p.Y + cloud * p.y_cloud_stride;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int col = n0 + 16 * t + fr;
+      const float bv = (p.bias && col < p.Cout) ? p.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = rbase + r;
+        if (row < p.M && col < p.Cout) {
+          float v = acc[t][r] + bv;
+          if (EPI == EPI_LINEAR && p.residual) v += p.residual[cloud * p.res_cloud_stride + (int64_t)row * p.ldres + col];
+          if (EPI == EPI_ACT && v < 0.f) v *= 0.2f;
+          Y[(int64_t)row * p.ldy + col] = v;
+        }
+      }
+    }
+  } else if (EPI == EPI_L2NORM) {
+    // requires BN == Cout (whole row in the block): x / max(||x||_2, 1e-12)  (F.normalize, model.py:233)
+    float* Y = p.Y + cloud * p.y_cloud_stride;
+    float ss[4] = {0.f, 0.f, 0.f, 0.f};
+    float v[NT][4];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int col = n0 + 16 * t + fr;
+      const float bv = (p.bias && col < p.Cout) ? p.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[t][r] = (col < p.Cout) ? acc[t][r] + bv : 0.f;
+        ss[r] += v[t][r] * v[t][r];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      ss[r] += __shfl_xor(ss[r], 1); ss[r] += __shfl_xor(ss[r], 2);
+      ss[r] += __shfl_xor(ss[r], 4); ss[r] += __shfl_xor(ss[r], 8);
+      const float den = fmaxf(__fsqrt_rn(ss[r]), 1e-12f);
+      const int row = rbase + r;
+      if (row < p.M) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int col = n0 + 16 * t + fr;
+          if (col < p.Cout) Y[(int64_t)row * p.ldy + col] = v[t][r] / den;
+        }
+      }
+    }
+  } else if (EPI == EPI_ATT) {
+    // One 16-row MFMA tile = the 16 neighbours of one point: softmax over rows
+    // per column, then sum_k f[k][c] * a[k][c]   (RandLANet.py:152-155).
+    const int point = (m0 + 16 * w) >> 4;
+    if (m0 + 16 * w < p.M) {
+      float* Y = p.Y + cloud * p.y_cloud_stride;
+      RowSrc er[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) er[r] = row_source(p, cloud, rbase + r);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int col = n0 + 16 * t + fr;
+        float mx = fmaxf(fmaxf(acc[t][0], acc[t][1]), fmaxf(acc[t][2], acc[t][3]));
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float e[4], se = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { e[r] = expf(acc[t][r] - mx); se += e[r]; }
+        se += __shfl_xor(se, 16); se += __shfl_xor(se, 32);
+        float o = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float f = seg_elem(p, er[r], col, s_sc, s_sh);
+          o += f * (e[r] / se);
+        }
+        o += __shfl_xor(o, 16); o += __shfl_xor(o, 32);
+        if (lane < 16 && col < p.Cout) Y[(int64_t)point * p.ldy + col] = o;
+      }
+    }
+  }
+}
+
+template <int BN, int EPI, int AMODE>
+void launch_t(const GemmArgs& a, hipStream_t st) {
+  dim3 grid((a.M + BM - 1) / BM, (a.Cout + BN - 1) / BN, a.clouds);
+  hipLaunchKernelGGL((pw_gemm_kernel<BN, EPI, AMODE>), grid, dim3(256), 0, st, a);
+}
+
+template <int EPI, int AMODE>
+void launch_bn(const GemmArgs& a, hipStream_t st) {
+  if (a.Cout <= 16) launch_t<16, EPI, AMODE>(a, st);
+  else if (a.Cout <= 32) launch_t<32, EPI, AMODE>(a, st);
+  else launch_t<64, EPI, AMODE>(a, st);
+}
+
+}  // namespace
+
+void launch_pw_gemm(const GemmArgs& a, hipStream_t st) {
+  if (a.M <= 0 || a.clouds <= 0) return;
+  if (a.amode == A_LSE) {
+    launch_bn<EPI_GN, A_LSE>(a, st);
+    return;
+  }
+  switch (a.epi) {
+    case EPI_GN: launch_bn<EPI_GN, A_SEGS>(a, st); break;
+    case EPI_ACT: launch_bn<EPI_ACT, A_SEGS>(a, st); break;
+    case EPI_LINEAR: launch_bn<EPI_LINEAR, A_SEGS>(a, st); break;
+    case EPI_L2NORM: launch_t<64, EPI_L2NORM, A_SEGS>(a, st); break;
+    case EPI_ATT: launch_bn<EPI_ATT, A_SEGS>(a, st); break;
+  }
+}
+
+}  // namespace dsir

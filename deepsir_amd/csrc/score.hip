@@ -1,0 +1,112 @@
+// Saliency score of every point (reference network/model.py:638-639 torch.max(logits),
+// :701-757 score_fun).  Two launches:
+//   1. per-point (prob,label) = max/argmax of the semantic logits + three
+//      per-cloud maxima (feature max, label-weight max, prob max) via wave
+//      reductions and order-preserving integer atomics;
+//   2. one wave per point, lane = feature channel: neighbour mean of the
+//      normalised feature (16 coalesced 256-B row gathers), softplus saliency,
+//      density gate, channel-max ratio, semantic weight, max over channels.
+#include "kernels.h"
+#include "device_utils.h"
+
+namespace dsir {
+
+namespace {
+
+__constant__ float c_label_weights[32] = {3, 1, 1, 3, 2, 0, 0, 0, 6, 5, 6, 4, 7, 7, 6, 8, 4, 9, 9,
+                                          0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // model.py:146-149
+
+constexpr float kEps = 1e-16f;  // model.py:18
+
+__global__ __launch_bounds__(256) void score_reduce_kernel(const float* __restrict__ feat, const float* __restrict__ logits,
+                                                           int ncls, int n, ScoreScratch s) {
+  const int cloud = blockIdx.y;
+  const float* F = feat + (int64_t)cloud * n * 64;
+  const float* L = logits + (int64_t)cloud * n * ncls;
+  float fmx = -INFINITY, lmx = -INFINITY, pmx = -INFINITY;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    float best = L[(int64_t)i * ncls];
+    int arg = 0;
+    for (int c = 1; c < ncls; ++c) {
+      const float v = L[(int64_t)i * ncls + c];
+      if (v > best) { best = v; arg = c; }   // first maximum wins, as torch.max on CPU
+    }
+    s.prob[(int64_t)cloud * n + i] = best;
+    s.label[(int64_t)cloud * n + i] = arg;
+    pmx = fmaxf(pmx, best);
+    lmx = fmaxf(lmx, c_label_weights[arg]);
+  }
+  const int64_t total = (int64_t)n * 64;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x)
+    fmx = fmaxf(fmx, F[e]);
+  fmx = wave_max(fmx); lmx = wave_max(lmx); pmx = wave_max(pmx);
+  if ((threadIdx.x & 63) == 0) {
+    float* r = s.red + cloud * 4;
+    atomic_max_float(r + 0, fmx);
+    atomic_max_float(r + 1, lmx);
+    atomic_max_float(r + 2, pmx);
+  }
+}
+
+__device__ __forceinline__ float softplus(float x) {  // F.softplus, beta = 1, threshold = 20
+  return x > 20.f ? x : log1pf(expf(x));
+}
+
+__global__ __launch_bounds__(256) void score_point_kernel(const float* __restrict__ feat, const float* __restrict__ xyz,
+                                                          int64_t xyz_cs, const int32_t* __restrict__ neigh,
+                                                          int64_t neigh_cs, int n, ScoreScratch s,
+                                                          float* __restrict__ score, int32_t* __restrict__ label_out) {
+  const int cloud = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const float* F = feat + (int64_t)cloud * n * 64;
+  const float* X = xyz + cloud * xyz_cs;
+  const int32_t* nb = neigh + cloud * neigh_cs + (int64_t)i * kKnn;
+  const float* red = s.red + cloud * 4;
+  const float fden = red[0] + kEps;
+  // 1. saliency
+  const float fn = F[(int64_t)i * 64 + lane] / fden;
+  float acc = 0.f;
+#pragma unroll
+  for (int k = 0; k < kKnn; ++k) acc += F[(int64_t)nb[k] * 64 + lane] / fden;
+  const float sal = softplus(fn - acc / 16.f);
+  // 2. density gate: mean neighbour distance < 2.0
+  float dist = 0.f;
+  if (lane < kKnn) {
+    const int j = nb[lane];
+    const float dx = __fsub_rn(X[(int64_t)j * 3], X[(int64_t)i * 3]);
+    const float dy = __fsub_rn(X[(int64_t)j * 3 + 1], X[(int64_t)i * 3 + 1]);
+    const float dz = __fsub_rn(X[(int64_t)j * 3 + 2], X[(int64_t)i * 3 + 2]);
+    dist = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
+  }
+  const float gate = (wave_sum(dist) / 16.f < 2.0f) ? 1.f : 0.f;
+  // 3. channel-wise max ratio
+  const float chan = fn / (wave_max(fn) + kEps);
+  // 4. semantic weight
+  const int lab = s.label[(int64_t)cloud * n + i];
+  float ls = c_label_weights[lab] / (red[1] + kEps);
+  const float pr = s.prob[(int64_t)cloud * n + i] / (red[2] + kEps);
+  ls = ls * (pr > 0.2f ? 1.f : 0.f);
+  // 5. total, max over channels
+  const float v = wave_max(((sal * gate) * chan) * ls);
+  if (lane == 0) {
+    score[(int64_t)cloud * n + i] = v;
+    if (label_out) label_out[(int64_t)cloud * n + i] = lab;
+  }
+}
+
+}  // namespace
+
+void launch_score(const float* feat, const float* logits, int ncls, const float* xyz, int64_t xyz_cs,
+                  const int32_t* neigh, int64_t neigh_cs, int clouds, int n, ScoreScratch s, float* score,
+                  int32_t* label_out, hipStream_t st) {
+  hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(s.red), 0xff800000u, (size_t)clouds * 4, st);  // -inf
+  int gx = (n + 255) / 256;
+  if (gx > 256) gx = 256;
+  hipLaunchKernelGGL(score_reduce_kernel, dim3(gx, clouds), dim3(256), 0, st, feat, logits, ncls, n, s);
+  hipLaunchKernelGGL(score_point_kernel, dim3((n + 3) / 4, clouds), dim3(256), 0, st, feat, xyz, xyz_cs, neigh, neigh_cs,
+                     n, s, score, label_out);
+}
+
+}  // namespace dsir

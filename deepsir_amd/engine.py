@@ -1,0 +1,263 @@
+"""Thin Python object over a ``dsir_ctx`` (include/dsir.h).
+
+PyTorch is used for device memory only: every method takes / returns
+``torch`` CUDA tensors and hands raw device pointers to the C ABI.  All
+compute is in libdsir.so; nothing here falls back to torch ops or the CPU.
+
+Activations crossing this boundary are point-major ``[clouds, n, C]``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from .arch import NetConfig, level_sizes
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _chk(t: torch.Tensor, dtype, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise EngineError(f"{name}: expected a CUDA tensor (the engine has no CPU path)")
+    if t.dtype != dtype:
+        raise EngineError(f"{name}: expected {dtype}, got {t.dtype}")
+    return t.contiguous()
+
+
+class Engine:
+    def __init__(self, cfg: NetConfig, device: int = 0, max_points: int = 8192, max_pairs: int = 1):
+        if cfg.use_ppf:
+            raise EngineError("use_ppf=True is outside the hot path (reference default is False)")
+        self.lib = _lib.load()
+        self.cfg = cfg
+        self.device = torch.device("cuda", device)
+        self.max_points, self.max_pairs = int(max_points), int(max_pairs)
+        c = _lib.dsir_cfg()
+        c.feat_len, c.num_knn, c.num_layers = cfg.feat_len, cfg.num_knn, len(cfg.d_out)
+        for i in range(4):
+            c.sub_sampling_ratio[i] = cfg.sub_sampling_ratio[i]
+            c.d_out[i] = cfg.d_out[i]
+        c.out_feat_dim, c.num_classes = cfg.out_feat_dim, cfg.num_classes
+        c.max_points, c.max_pairs = self.max_points, self.max_pairs
+        h = C.c_void_p()
+        if self.lib.dsir_create(device, C.byref(c), C.byref(h)) != 0:
+            raise EngineError("dsir_create: " + self.lib.dsir_last_error(None).decode())
+        self.h = h
+        self.weights_loaded = False
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.dsir_destroy(self.h)
+            self.h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ helpers
+    def _call(self, rc: int):
+        if rc != 0:
+            raise EngineError(self.lib.dsir_last_error(self.h).decode())
+
+    def _pre(self):
+        torch.cuda.current_stream(self.device).synchronize()
+
+    def sync(self):
+        self._call(self.lib.dsir_sync(self.h))
+
+    def _empty(self, shape, dtype=torch.float32):
+        return torch.empty(shape, dtype=dtype, device=self.device)
+
+    # ------------------------------------------------------------------ weights
+    def expected_keys(self):
+        n = self.lib.dsir_num_weights(self.h)
+        out = []
+        for i in range(n):
+            numel = C.c_int64()
+            out.append((self.lib.dsir_weight_name(self.h, i, C.byref(numel)).decode(), numel.value))
+        return out
+
+    def load_state_dict(self, sd: Dict[str, "np.ndarray | torch.Tensor"], strict: bool = True):
+        """Network.load_state_dict counterpart (reference test.py:614): strict key/shape checking."""
+        expected = [k for k, _ in self.expected_keys()]
+        missing = [k for k in expected if k not in sd]
+        unexpected = [k for k in sd if k not in set(expected)]
+        if strict and (missing or unexpected):
+            raise EngineError(f"Error(s) in loading state_dict: missing keys {missing[:5]}{'...' if len(missing) > 5 else ''}, "
+                              f"unexpected keys {unexpected[:5]}{'...' if len(unexpected) > 5 else ''}")
+        for k in expected:
+            if k not in sd:
+                continue
+            v = sd[k]
+            a = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+            if k.endswith("num_batches_tracked"):
+                self._call(self.lib.dsir_load_weight(self.h, k.encode(), None, None, 0))
+                continue
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            shape = (C.c_int64 * a.ndim)(*a.shape)
+            self._call(self.lib.dsir_load_weight(self.h, k.encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim))
+        self._call(self.lib.dsir_finalize_weights(self.h))
+        self.weights_loaded = True
+
+    # ------------------------------------------------------------------ stages
+    def pyramid_shapes(self, n: int) -> Tuple[int, int]:
+        nl = level_sizes(n, self.cfg.sub_sampling_ratio)
+        return sum(nl[:-1]), sum(nl[1:])
+
+    def narrow(self, t: torch.Tensor) -> torch.Tensor:
+        """int64 index tensor -> int32 (on device)."""
+        if t.dtype == torch.int32:
+            return t.contiguous()
+        t = _chk(t, torch.int64, "index tensor")
+        out = self._empty(t.shape, torch.int32)
+        self._pre()
+        self._call(self.lib.dsir_narrow_i64(self.h, _ptr(t), _ptr(out), t.numel()))
+        return out
+
+    def knn_pyramid(self, points: torch.Tensor):
+        """DataBase.nn_search counterpart.  points [clouds, n, >=3] ->
+        (xyz [c,S,3], neigh_idx [c,S,16] i32, sub_idx [c,S1,16] i32, interp_idx [c,S,1] i32)."""
+        points = _chk(points, torch.float32, "points")
+        c, n, stride = points.shape
+        S, S1 = self.pyramid_shapes(n)
+        xyz = self._empty((c, S, 3))
+        neigh = self._empty((c, S, 16), torch.int32)
+        sub = self._empty((c, S1, 16), torch.int32)
+        interp = self._empty((c, S, 1), torch.int32)
+        self._pre()
+        self._call(self.lib.dsir_knn_pyramid(self.h, _ptr(points), stride, c, n, _ptr(xyz), _ptr(neigh), _ptr(sub), _ptr(interp)))
+        self.sync()
+        return xyz, neigh, sub, interp
+
+    def randla_forward(self, which: str, features, xyz, neigh, sub, interp, want_logits=True):
+        """RandLA.forward counterpart -> (feat [c,n,64], logits [c,n,ncls])."""
+        features = _chk(features, torch.float32, "features")
+        c, n, cin = features.shape
+        w = {"feat_extractor": 0, "inlier_model": 1}[which]
+        ncls = self.cfg.num_classes if w == 0 else 1
+        feat = self._empty((c, n, 64))
+        logits = self._empty((c, n, ncls)) if want_logits else None
+        xyz, neigh, sub, interp = (_chk(xyz, torch.float32, "xyz"), _chk(neigh, torch.int32, "neigh_idx"),
+                                   _chk(sub, torch.int32, "sub_idx"), _chk(interp, torch.int32, "interp_idx"))
+        self._pre()
+        self._call(self.lib.dsir_randla_forward(self.h, w, _ptr(features), cin, c, n, _ptr(xyz), _ptr(neigh), _ptr(sub),
+                                                _ptr(interp), _ptr(feat), _ptr(logits)))
+        self.sync()
+        return feat, logits
+
+    def score(self, feat, logits, xyz_multi, neigh_multi):
+        """torch.max(logits) + score_fun counterpart -> (score [c,n], label [c,n] i32)."""
+        feat, logits = _chk(feat, torch.float32, "feat"), _chk(logits, torch.float32, "logits")
+        xyz_multi, neigh_multi = _chk(xyz_multi, torch.float32, "xyz"), _chk(neigh_multi, torch.int32, "neigh_idx")
+        c, n, _ = feat.shape
+        score = self._empty((c, n))
+        label = self._empty((c, n), torch.int32)
+        self._pre()
+        self._call(self.lib.dsir_score(self.h, _ptr(feat), _ptr(logits), _ptr(xyz_multi), xyz_multi.shape[1] * 3,
+                                       _ptr(neigh_multi), neigh_multi.shape[1] * 16, c, n, _ptr(score), _ptr(label)))
+        self.sync()
+        return score, label
+
+    def aggregate(self, xyz, feat0, score):
+        """One cloud-batch half of Network.aggregation -> desc [c,n,64]."""
+        xyz, feat0, score = _chk(xyz, torch.float32, "xyz"), _chk(feat0, torch.float32, "feat0"), _chk(score, torch.float32, "score")
+        c, n, _ = feat0.shape
+        desc = self._empty((c, n, 64))
+        self._pre()
+        self._call(self.lib.dsir_aggregate(self.h, _ptr(xyz), xyz.shape[1] * 3, _ptr(feat0), _ptr(score), c, n, _ptr(desc)))
+        self.sync()
+        return desc
+
+    def nn_match(self, desc_src, desc_ref, sync=True):
+        """match_features_V2 + min(dim=2)[1] counterpart -> idx [p,J] i32."""
+        desc_src, desc_ref = _chk(desc_src, torch.float32, "desc_src"), _chk(desc_ref, torch.float32, "desc_ref")
+        p, J, _ = desc_src.shape
+        K = desc_ref.shape[1]
+        idx = self._empty((p, J), torch.int32)
+        self._pre()
+        self._call(self.lib.dsir_nn_match(self.h, _ptr(desc_src), _ptr(desc_ref), p, J, K, _ptr(idx)))
+        if sync:
+            self.sync()
+        return idx
+
+    def kabsch(self, src, tgt, w):
+        """compute_rigid_transform_2 counterpart -> (T [p,3,4], invalid [p] i32)."""
+        src, tgt = _chk(src, torch.float32, "src"), _chk(tgt, torch.float32, "tgt")
+        w = _chk(w.reshape(w.shape[0], -1), torch.float32, "weights")
+        p, m, _ = src.shape
+        T = self._empty((p, 3, 4))
+        bad = self._empty((p,), torch.int32)
+        self._pre()
+        self._call(self.lib.dsir_kabsch(self.h, _ptr(src), _ptr(tgt), _ptr(w), p, m, _ptr(T), _ptr(bad)))
+        self.sync()
+        return T, bad
+
+    # ------------------------------------------------------------------ the whole path
+    def register(self, points_src, points_ref, n_iter: int = 5, pyramids: Optional[dict] = None,
+                 forced_idx: Optional[torch.Tensor] = None, want_aux: bool = True, sync: bool = True, out: Optional[dict] = None):
+        """forward_align_4 counterpart for P pairs.
+
+        points_* [P, N, feat_len].  pyramids: optional dict with the reference's
+        data-dict keys (points_{src,ref}_{xyz,neigh_idx,sub_idx,interp_idx}),
+        int32 or int64.  Returns dict(transforms [P,n_iter,3,4], idx [n_iter,P,J],
+        logits [n_iter,P,J], pt_ref_new [P,J,3], invalid [P])."""
+        points_src, points_ref = _chk(points_src, torch.float32, "points_src"), _chk(points_ref, torch.float32, "points_ref")
+        P, J, cin = points_src.shape
+        K = points_ref.shape[1]
+        if cin != self.cfg.feat_len or points_ref.shape[2] != cin:
+            raise EngineError(f"points have {cin} channels, engine was built for feat_len={self.cfg.feat_len}")
+        b = _lib.dsir_pair_batch()
+        b.pairs, b.n_src, b.n_ref = P, J, K
+        b.points_src, b.points_ref = _ptr(points_src), _ptr(points_ref)
+        keep = []
+        if pyramids is not None:
+            for side, fld in (("src", "src"), ("ref", "ref")):
+                x = _chk(pyramids[f"points_{side}_xyz"], torch.float32, "xyz")
+                nb = self.narrow(pyramids[f"points_{side}_neigh_idx"])
+                sb = self.narrow(pyramids[f"points_{side}_sub_idx"])
+                ip = self.narrow(pyramids[f"points_{side}_interp_idx"])
+                keep += [x, nb, sb, ip]
+                setattr(b, fld + "_xyz", _ptr(x)); setattr(b, fld + "_neigh", _ptr(nb))
+                setattr(b, fld + "_sub", _ptr(sb)); setattr(b, fld + "_interp", _ptr(ip))
+        if forced_idx is not None:
+            forced_idx = _chk(forced_idx, torch.int32, "forced_idx")
+            assert tuple(forced_idx.shape) == (n_iter, P, J)
+            b.forced_idx = _ptr(forced_idx)
+        if out is None:
+            out = {"transforms": self._empty((P, n_iter, 3, 4))}
+            if want_aux:
+                out["idx"] = self._empty((n_iter, P, J), torch.int32)
+                out["logits"] = self._empty((n_iter, P, J))
+                out["pt_ref_new"] = self._empty((P, J, 3))
+                out["invalid"] = self._empty((P,), torch.int32)
+        r = _lib.dsir_pair_result()
+        r.transforms = _ptr(out["transforms"])
+        r.idx, r.logits = _ptr(out.get("idx")), _ptr(out.get("logits"))
+        r.pt_ref_new, r.invalid = _ptr(out.get("pt_ref_new")), _ptr(out.get("invalid"))
+        self._pre()
+        self._call(self.lib.dsir_register(self.h, C.byref(b), n_iter, C.byref(r)))
+        if sync:
+            self.sync()
+        out["_keep"] = keep
+        return out
+
+    # ------------------------------------------------------------------ measurement hooks
+    def enable_match_timer(self, on=True):
+        self._call(self.lib.dsir_enable_match_timer(self.h, 1 if on else 0))
+
+    def match_timer(self, reset=True):
+        ms, n = C.c_double(), C.c_int64()
+        self._call(self.lib.dsir_match_timer(self.h, 1 if reset else 0, C.byref(ms), C.byref(n)))
+        return ms.value, n.value

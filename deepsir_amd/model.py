@@ -1,0 +1,112 @@
+"""Drop-in for the reference's ``network.model.Network`` (align pipeline).
+
+Keeps the reference's host API verbatim (reference network/model.py:119-195,
+:297-298, :520-607; test.py:609-614):
+
+    net = Network(args); net.load_state_dict(torch.load(p)['state_dict'])
+    net.to(device); net.eval()
+    transforms, endpoints = net(data, (num_reg_iter, clip_weight))
+
+but everything inside ``forward`` runs in libdsir.so (hand-written HIP for
+gfx950) through the C ABI of include/dsir.h.  The module holds the
+checkpoint tensors as buffers under the reference's key names so that
+``state_dict()`` / ``load_state_dict()`` round-trip a reference checkpoint.
+There is no CPU path: calling it without the built library or without a GPU
+raises.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .arch import NetConfig, network_specs
+from .engine import Engine, EngineError
+
+_PYR_KEYS = ("xyz", "neigh_idx", "sub_idx", "interp_idx")
+
+
+class _Node(nn.Module):
+    """Name-space node of the checkpoint tree (no computation)."""
+
+
+def _attach(root: nn.Module, dotted: str, tensor: torch.Tensor):
+    parts = dotted.split(".")
+    m = root
+    for p in parts[:-1]:
+        if p not in m._modules:
+            m.add_module(p, _Node())
+        m = m._modules[p]
+    m.register_buffer(parts[-1], tensor)
+
+
+class Network(nn.Module):
+    def __init__(self, args):
+        super().__init__()
+        self.cfg = NetConfig.from_args(args)
+        self.pipeline = self.cfg.pipeline
+        if self.pipeline != "align":
+            raise NotImplementedError("only pipeline='align' (forward_align_4) is on the accelerated path")
+        if self.cfg.num_sub > 0:
+            raise NotImplementedError("num_sub > 0 (top-k sub-selection) is outside the accelerated path")
+        self.num_sub, self.num_knn, self.d_out = self.cfg.num_sub, self.cfg.num_knn, self.cfg.out_feat_dim
+        self.clip_weight_thresh = getattr(args, "clip_weight_thresh", 0.0)
+        for spec in network_specs(self.cfg):
+            dtype = torch.int64 if spec.kind == "bn_count" else torch.float32
+            _attach(self, spec.name, torch.zeros(spec.shape, dtype=dtype))
+        self._engine: Optional[Engine] = None
+        self._dirty = True
+        self._max_points = 0
+        self._max_pairs = 0
+
+    # ---- checkpoint plumbing
+    def load_state_dict(self, state_dict, strict: bool = True):
+        r = super().load_state_dict(state_dict, strict=strict)
+        self._dirty = True
+        return r
+
+    def _device_index(self) -> int:
+        dev = next(self.buffers()).device
+        if dev.type != "cuda":
+            raise EngineError("Network is on the CPU: this engine has no CPU path; call .to('cuda') / .cuda() first")
+        return dev.index or 0
+
+    def _ensure_engine(self, n_points: int, pairs: int) -> Engine:
+        dev = self._device_index()
+        if self._engine is None or n_points > self._max_points or pairs > self._max_pairs:
+            if self._engine is not None:
+                self._engine.close()
+            self._max_points = max(self._max_points, n_points, 1024)
+            self._max_pairs = max(self._max_pairs, pairs)
+            self._engine = Engine(self.cfg, dev, self._max_points, self._max_pairs)
+            self._dirty = True
+        if self._dirty:
+            self._engine.load_state_dict({k: v for k, v in self.state_dict().items()})
+            self._dirty = False
+        return self._engine
+
+    # ---- forward = forward_align_4
+    @torch.no_grad()
+    def forward(self, data: Dict[str, torch.Tensor], opt=None):
+        num_reg_iter, _clip_weight = opt  # clip_weight is ignored by the reference too (model.py:581-582)
+        src, ref = data["points_src"], data["points_ref"]
+        B, J, _ = src.shape
+        K = ref.shape[1]
+        eng = self._ensure_engine(max(J, K), B)
+        have = all(f"points_{s}_{k}" in data for s in ("src", "ref") for k in _PYR_KEYS)
+        pyr = {f"points_{s}_{k}": data[f"points_{s}_{k}"] for s in ("src", "ref") for k in _PYR_KEYS} if have else None
+        out = eng.register(src.float(), ref.float(), int(num_reg_iter), pyramids=pyr)
+        transforms: List[torch.Tensor] = [out["transforms"][:, i].contiguous() for i in range(num_reg_iter)]
+        idx_cpu = out["idx"].cpu()
+        ar = torch.arange(J, dtype=torch.int32)[None, :, None].expand(B, J, 1)
+        endpoints = {
+            "pt_src": src[:, :, :3].contiguous(),
+            "pt_ref": ref[:, :, :3].contiguous(),
+            "perm_matrices": [out["logits"][i] for i in range(num_reg_iter)],
+            "pred_pairs": [torch.cat([ar, idx_cpu[i][:, :, None]], dim=2) for i in range(num_reg_iter)],
+            "invalid_gradient": bool(out["invalid"].any().item()),
+            "pt_ref_new": out["pt_ref_new"],
+        }
+        return transforms, endpoints

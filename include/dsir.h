@@ -1,0 +1,169 @@
+/*
+ * dsir.h — C ABI of the MI355X-native registration engine (libdsir.so).
+ *
+ * Drop-in boundary for the hot path of LeoQLi/DeepSIR.  Every
+ * entry point names the reference interface it replaces (file:line into the
+ * reference tree).  Plain pointers and sizes only; no torch types.
+ *
+ * Conventions
+ *   - All tensor pointers are DEVICE pointers (HBM) unless a parameter says
+ *     "host".  Calls are asynchronous on the context's HIP stream
+ *     (dsir_stream) unless documented otherwise; dsir_sync waits for it.
+ *   - Activations are POINT-MAJOR: a feature tensor is [clouds][points][C]
+ *     fp32 (the reference is channel-major [B,C,N]; the Python wrapper
+ *     transposes where it returns such tensors to the caller).
+ *   - Indices are int32 on this side (the reference's int64 index tensors are
+ *     narrowed with dsir_narrow_i64).
+ *   - A "cloud batch" is a set of clouds with the same point count; src and
+ *     ref clouds of P pairs are 2P clouds for the shared feature extractor.
+ *   - Return value: 0 on success, non-zero on error; the message is then
+ *     available from dsir_last_error.  A degenerate Kabsch covariance is NOT
+ *     an error: identity is returned and the pair's invalid flag is set
+ *     (reference network/model.py:61-64).
+ *   - A context is not thread-safe: one context per (thread, device).
+ */
+#ifndef DSIR_H
+#define DSIR_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSIR_MAX_LEVELS 4
+#define DSIR_KNN 16
+
+typedef struct dsir_ctx dsir_ctx;
+
+/* The args fields the path reads: reference arguments.py:27-82,
+ * network/model.py:122-126, network/RandLANet.py:240-247. */
+typedef struct dsir_cfg {
+  int32_t feat_len;                       /* 3 (xyz) or 4 (xyz+reflectance)   */
+  int32_t num_knn;                        /* must be 16                        */
+  int32_t num_layers;                     /* must be 4                         */
+  int32_t sub_sampling_ratio[DSIR_MAX_LEVELS];
+  int32_t d_out[DSIR_MAX_LEVELS];         /* 16,64,128,256                     */
+  int32_t out_feat_dim;                   /* 64                                */
+  int32_t num_classes;                    /* 19 (semantic head of feat_extractor) */
+  int32_t max_points;                     /* workspace sizing: points per cloud */
+  int32_t max_pairs;                      /* workspace sizing: pairs per call   */
+} dsir_cfg;
+
+/* ---- lifecycle ------------------------------------------------------------ */
+
+/* Replaces Network.__init__ + .to(device) (network/model.py:119-195, test.py:609-611). */
+int dsir_create(int device, const dsir_cfg* cfg, dsir_ctx** out);
+void dsir_destroy(dsir_ctx* ctx);
+const char* dsir_last_error(const dsir_ctx* ctx);   /* ctx may be NULL: creation errors */
+/* The HIP stream (hipStream_t) every call is ordered on. */
+void* dsir_stream(dsir_ctx* ctx);
+int dsir_sync(dsir_ctx* ctx);
+int dsir_num_weights(const dsir_ctx* ctx);
+/* i-th expected state-dict key and its element count (for host-side validation). */
+const char* dsir_weight_name(const dsir_ctx* ctx, int i, int64_t* numel);
+
+/* Replaces Network.load_state_dict (test.py:614): called once per state-dict
+ * key with a HOST fp32 pointer; the engine copies.  Unknown keys and shape
+ * mismatches are errors (strict loading); '*.num_batches_tracked' is accepted
+ * and ignored.  dsir_finalize_weights folds eval-mode BatchNorm1d into the
+ * preceding Conv1d (RandLANet.py:34-55) and uploads everything; it fails if a
+ * key is missing. */
+int dsir_load_weight(dsir_ctx* ctx, const char* key, const float* host_data, const int64_t* shape, int ndim);
+int dsir_finalize_weights(dsir_ctx* ctx);
+
+/* ---- stage entry points (each mirrors one reference operator) ------------- */
+
+/* torch int64 index tensor -> int32 (device to device). */
+int dsir_narrow_i64(dsir_ctx* ctx, const int64_t* src, int32_t* dst, int64_t n);
+
+/* Replaces DataBase.nn_search (dataloader/data_base.py:153-183) incl. the
+ * third-party torch_points_kernels.knn: 4-level KNN pyramid of `clouds`
+ * clouds of n points each.  points: [clouds][n][stride] fp32, xyz in the
+ * first three columns.
+ * Outputs (per cloud, levels concatenated; S = sum n_l, S1 = sum n_{l+1}):
+ *   xyz_multi [clouds][S][3] f32, neigh_idx [clouds][S][16] i32,
+ *   sub_idx [clouds][S1][16] i32, interp_idx [clouds][S] i32.
+ * Tie rule: (fp32 squared distance, then lower index) — oracle/knn.py. */
+int dsir_knn_pyramid(dsir_ctx* ctx, const float* points, int stride, int clouds, int n,
+                     float* xyz_multi, int32_t* neigh_idx, int32_t* sub_idx, int32_t* interp_idx);
+
+/* Replaces RandLA.forward (network/RandLANet.py:311-372).
+ * which: 0 = feat_extractor (Cin = feat_len, num_classes logits),
+ *        1 = inlier_model   (Cin = 6, 1 logit).
+ * features [clouds][n][cin]; pyramids as produced by dsir_knn_pyramid.
+ * Outputs: feat [clouds][n][64], logits [clouds][n][ncls] (either may be NULL). */
+int dsir_randla_forward(dsir_ctx* ctx, int which, const float* features, int cin, int clouds, int n,
+                        const float* xyz_multi, const int32_t* neigh_idx, const int32_t* sub_idx,
+                        const int32_t* interp_idx, float* feat, float* logits);
+
+/* Replaces torch.max(logits,1) + Network.feat_score/score_fun with num_sub<=0
+ * (network/model.py:638-644, :668-757).
+ * feat [clouds][n][64], logits [clouds][n][ncls], xyz [clouds][n][3],
+ * neigh_idx = level-0 rows of the pyramid with row stride `neigh_stride` ints
+ * between clouds.  Outputs: score [clouds][n] f32, label [clouds][n] i32 (may be NULL). */
+int dsir_score(dsir_ctx* ctx, const float* feat, const float* logits, const float* xyz, int64_t xyz_cloud_stride,
+               const int32_t* neigh_idx, int64_t neigh_cloud_stride, int clouds, int n, float* score, int32_t* label);
+
+/* Replaces one cloud's half of Network.aggregation (network/model.py:209-235):
+ * desc = normalize(mlp_proj(mlp_feat(feat0) + mlp_att([xyz; score]))).
+ * xyz [clouds][n][3], feat0 [clouds][n][64], score [clouds][n] -> desc [clouds][n][64]. */
+int dsir_aggregate(dsir_ctx* ctx, const float* xyz, int64_t xyz_cloud_stride, const float* feat0, const float* score,
+                   int clouds, int n, float* desc);
+
+/* Replaces match_features_V2 + min(dim=2)[1] incl. the 6000-row chunking
+ * (network/matchnet.py:96-144, network/model.py:558-569): for every src
+ * descriptor the index of the nearest ref descriptor, distance evaluated as
+ * fp32 ((-2 a.b) + |a|^2) + |b|^2, ties to the lower index.
+ * desc_src [pairs][J][64], desc_ref [pairs][K][64] -> idx [pairs][J] i32. */
+int dsir_nn_match(dsir_ctx* ctx, const float* desc_src, const float* desc_ref, int pairs, int J, int K, int32_t* idx);
+
+/* Replaces compute_rigid_transform_2 (network/model.py:22-66): weighted
+ * Kabsch with fp64 3x3 SVD on device.  src/tgt [pairs][m][3], w [pairs][m]
+ * -> T [pairs][3][4] f32, invalid [pairs] i32 (1 = non-finite covariance,
+ * identity returned). */
+int dsir_kabsch(dsir_ctx* ctx, const float* src, const float* tgt, const float* w, int pairs, int m,
+                float* T, int32_t* invalid);
+
+/* ---- the whole path -------------------------------------------------------- */
+
+typedef struct dsir_pair_batch {
+  int32_t pairs;                 /* P */
+  int32_t n_src, n_ref;          /* J, K points per cloud */
+  const float* points_src;       /* [P][J][feat_len] */
+  const float* points_ref;       /* [P][K][feat_len] */
+  /* Optional caller-supplied pyramids (reference data dict keys
+   * points_{src,ref}_{xyz,neigh_idx,sub_idx,interp_idx}, data_base.py:178-181),
+   * already int32.  All NULL => built on device (dsir_knn_pyramid). */
+  const float* src_xyz;   const int32_t* src_neigh;   const int32_t* src_sub;   const int32_t* src_interp;
+  const float* ref_xyz;   const int32_t* ref_neigh;   const int32_t* ref_sub;   const int32_t* ref_interp;
+  /* Optional teacher forcing (tests): correspondences per iteration [n_iter][P][J] i32. */
+  const int32_t* forced_idx;
+} dsir_pair_batch;
+
+typedef struct dsir_pair_result {
+  float* transforms;     /* [P][n_iter][3][4] cumulative src->ref (model.py:595)        required */
+  int32_t* idx;          /* [n_iter][P][J] arg-min correspondences (pred_pairs[...,1])   or NULL  */
+  float* logits;         /* [n_iter][P][J] inlier logits (endpoints['perm_matrices'])    or NULL  */
+  float* pt_ref_new;     /* [P][J][3] matched ref points of the last iteration           or NULL  */
+  int32_t* invalid;      /* [P] OR over iterations (endpoints['invalid_gradient'])       or NULL  */
+} dsir_pair_result;
+
+/* Replaces Network.forward -> forward_align_4 (network/model.py:297-298,
+ * :520-607) for P independent pairs in one call: KNN pyramids (if not
+ * supplied), 2x feature RandLA + score, then n_iter x {aggregation, NN match,
+ * inlier RandLA, weighted Kabsch, SE(3) update}. */
+int dsir_register(dsir_ctx* ctx, const dsir_pair_batch* in, int n_iter, const dsir_pair_result* out);
+
+/* Test/measurement hooks. */
+/* Wall-clock-free kernel timing of the dominant kernel (nn_match) accumulated
+ * with HIP events on the engine stream since the last reset: total ms and
+ * launch count. */
+int dsir_match_timer(dsir_ctx* ctx, int reset, double* total_ms, int64_t* launches);
+int dsir_enable_match_timer(dsir_ctx* ctx, int enable);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSIR_H */

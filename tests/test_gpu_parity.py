@@ -1,0 +1,320 @@
+"""GPU parity tests: the HIP engine (through the C ABI of include/dsir.h) against
+the CPU oracle and against the golden fixtures captured from the imported
+reference.  Run on the MI355X box with ``pytest -m gpu``.
+
+Tolerances (BASELINE.json north_star): (R, t) within 1e-4 rad / 1e-4 m of the
+reference on identical inputs.  Index/integer work (KNN pyramid) is bit-exact.
+Per-stage float tensors are compared at rtol/atol 2e-4 against values of O(1)
+(fp32 summation-order noise of ~35 chained layers).
+"""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLD, build_case, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU (run with -m 'not gpu' on CPU-only hosts)")
+    return torch.device("cuda", 0)
+
+
+_ENGINES = {}
+
+
+def engine_for(cfg, sd, key, max_points=8192, max_pairs=2):
+    from deepsir_amd.engine import Engine
+    k = (key, cfg.feat_len, max_points, max_pairs)
+    if k not in _ENGINES:
+        e = Engine(cfg, 0, max_points=max_points, max_pairs=max_pairs)
+        e.load_state_dict(sd)
+        _ENGINES[k] = e
+    return _ENGINES[k]
+
+
+def cu(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(_dev())
+
+
+def rot_angle(Ra, Rb):
+    """Rounding-robust rotation distance (rad): |vee(skew(Ra^T Rb))| in fp64."""
+    D = Ra.astype(np.float64).T @ Rb.astype(np.float64)
+    v = 0.5 * np.array([D[2, 1] - D[1, 2], D[0, 2] - D[2, 0], D[1, 0] - D[0, 1]])
+    s = np.linalg.norm(v)
+    c = 0.5 * (np.trace(D) - 1.0)
+    return float(np.arctan2(s, c))
+
+
+def assert_pose_close(T, Tref, tol_rad=1e-4, tol_m=1e-4, msg=""):
+    T, Tref = np.asarray(T), np.asarray(Tref)
+    for t, r in zip(T.reshape(-1, 3, 4), Tref.reshape(-1, 3, 4)):
+        a = rot_angle(t[:, :3], r[:, :3])
+        d = float(np.linalg.norm(t[:, 3].astype(np.float64) - r[:, 3].astype(np.float64)))
+        assert a < tol_rad and d < tol_m, f"{msg} rot diff {a:.3e} rad, trans diff {d:.3e} m"
+
+
+# --------------------------------------------------------------------------- KNN pyramid (bit-exact)
+@pytest.mark.parametrize("n,seed", [(1024, 0), (1100, 1), (2048, 2), (4999, 3), (5000, 4)])
+def test_knn_pyramid_bit_exact(n, seed):
+    from deepsir_amd.arch import NetConfig
+    from deepsir_amd.weights import generate_state_dict
+    from oracle.knn import knn_pyramid
+    cfg = NetConfig(feat_len=3)
+    eng = engine_for(cfg, generate_state_dict(cfg, 0), "w0")
+    rng = np.random.default_rng(seed)
+    pts = rng.uniform(0, 3, (2, n, 4)).astype(np.float32)
+    pts[0, 7:12, :3] = pts[0, 3, :3]          # duplicates -> exact distance ties (padded clouds have them)
+    pts[1, n // 2, :3] = pts[1, 0, :3]
+    xyz, neigh, sub, interp = eng.knn_pyramid(cu(pts))
+    for c in range(2):
+        ref = knn_pyramid(pts[c], 16, cfg.sub_sampling_ratio)
+        assert np.array_equal(xyz[c].cpu().numpy(), ref["xyz"])
+        assert np.array_equal(neigh[c].cpu().numpy(), ref["neigh_idx"])
+        assert np.array_equal(sub[c].cpu().numpy(), ref["sub_idx"])
+        assert np.array_equal(interp[c].cpu().numpy(), ref["interp_idx"])
+
+
+def test_knn_rejects_small_cloud():
+    from deepsir_amd.arch import NetConfig
+    from deepsir_amd.engine import EngineError
+    from deepsir_amd.weights import generate_state_dict
+    cfg = NetConfig(feat_len=3)
+    eng = engine_for(cfg, generate_state_dict(cfg, 0), "w0")
+    with pytest.raises(EngineError):
+        eng.knn_pyramid(cu(np.zeros((1, 512, 3), np.float32)))
+
+
+# --------------------------------------------------------------------------- stage parity on the golden stage cases
+@pytest.mark.parametrize("name", ["stage_n1024_s1", "stage_n1024_s2_sep"])
+def test_stages_vs_oracle_and_golden(name):
+    from oracle.network import OracleNet, to_torch
+    torch.set_num_threads(1)
+    g, m, cfg, sd, data = build_case(name)
+    eng = engine_for(cfg, sd, name)
+    net = OracleNet(cfg, sd)
+    d = to_torch(data)
+    N = m["n"]
+    # ---- RandLA.forward (feature extractor), src and ref as one batch of two clouds
+    feats = cu(np.concatenate([data["points_src"], data["points_ref"]], 0))
+    xyz = cu(np.concatenate([data["points_src_xyz"], data["points_ref_xyz"]], 0))
+    neigh = cu(np.concatenate([data["points_src_neigh_idx"], data["points_ref_neigh_idx"]], 0), torch.int32)
+    sub = cu(np.concatenate([data["points_src_sub_idx"], data["points_ref_sub_idx"]], 0), torch.int32)
+    interp = cu(np.concatenate([data["points_src_interp_idx"], data["points_ref_interp_idx"]], 0), torch.int32)
+    feat, logits = eng.randla_forward("feat_extractor", feats, xyz, neigh, sub, interp)
+    f_s, x_s, lab_s, sc_s, f_r, x_r, lab_r, sc_r = net.forward_pair(d)
+    feat_np = feat.cpu().numpy()
+    np.testing.assert_allclose(feat_np[0].T, g["feat_src"][0], rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(feat_np[1].T, g["feat_ref"][0], rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(feat_np[0].T, f_s[0].numpy(), rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(logits[0].cpu().numpy().T, g["logits_src"][0], rtol=2e-4, atol=2e-4)
+    # ---- score_fun: teacher-forced on the reference's feat/logits
+    _, _, lg_r = net.randla("feat_extractor", d["points_ref"], d["points_ref_xyz"], d["points_ref_neigh_idx"],
+                            d["points_ref_sub_idx"], d["points_ref_interp_idx"])
+    feat_ref_in = cu(np.stack([g["feat_src"][0].T, g["feat_ref"][0].T]))
+    logit_in = cu(np.stack([g["logits_src"][0].T, lg_r[0].numpy().T]))
+    score, label = eng.score(feat_ref_in, logit_in, xyz, neigh)
+    np.testing.assert_allclose(score[0].cpu().numpy(), g["score_src"][0], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(score[1].cpu().numpy(), g["score_ref"][0], rtol=1e-4, atol=1e-6)
+    assert np.array_equal(label[0].cpu().numpy().astype(np.int8), g["label_src"][0, 0])
+    assert np.array_equal(label[1].cpu().numpy().astype(np.int8), g["label_ref"][0, 0])
+    # ---- aggregation: teacher-forced inputs
+    sc_in = cu(np.stack([g["score_src"][0], g["score_ref"][0]]))
+    desc = eng.aggregate(xyz[:, :N].contiguous(), feat_ref_in, sc_in)
+    np.testing.assert_allclose(desc[0].cpu().numpy().T, g["desc_src0"][0], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(desc[1].cpu().numpy().T, g["desc_ref0"][0], rtol=1e-4, atol=2e-5)
+    # ---- nearest-descriptor match on the reference's own descriptors
+    ds, dr = torch.from_numpy(g["desc_src0"]), torch.from_numpy(g["desc_ref0"])
+    idx = eng.nn_match(cu(g["desc_src0"][0].T[None]), cu(g["desc_ref0"][0].T[None]))[0].cpu().numpy()
+    ref_idx = g["idx0_direct"][0].astype(np.int64)
+    bad = np.nonzero(idx != ref_idx)[0]
+    if len(bad):   # every disagreeing row must be a near tie in fp64
+        best, second, _ = OracleNet.nn_gap(ds, dr)
+        d64 = -2 * (ds.double()[0].T @ dr.double()[0]) + (ds.double()[0] ** 2).sum(0)[:, None] + (dr.double()[0] ** 2).sum(0)[None]
+        for r in bad:
+            assert abs(float(d64[r, idx[r]] - d64[r, ref_idx[r]])) < 1e-6, f"row {r}: not a tie"
+    assert len(bad) <= 0.005 * len(idx)
+    # ---- inlier RandLA, teacher-forced on the reference's iteration-0 correspondences
+    i0 = g["idx"][0, 0].astype(np.int64)
+    cat = np.concatenate([data["points_src_xyz"][0, :N], data["points_ref_xyz"][0, :N][i0]], 1)[None]
+    _, lg_in = eng.randla_forward("inlier_model", cu(cat), xyz[:1], neigh[:1], sub[:1], interp[:1])
+    np.testing.assert_allclose(lg_in[0, :, 0].cpu().numpy(), g["inlier_logit0"][0, 0], rtol=5e-4, atol=5e-4)
+    # ---- Kabsch on the reference's weights
+    w = 1.0 / (1.0 + np.exp(-g["inlier_logit0"][0, 0].astype(np.float64)))
+    T, badflag = eng.kabsch(cu(data["points_src_xyz"][:, :N]), cu(data["points_ref_xyz"][:, :N][:, i0]),
+                            cu(w[None].astype(np.float32)))
+    assert_pose_close(T.cpu().numpy(), g["kabsch_T0"], 2e-6, 2e-6, "kabsch")
+    assert int(badflag[0]) == 0
+
+
+def test_kabsch_golden_cases():
+    from deepsir_amd.arch import NetConfig
+    from deepsir_amd.weights import generate_state_dict
+    cfg = NetConfig(feat_len=3)
+    eng = engine_for(cfg, generate_state_dict(cfg, 0), "w0")
+    g = np.load(GOLD + "/kabsch_cases.npz")
+    names = sorted({k[:-4] for k in g.files if k.endswith("_src")})
+    for n in names:
+        T, bad = eng.kabsch(cu(g[n + "_src"]), cu(g[n + "_tgt"]), cu(g[n + "_w"][..., 0]))
+        assert bool(bad.any().item()) == bool(g[n + "_invalid"]), n
+        assert_pose_close(T.cpu().numpy(), g[n + "_T"], 5e-6, 5e-6, n)
+        R = T.cpu().numpy()[:, :, :3].astype(np.float64)
+        assert np.all(np.linalg.det(R) > 0.999), n
+
+
+# --------------------------------------------------------------------------- whole path
+@pytest.mark.parametrize("name", ["stage_n1024_s1", "stage_n1024_s2_sep", "e2e_n2048_s3", "e2e_n2048_s4_sep",
+                                  "e2e_n2048_s6_f4", "e2e_n5000_s5"])
+def test_register_teacher_forced_matches_reference(name):
+    """forward_align_4 with the reference's own correspondences forced: every
+    stage but the arg-min runs on the engine; (R,t) per iteration within 1e-4."""
+    g, m, cfg, sd, data = build_case(name)
+    eng = engine_for(cfg, sd, name)
+    forced = cu(np.transpose(g["idx"].astype(np.int32), (1, 0, 2)))           # [n_iter, P, J]
+    out = eng.register(cu(data["points_src"]), cu(data["points_ref"]), m["n_iter"], forced_idx=forced)
+    assert_pose_close(out["transforms"].cpu().numpy(), g["transforms"], 1e-4, 1e-4, name)
+    lg = out["logits"].cpu().numpy()[:, 0]
+    np.testing.assert_allclose(lg, g["logits"][0], rtol=2e-3, atol=2e-3)
+    assert int(out["invalid"][0]) == int(bool(g["invalid"]))
+    np.testing.assert_allclose(out["pt_ref_new"].cpu().numpy(), g["pt_ref_new"], rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("name", ["stage_n1024_s1", "stage_n1024_s2_sep", "e2e_n2048_s3", "e2e_n2048_s4_sep",
+                                  "e2e_n2048_s6_f4", "e2e_n5000_s5"])
+def test_register_free_running(name):
+    """No teacher forcing, pyramids built on device.  The arg-min over fp32
+    near-ties is not reproducible even by the reference against itself
+    (SURVEY §8c), so: report the agreement rate; when it is 100 % through
+    iteration i, (R,t) must be within 1e-4 through iteration i."""
+    g, m, cfg, sd, data = build_case(name)
+    eng = engine_for(cfg, sd, name)
+    out = eng.register(cu(data["points_src"]), cu(data["points_ref"]), m["n_iter"])
+    idx = out["idx"].cpu().numpy()[:, 0]
+    agree = [(idx[i] == g["idx"][0, i]).mean() for i in range(m["n_iter"])]
+    print(f"{name}: arg-min agreement per iteration {['%.4f' % a for a in agree]}")
+    assert agree[0] > 0.99
+    T = out["transforms"].cpu().numpy()[0]
+    for i in range(m["n_iter"]):
+        if all(a == 1.0 for a in agree[: i + 1]):
+            assert_pose_close(T[i], g["transforms"][0, i], 1e-4, 1e-4, f"{name} iter {i}")
+    # whatever the flips, the result stays a rigid transform close to the reference's
+    for i in range(m["n_iter"]):
+        R = T[i][:, :3].astype(np.float64)
+        np.testing.assert_allclose(R @ R.T, np.eye(3), atol=1e-5)
+    assert rot_angle(T[-1][:, :3], g["transforms"][0, -1][:, :3]) < 2e-2
+
+
+def test_register_with_supplied_pyramids_and_batch():
+    """Caller-supplied int64 pyramids (the reference's data dict) and a batch of 2 pairs
+    give the same answer as device-built pyramids / single pairs (bitwise)."""
+    g, m, cfg, sd, data = build_case("e2e_n2048_s3")
+    g2, m2, _, _, data2 = build_case("e2e_n2048_s4_sep")   # different weights in the fixture; only its points are used
+    eng = engine_for(cfg, sd, "e2e_n2048_s3")
+    src = cu(np.concatenate([data["points_src"], data2["points_src"]], 0))
+    ref = cu(np.concatenate([data["points_ref"], data2["points_ref"]], 0))
+    both = eng.register(src, ref, 3)
+    one = eng.register(src[:1], ref[:1], 3)
+    two = eng.register(src[1:], ref[1:], 3)
+    assert torch.equal(both["transforms"][0], one["transforms"][0])
+    assert torch.equal(both["transforms"][1], two["transforms"][0])
+    assert torch.equal(both["idx"][:, 0], one["idx"][:, 0])
+    pyr = {k: cu(v) for k, v in data.items() if k.endswith(("_xyz", "_idx"))}
+    sup = eng.register(src[:1], ref[:1], 3, pyramids=pyr)
+    assert torch.equal(sup["transforms"], one["transforms"])
+    assert torch.equal(sup["idx"], one["idx"])
+
+
+def test_determinism_and_full_size_properties():
+    """BASELINE full size (5000-pt pairs): run twice -> bitwise identical; the
+    cumulative transforms are rotations; the identity-alignment property:
+    registering a cloud against itself with forced identity correspondences
+    returns the identity pose."""
+    from deepsir_amd.arch import NetConfig
+    from deepsir_amd.synth import make_batch
+    from deepsir_amd.weights import generate_state_dict
+    cfg = NetConfig(feat_len=3)
+    sd = generate_state_dict(cfg, 0)
+    eng = engine_for(cfg, sd, "w0")
+    b = make_batch(5000, [11, 12], 3)
+    src, ref = cu(b["points_src"]), cu(b["points_ref"])
+    o1 = eng.register(src, ref, 5)
+    o2 = eng.register(src, ref, 5)
+    assert torch.equal(o1["transforms"], o2["transforms"])
+    assert torch.equal(o1["idx"], o2["idx"])
+    assert torch.equal(o1["logits"], o2["logits"])
+    T = o1["transforms"].cpu().numpy().astype(np.float64)
+    for R in T.reshape(-1, 3, 4)[:, :, :3]:
+        np.testing.assert_allclose(R @ R.T, np.eye(3), atol=2e-5)
+        assert np.linalg.det(R) > 0.999
+    ident = torch.arange(5000, dtype=torch.int32, device=src.device)[None, None].expand(5, 2, 5000).contiguous()
+    o3 = eng.register(src, src, 5, forced_idx=ident)
+    Ti = o3["transforms"].cpu().numpy()
+    eye = np.tile(np.eye(3, 4, dtype=np.float32), (2, 5, 1, 1))
+    np.testing.assert_allclose(Ti, eye, atol=5e-6)
+
+
+def test_nn_match_properties_full_size():
+    """5000 x 5000 and ragged 4999 x 5003: exact agreement with a float64 arg-min
+    wherever the fp64 top-2 gap exceeds fp32 resolution; self-match is the identity."""
+    from deepsir_amd.arch import NetConfig
+    from deepsir_amd.weights import generate_state_dict
+    cfg = NetConfig(feat_len=3)
+    eng = engine_for(cfg, generate_state_dict(cfg, 0), "w0")
+    rng = np.random.default_rng(5)
+    for J, K in ((5000, 5000), (4999, 5003), (1, 64), (70, 63)):
+        a = rng.standard_normal((2, J, 64)).astype(np.float32)
+        b = rng.standard_normal((2, K, 64)).astype(np.float32)
+        a /= np.linalg.norm(a, axis=2, keepdims=True)
+        b /= np.linalg.norm(b, axis=2, keepdims=True)
+        idx = eng.nn_match(cu(a), cu(b)).cpu().numpy()
+        for p in range(2):
+            d = -2 * a[p].astype(np.float64) @ b[p].astype(np.float64).T + (b[p].astype(np.float64) ** 2).sum(1)[None]
+            ref = d.argmin(1)
+            part = np.partition(d, 1, axis=1) if K > 1 else d
+            gap = part[:, 1] - part[:, 0] if K > 1 else np.ones(J)
+            clear = gap > 1e-5
+            assert np.array_equal(idx[p][clear], ref[clear])
+            got = np.take_along_axis(d, idx[p][:, None].astype(np.int64), 1)[:, 0]
+            assert np.all(got - d.min(1) < 1e-5)
+    a = rng.standard_normal((1, 3000, 64)).astype(np.float32)
+    a /= np.linalg.norm(a, axis=2, keepdims=True)
+    idx = eng.nn_match(cu(a), cu(a)).cpu().numpy()[0]
+    assert np.array_equal(idx, np.arange(3000))
+    # exact duplicates in ref: the lower index wins (torch.min / oracle tie rule)
+    b = np.concatenate([a[0, :100], a[0, :100]], 0)[None]
+    idx = eng.nn_match(cu(a[:, :100]), cu(b)).cpu().numpy()[0]
+    assert np.array_equal(idx, np.arange(100))
+
+
+def test_network_dropin_api():
+    """The reference's host API: Network(args), load_state_dict, .cuda(), .eval(), net(data, opt)."""
+    import argparse
+    from deepsir_amd.model import Network
+    from deepsir_amd.weights import to_torch_state_dict
+    g, m, cfg, sd, data = build_case("e2e_n2048_s3")
+    args = argparse.Namespace(pipeline="align", num_sub=-1, num_knn=16, out_feat_dim=64, clip_weight_thresh=0.0,
+                              feat_len=3, d_out=[16, 64, 128, 256], num_points=2048, sub_sampling_ratio=[4, 4, 4, 4],
+                              use_ppf=False)
+    net = Network(args)
+    assert len(net.state_dict()) == 370
+    net.load_state_dict(to_torch_state_dict(sd))
+    net = net.cuda().eval()
+    d = {k: cu(v) for k, v in data.items()}
+    transforms, ep = net(d, (5, True))
+    assert len(transforms) == 5 and tuple(transforms[0].shape) == (1, 3, 4) and transforms[0].is_cuda
+    assert tuple(ep["pred_pairs"][0].shape) == (1, 2048, 2) and ep["pred_pairs"][0].dtype == torch.int32
+    assert not ep["pred_pairs"][0].is_cuda and tuple(ep["perm_matrices"][0].shape) == (1, 2048)
+    assert ep["invalid_gradient"] is False
+    agree = (ep["pred_pairs"][0][0, :, 1].numpy() == g["idx"][0, 0]).mean()
+    assert agree > 0.99
+    if all((ep["pred_pairs"][i][0, :, 1].numpy() == g["idx"][0, i]).all() for i in range(5)):
+        assert_pose_close(torch.stack(transforms, 1).cpu().numpy(), g["transforms"], 1e-4, 1e-4)
+    with pytest.raises(RuntimeError):
+        net.load_state_dict({"bogus": torch.zeros(1)})
