@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""Headline benchmark: registered pairs/sec on 3DMatch-shaped 5000-point pairs.
+
+    python bench.py --gpus N --steps K --warmup W            (N = 1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the whole hot path (KNN pyramid -> 2x feature RandLA +
+score -> 5 x {aggregation, NN match, inlier RandLA, weighted Kabsch}) over one
+batch of P synthetic pairs per GPU, through the C ABI (dsir_register).  Inputs
+(raw [P,5000,3] clouds) are resident in HBM before the timed region; outputs
+(R,t per iteration) stay in HBM.  Pairs shard across ranks with no data-path
+collective; one RCCL all_gather of the (R,t) results closes the timed region.
+
+Prints ONE JSON line on rank 0 (see README / DESIGN.md §Measurement).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+
+
+def match_flops(P, J, K):
+    """Algorithmic FLOPs of one nn_match launch (128 J K + 3 J K per pair)."""
+    return float(P) * (128.0 * J * K + 3.0 * J * K)
+
+
+def cpu_baseline(cfg, sd, n_points, n_iter, budget_s=25.0):
+    """The oracle (CPU port of the reference path) timed on this box's host cores.
+    Model-only window, as the reference times it (test.py:399-402): the KNN pyramid is built beforehand."""
+    from deepsir_amd.synth import make_pair
+    from oracle.knn import add_pyramids
+    from oracle.network import OracleNet, to_torch
+
+    # the GPU box gives one GPU a share of 16 host cores; never oversubscribe (affinity may list far more)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    threads = max(1, min(avail, int(os.environ.get("DSIR_CPU_THREADS", "16"))))
+    torch.set_num_threads(threads)
+    net = OracleNet(cfg, sd)
+    data = to_torch(add_pyramids(make_pair(n_points, 1001, cfg.feat_len), cfg.num_knn, cfg.sub_sampling_ratio))
+    t0 = time.time()
+    net.register(data, n_iter)  # warm-up (timed only to bound the sample)
+    warm = time.time() - t0
+    times = []
+    t_end = time.time() + budget_s
+    while (len(times) < 3 and warm < budget_s / 3) or (time.time() < t_end and len(times) < 12):
+        t0 = time.time()
+        net.register(data, n_iter)
+        times.append(time.time() - t0)
+    if not times:
+        times = [warm]
+    med = float(np.median(times))
+    return {"value": round(1.0 / med, 4), "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{len(times)} timed runs of 1 pair x {n_points} pts x {n_iter} iters after 1 warm-up, median; "
+                      f"model-only window (KNN pyramid pre-built, as reference test.py:399-402); oracle = PyTorch-CPU "
+                      f"restatement, bit-identical to the imported reference on the golden fixtures"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--pairs", type=int, default=int(os.environ.get("DSIR_BENCH_PAIRS", "16")), help="pairs per step per GPU")
+    ap.add_argument("--points", type=int, default=5000)
+    ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # noqa: F811
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from deepsir_amd.arch import NetConfig
+    from deepsir_amd.dist import gather_results
+    from deepsir_amd.engine import Engine
+    from deepsir_amd.synth import make_batch
+    from deepsir_amd.weights import generate_state_dict
+
+    cfg = NetConfig(feat_len=3)
+    sd = generate_state_dict(cfg, 0)
+    P, N, n_iter = a.pairs, a.points, a.iters
+    eng = Engine(cfg, local_rank, max_points=N, max_pairs=P)
+    eng.load_state_dict(sd)
+    # every rank registers different pairs (weak scaling): seeds partitioned by rank
+    batch = make_batch(N, [10_000 + rank * P + i for i in range(P)], cfg.feat_len)
+    src = torch.from_numpy(batch["points_src"]).to(dev)
+    ref = torch.from_numpy(batch["points_ref"]).to(dev)
+    outs = [None] * max(a.steps, 1)
+    out_buf = eng.register(src, ref, n_iter, want_aux=False)   # allocates the output buffer once
+
+    def step(i):
+        outs[i % len(outs)] = eng.register(src, ref, n_iter, want_aux=False, sync=False, out={"transforms": out_buf["transforms"]})
+
+    def fence():
+        eng.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for i in range(a.warmup):
+        step(i)
+    fence()
+    eng.enable_match_timer(True)
+    eng.match_timer(reset=True)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(i)
+    eng.sync()
+    results = gather_results(out_buf["transforms"], dist)   # RCCL all_gather of (R,t) — the only collective
+    fence()
+    dt = time.perf_counter() - t0
+    match_ms, match_n = eng.match_timer(reset=True)
+    eng.enable_match_timer(False)
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert results.shape[0] == world * P and torch.isfinite(results).all()
+
+    if rank == 0:
+        total_pairs = world * P * a.steps
+        avg_match_s = (match_ms / 1e3) / max(match_n, 1)
+        achieved = match_flops(P, N, N) / avg_match_s / 1e12 if match_n else None
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "nn_match_pmc.json")
+        if os.path.exists(pmc):
+            try:
+                with open(pmc) as f:
+                    j = json.load(f)
+                if j.get("pairs") == P and j.get("points") == N:
+                    traffic = j.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "registered pairs/sec (5k-pt 3DMatch-shaped synthetic pairs, 5 registration iterations, KNN pyramid included)",
+            "value": round(total_pairs / dt, 3), "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C2: 3DMatch-shaped pairs, uniform [0,3]^3 m clouds, random SO(3)+t, raw clouds resident in HBM -> (R,t) in HBM",
+                       "points_per_cloud": N, "pairs_per_step_per_gpu": P, "num_reg_iter": n_iter, "knn": 16,
+                       "weights": "seeded random state-dict (checkpoint not available)", "parallelism": f"pair-sharded x{world}, RCCL all_gather of results"},
+            "roofline": {"kernel": "nn_match_kernel (fused 64-ch distance GEMM + row arg-min)", "bound": "mfma",
+                         "achieved": None if achieved is None else round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": None if achieved is None else round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                         "launches": int(match_n), "avg_launch_ms": round(avg_match_s * 1e3, 5),
+                         "flops_per_launch": match_flops(P, N, N)},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg, sd, N, n_iter)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -18,6 +18,7 @@ namespace {
 constexpr int QB = 64;      // queries per block (one per lane)
 constexpr int NW = 4;       // waves per block = support slices
 constexpr int TILE = 256;   // support points staged per wave per step
+constexpr int QCAP = 16;    // per-lane candidate queue depth (flushed when fewer than 8 free slots remain)
 
 __device__ __forceinline__ float sqdist(float qx, float qy, float qz, const float4& s) {
   const float dx = __fsub_rn(s.x, qx), dy = __fsub_rn(s.y, qy), dz = __fsub_rn(s.z, qz);
@@ -50,6 +51,8 @@ __global__ __launch_bounds__(QB * NW) void knn16_kernel(const float* __restrict_
   __shared__ float4 tile[NW][TILE];
   __shared__ float md[NW - 1][kKnn][QB];
   __shared__ int mi[NW - 1][kKnn][QB];
+  __shared__ float qd[NW][QCAP][QB];
+  __shared__ int qi[NW][QCAP][QB];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int cloud = blockIdx.y;
   const float* P = pts + cloud * cs;
@@ -61,6 +64,20 @@ __global__ __launch_bounds__(QB * NW) void knn16_kernel(const float* __restrict_
   const int s_end = min(n, s_begin + slice);
   Top16 top;
   top.init();
+  // Candidates that beat the lane's current 16th distance are parked in a small
+  // per-lane LDS queue; the (75-instruction, divergent) sorted insertion runs only
+  // when some lane's queue is full, for all lanes at once.  The threshold is only
+  // refreshed at a flush, so the queue may hold a few candidates insert() rejects:
+  // harmless, insert() re-checks.  Order of arrival (ascending index) is kept.
+  float thr = INFINITY;
+  int nq = 0;
+  auto flush = [&]() {
+#pragma unroll 1
+    for (int c = 0; c < QCAP; ++c)
+      if (c < nq) top.insert(qd[w][c][lane], qi[w][c][lane]);
+    nq = 0;
+    thr = top.d[kKnn - 1];
+  };
   for (int t0 = 0; t0 < slice; t0 += TILE) {
     // stage: each lane loads TILE/64 support points of this wave's slice
 #pragma unroll
@@ -72,9 +89,22 @@ __global__ __launch_bounds__(QB * NW) void knn16_kernel(const float* __restrict_
     }
     __syncthreads();
     const int cnt = max(0, min(TILE, s_end - (s_begin + t0)));
-    for (int j = 0; j < cnt; ++j) top.insert(sqdist(qx, qy, qz, tile[w][j]), s_begin + t0 + j);
+    // 8 support points per step: the 8 broadcast ds_read_b128 are independent, so their latency overlaps
+    for (int j0 = 0; j0 < cnt; j0 += 8) {
+      float dd[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float4 s = tile[w][j0 + u];
+        dd[u] = (j0 + u < cnt) ? sqdist(qx, qy, qz, s) : INFINITY;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (dd[u] < thr) { qd[w][nq][lane] = dd[u]; qi[w][nq][lane] = s_begin + t0 + j0 + u; ++nq; }
+      if (__any(nq > QCAP - 8)) flush();
+    }
     __syncthreads();
   }
+  flush();
   if (w > 0) {
 #pragma unroll
     for (int t = 0; t < kKnn; ++t) { md[w - 1][t][lane] = top.d[t]; mi[w - 1][t][lane] = top.i[t]; }

@@ -22,6 +22,7 @@
 // chunk's global loads are issued before the MFMAs of the current one.
 #include "kernels.h"
 #include "device_utils.h"
+#include <cstdlib>
 
 namespace dsir {
 
@@ -312,6 +313,8 @@ void launch_bn(const GemmArgs& a, hipStream_t st) {
 
 void launch_pw_gemm(const GemmArgs& a, hipStream_t st) {
   if (a.M <= 0 || a.clouds <= 0) return;
+  static const bool no_stream = getenv("DSIR_NO_STREAM") != nullptr;   // A/B switch for tests and profiling
+  if (!no_stream && launch_pw_stream(a, st)) return;
   if (a.amode == A_LSE) {
     launch_bn<EPI_GN, A_LSE>(a, st);
     return;

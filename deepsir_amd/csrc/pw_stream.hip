@@ -1,0 +1,389 @@
+// Row-streaming point-wise GEMM for narrow layers (Cin <= 64): the layers at
+// pyramid levels 0/1 and the per-point MLP heads, where a row is 32-256 bytes
+// in, 32-256 bytes out and the bound is HBM/L2 bandwidth, not MFMA rate.
+//
+// No LDS staging and no block-level barrier in the main loop:
+//   * every wave owns whole 16-row MFMA tiles and walks them grid-stride;
+//   * the MFMA k index is re-ordered so that lane (r = lane & 15, q = lane >> 4)
+//     holds the CONTIGUOUS channels [q*KQ, (q+1)*KQ) of row r (KQ = Cin/4): the A
+//     fragment of a tile is one 4..64-byte vector load per lane straight from
+//     global memory (a wave reads 16 full rows), the producer's GroupNorm +
+//     LeakyReLU is applied in registers;
+//   * the weight fragments W[col][q*KQ + s] (same k order) and the GroupNorm
+//     scale/shift of the lane's channels live in registers for the whole kernel;
+//   * GroupNorm statistics of the output are accumulated in registers across all
+//     tiles of the wave and reduced once at the end (one fp64 atomic per group per
+//     block).
+// The sum over k is the same set of products as in pw_gemm.hip, associated in a
+// different (fixed) order; results are deterministic.
+// Loader modes: vector (aligned segments), element-wise (tiny Cin: xyz / score /
+// 6-channel inlier input), and the relative position encoding (RandLANet.py:197-212).
+#include "kernels.h"
+#include "device_utils.h"
+
+namespace dsir {
+
+namespace {
+
+enum SMode { S_VEC = 0, S_ELEM = 1, S_LSE = 2 };
+
+template <int KQ>
+struct Chunk { float v[KQ]; };
+
+template <int KQ>
+__device__ __forceinline__ void vec_load(const float* __restrict__ p, float (&v)[KQ]) {
+  if constexpr (KQ == 2) {
+    const float2 t = *reinterpret_cast<const float2*>(p);
+    v[0] = t.x; v[1] = t.y;
+  } else if constexpr (KQ % 4 == 0) {
+#pragma unroll
+    for (int i = 0; i < KQ / 4; ++i) {
+      const float4 t = *reinterpret_cast<const float4*>(p + 4 * i);
+      v[4 * i] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < KQ; ++i) v[i] = p[i];
+  }
+}
+
+__device__ __forceinline__ int src_row(const Seg& s, int cloud, int row) {
+  return s.idx ? s.idx[cloud * s.idx_cloud_stride + row] : row / s.row_div;
+}
+
+template <int KQ, int NT, int EPI, int MODE>
+__global__ __launch_bounds__(256) void pw_stream_kernel(const GemmArgs p) {
+  constexpr int BN = NT * 16;
+  constexpr int CP = KQ * 4;  // padded Cin
+  __shared__ float s_sc[CP];
+  __shared__ float s_sh[CP];
+  __shared__ float s_red[EPI == EPI_GN ? 4 * BN * 2 : 1];
+  __shared__ float s_att[EPI == EPI_ATT ? 4 * 16 * (CP + 4) : 1];
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int cloud = blockIdx.z;
+  const int n0 = blockIdx.y * BN;
+
+  if (MODE != S_LSE) {
+    for (int c = tid; c < CP; c += 256) {
+      float scale = 1.f, shift = 0.f;
+      if (c < p.Cin) {
+        const Seg& s = (c < p.seg[0].C) ? p.seg[0] : p.seg[1];
+        const int lc = (c < p.seg[0].C) ? c : c - p.seg[0].C;
+        if (s.gn.stats) {
+          const int g = lc / (s.C / s.gn.groups);
+          const double* st = s.gn.stats + ((int64_t)cloud * s.gn.groups + g) * 2;
+          const double mean = st[0] * s.gn.inv_count;
+          double var = st[1] * s.gn.inv_count - mean * mean;
+          var = var > 0.0 ? var : 0.0;
+          const double rstd = 1.0 / sqrt(var + 1e-5);
+          const double scd = (double)s.gn.gamma[lc] * rstd;
+          scale = (float)scd;
+          shift = (float)((double)s.gn.beta[lc] - mean * scd);
+        }
+      }
+      s_sc[c] = scale;
+      s_sh[c] = shift;
+    }
+    __syncthreads();
+  }
+
+  // lane-constant pieces
+  const int c_lo = fq * KQ;                       // first channel of this lane's chunk
+  float sc[KQ], sh[KQ];
+#pragma unroll
+  for (int j = 0; j < KQ; ++j) { sc[j] = (MODE != S_LSE) ? s_sc[c_lo + j] : 1.f; sh[j] = (MODE != S_LSE) ? s_sh[c_lo + j] : 0.f; }
+  float wf[NT][KQ];
+  float bv[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int col = n0 + 16 * t + fr;
+#pragma unroll
+    for (int j = 0; j < KQ; ++j) {
+      const int k = c_lo + j;
+      wf[t][j] = (col < p.Cout && k < p.Cin) ? p.W[(int64_t)col * p.Cin + k] : 0.f;
+    }
+    bv[t] = (p.bias && col < p.Cout) ? p.bias[col] : 0.f;
+  }
+  // vector mode: the chunk lies inside one segment
+  const int C0 = p.seg[0].C;
+  const bool in_seg1 = (MODE == S_VEC) && (p.nseg > 1) && (c_lo >= C0);
+  const Seg& myseg = in_seg1 ? p.seg[1] : p.seg[0];
+  const int seg_c = in_seg1 ? c_lo - C0 : c_lo;
+  const int my_act = myseg.act;
+
+  const int ntiles = (p.M + 15) >> 4;
+  const int wave0 = blockIdx.x * 4 + w, nwaves = gridDim.x * 4;
+
+  auto load_tile = [&](int tile, Chunk<KQ>& ch) {
+    const int row = tile * 16 + fr;
+    const bool ok = row < p.M;
+    if (MODE == S_VEC) {
+      if (ok) {
+        const float* src = myseg.x + cloud * myseg.cloud_stride + (int64_t)src_row(myseg, cloud, row) * myseg.ld + seg_c;
+        vec_load<KQ>(src, ch.v);
+#pragma unroll
+        for (int j = 0; j < KQ; ++j) {
+          const float v = fmaf(ch.v[j], sc[j], sh[j]);
+          ch.v[j] = (my_act && v < 0.f) ? 0.2f * v : v;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < KQ; ++j) ch.v[j] = 0.f;
+      }
+    } else if (MODE == S_ELEM) {
+#pragma unroll
+      for (int j = 0; j < KQ; ++j) {
+        const int c = c_lo + j;
+        float v = 0.f;
+        if (ok && c < p.Cin) {
+          const Seg& s = (c < C0) ? p.seg[0] : p.seg[1];
+          const int lc = (c < C0) ? c : c - C0;
+          const float x = s.x[cloud * s.cloud_stride + (int64_t)src_row(s, cloud, row) * s.ld + lc];
+          v = fmaf(x, sc[j], sh[j]);
+          if (s.act && v < 0.f) v *= 0.2f;
+        }
+        ch.v[j] = v;
+      }
+    } else {  // S_LSE: KQ == 3; channels [dist, rel(3), pi(3), pj(3), 0, 0]
+      float e[12];
+#pragma unroll
+      for (int j = 0; j < 12; ++j) e[j] = 0.f;
+      if (ok) {
+        const int i = row >> 4;
+        const int jn = p.neigh[cloud * p.neigh_cloud_stride + row];
+        const float* pi = p.xyz + cloud * p.xyz_cloud_stride + (int64_t)i * 3;
+        const float* pj = p.xyz + cloud * p.xyz_cloud_stride + (int64_t)jn * 3;
+        const float ix = pi[0], iy = pi[1], iz = pi[2], jx = pj[0], jy = pj[1], jz = pj[2];
+        const float dx = __fsub_rn(jx, ix), dy = __fsub_rn(jy, iy), dz = __fsub_rn(jz, iz);
+        e[0] = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
+        e[1] = dx; e[2] = dy; e[3] = dz; e[4] = ix; e[5] = iy; e[6] = iz; e[7] = jx; e[8] = jy; e[9] = jz;
+      }
+#pragma unroll
+      for (int j = 0; j < KQ; ++j)
+        ch.v[j] = fq == 0 ? e[j] : (fq == 1 ? e[3 + j] : (fq == 2 ? e[6 + j] : e[9 + j]));
+    }
+  };
+
+  float g1[NT], g2[NT];   // GroupNorm partial sums of this lane's columns
+#pragma unroll
+  for (int t = 0; t < NT; ++t) { g1[t] = 0.f; g2[t] = 0.f; }
+
+  Chunk<KQ> cur;
+  int tile = wave0;
+  if (tile < ntiles) load_tile(tile, cur);
+  for (; tile < ntiles; tile += nwaves) {
+    Chunk<KQ> nxt;
+    const int tn = tile + nwaves;
+    if (tn < ntiles) load_tile(tn, nxt);
+
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < KQ; ++s)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.v[s], wf[t][s], acc[t], 0, 0, 0);
+
+    const int rbase = tile * 16 + 4 * fq;   // C layout: col = lane & 15, row = 4 * (lane >> 4) + reg
+    if (EPI == EPI_GN) {
+      float* Y = p.Y + cloud * p.y_cloud_stride;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int col = n0 + 16 * t + fr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = rbase + r;
+          if (row < p.M && col < p.Cout) {
+            const float v = acc[t][r] + bv[t];
+            Y[(int64_t)row * p.ldy + col] = v;
+            g1[t] += v;
+            g2[t] += v * v;
+          }
+        }
+      }
+    } else if (EPI == EPI_ACT || EPI == EPI_LINEAR) {
+      float* Y = p.Y + cloud * p.y_cloud_stride;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int col = n0 + 16 * t + fr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = rbase + r;
+          if (row < p.M && col < p.Cout) {
+            float v = acc[t][r] + bv[t];
+            if (EPI == EPI_LINEAR && p.residual) v += p.residual[cloud * p.res_cloud_stride + (int64_t)row * p.ldres + col];
+            if (EPI == EPI_ACT && v < 0.f) v *= 0.2f;
+            Y[(int64_t)row * p.ldy + col] = v;
+          }
+        }
+      }
+    } else if (EPI == EPI_L2NORM) {
+      float* Y = p.Y + cloud * p.y_cloud_stride;
+      float ss[4] = {0.f, 0.f, 0.f, 0.f};
+      float v[NT][4];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int col = n0 + 16 * t + fr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[t][r] = (col < p.Cout) ? acc[t][r] + bv[t] : 0.f;
+          ss[r] += v[t][r] * v[t][r];
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        ss[r] += __shfl_xor(ss[r], 1); ss[r] += __shfl_xor(ss[r], 2);
+        ss[r] += __shfl_xor(ss[r], 4); ss[r] += __shfl_xor(ss[r], 8);
+        const float den = fmaxf(__fsqrt_rn(ss[r]), 1e-12f);
+        const int row = rbase + r;
+        if (row < p.M) {
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            const int col = n0 + 16 * t + fr;
+            if (col < p.Cout) Y[(int64_t)row * p.ldy + col] = v[t][r] / den;
+          }
+        }
+      }
+    } else if (EPI == EPI_ATT) {
+      // the tile's 16 rows are the 16 neighbours of point `tile` (RandLANet.py:152-155).
+      // f[row][col] (already normalised) is in the A fragments of OTHER lanes: transpose it
+      // through a wave-private LDS tile [16][CP+4] (conflict-free: rows shift by 4 banks).
+      // Requires gridDim.y == 1 (Cout == Cin <= 64), which launch_pw_stream guarantees.
+      float* Y = p.Y + cloud * p.y_cloud_stride;
+      float* T = &s_att[w * 16 * (CP + 4)];
+#pragma unroll
+      for (int j = 0; j < KQ; ++j) T[fr * (CP + 4) + c_lo + j] = cur.v[j];
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int col = 16 * t + fr;
+        float mx = fmaxf(fmaxf(acc[t][0], acc[t][1]), fmaxf(acc[t][2], acc[t][3]));
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float e[4], se = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { e[r] = expf(acc[t][r] - mx); se += e[r]; }
+        se += __shfl_xor(se, 16); se += __shfl_xor(se, 32);
+        float o = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o += T[(4 * fq + r) * (CP + 4) + col] * (e[r] / se);
+        o += __shfl_xor(o, 16); o += __shfl_xor(o, 32);
+        if (lane < 16 && col < p.Cout) Y[(int64_t)tile * p.ldy + col] = o;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    cur = nxt;
+  }
+
+  if (EPI == EPI_GN) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      float s1 = g1[t], s2 = g2[t];
+      s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
+      s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
+      if (lane < 16) {
+        s_red[(w * BN + 16 * t + lane) * 2 + 0] = s1;
+        s_red[(w * BN + 16 * t + lane) * 2 + 1] = s2;
+      }
+    }
+    __syncthreads();
+    const int gw = p.Cout / p.groups_out;
+    if (tid < BN) {
+      float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+      for (int ww = 0; ww < 4; ++ww) { c1 += s_red[(ww * BN + tid) * 2]; c2 += s_red[(ww * BN + tid) * 2 + 1]; }
+      s_red[tid * 2] = c1;
+      s_red[tid * 2 + 1] = c2;
+    }
+    __syncthreads();
+    if (tid < BN && (tid % gw) == 0 && n0 + tid < p.Cout) {
+      double d1 = 0.0, d2 = 0.0;
+      for (int c = 0; c < gw && tid + c < BN; ++c) { d1 += (double)s_red[(tid + c) * 2]; d2 += (double)s_red[(tid + c) * 2 + 1]; }
+      double* st = p.stats_out + ((int64_t)cloud * p.groups_out + (n0 + tid) / gw) * 2;
+      atomicAdd(st, d1);
+      atomicAdd(st + 1, d2);
+    }
+  }
+}
+
+template <int KQ, int NT, int EPI, int MODE>
+void launch_s(const GemmArgs& a, hipStream_t st) {
+  const int ntiles = (a.M + 15) / 16;
+  const int gy = (a.Cout + NT * 16 - 1) / (NT * 16);
+  // ~4 tiles per wave.  The grid depends on (M, Cout) only — never on the number of clouds — so the
+  // tile->wave assignment, hence the summation order of the GroupNorm statistics, is the same for a
+  // cloud whether it is registered alone or inside a batch (bitwise batch invariance).
+  int blocks = (ntiles + 15) / 16;
+  if (blocks * gy < 64) {
+    const int want = (64 + gy - 1) / gy, most = (ntiles + 3) / 4;
+    blocks = want < most ? want : most;
+  }
+  if (blocks < 1) blocks = 1;
+  dim3 grid(blocks, gy, a.clouds);
+  hipLaunchKernelGGL((pw_stream_kernel<KQ, NT, EPI, MODE>), grid, dim3(256), 0, st, a);
+}
+
+template <int KQ, int NT, int MODE>
+bool launch_epi(const GemmArgs& a, hipStream_t st) {
+  switch (a.epi) {
+    case EPI_GN: launch_s<KQ, NT, EPI_GN, MODE>(a, st); return true;
+    case EPI_ACT: if (MODE == S_LSE) return false; launch_s<KQ, NT, EPI_ACT, MODE == S_LSE ? S_VEC : MODE>(a, st); return true;
+    case EPI_LINEAR: if (MODE == S_LSE) return false; launch_s<KQ, NT, EPI_LINEAR, MODE == S_LSE ? S_VEC : MODE>(a, st); return true;
+    default: return false;
+  }
+}
+
+template <int KQ, int MODE>
+bool launch_nt(const GemmArgs& a, hipStream_t st) {
+  if (a.Cout <= 16) return launch_epi<KQ, 1, MODE>(a, st);
+  if (a.Cout <= 32) return launch_epi<KQ, 2, MODE>(a, st);
+  return launch_epi<KQ, 4, MODE>(a, st);
+}
+
+bool seg_vec_ok(const Seg& s, int KQ) {
+  const int al = KQ >= 4 ? 4 : KQ;
+  return (s.ld % al) == 0 && (s.cloud_stride % al) == 0 && (reinterpret_cast<uintptr_t>(s.x) % (al * 4)) == 0;
+}
+
+}  // namespace
+
+// Returns false when the layer is outside this kernel's envelope (caller falls back to pw_gemm.hip).
+bool launch_pw_stream(const GemmArgs& a, hipStream_t st) {
+  if (a.M <= 0 || a.clouds <= 0) return true;
+  if (a.amode == A_LSE) {
+    if (a.epi != EPI_GN) return false;
+    return launch_nt<3, S_LSE>(a, st);
+  }
+  if (a.Cin > 64) return false;
+  const int C0 = a.seg[0].C;
+  // vector mode: Cin = 4 KQ exactly, chunks do not straddle the segment boundary, aligned rows
+  for (int KQ : {2, 4, 8, 16}) {
+    if (a.Cin != 4 * KQ) continue;
+    bool ok = seg_vec_ok(a.seg[0], KQ) && (a.nseg == 1 || (seg_vec_ok(a.seg[1], KQ) && (C0 % KQ) == 0));
+    if (!ok) break;
+    if (a.epi == EPI_ATT) {
+      if (KQ == 4 && a.Cout == 16) { launch_s<4, 1, EPI_ATT, S_VEC>(a, st); return true; }
+      if (KQ == 16 && a.Cout == 64) { launch_s<16, 4, EPI_ATT, S_VEC>(a, st); return true; }
+      return false;
+    }
+    if (a.epi == EPI_L2NORM) {
+      if (KQ == 16 && a.Cout == 64) { launch_s<16, 4, EPI_L2NORM, S_VEC>(a, st); return true; }
+      return false;
+    }
+    switch (KQ) {
+      case 2: return launch_nt<2, S_VEC>(a, st);
+      case 4: return launch_nt<4, S_VEC>(a, st);
+      case 8: return launch_nt<8, S_VEC>(a, st);
+      case 16: return launch_nt<16, S_VEC>(a, st);
+    }
+  }
+  if (a.Cin <= 8 && (a.epi == EPI_GN || a.epi == EPI_ACT || a.epi == EPI_LINEAR)) {
+    if (a.Cin <= 4) return launch_nt<1, S_ELEM>(a, st);
+    return launch_nt<2, S_ELEM>(a, st);
+  }
+  return false;
+}
+
+}  // namespace dsir

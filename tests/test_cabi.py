@@ -1,0 +1,58 @@
+"""The C-ABI library must load on a CPU-only host and export every symbol
+include/dsir.h declares (no compute calls here: there is no GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+def _declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "dsir.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(dsir_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from deepsir_amd import _lib
+    assert os.path.exists(_lib.LIB_PATH), "build it first: python -c 'import __graft_entry__ as g; g.build()'"
+    lib = _lib.load()
+    declared = _declared_symbols()
+    assert len(declared) >= 19
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/dsir.h but not exported"
+    assert set(declared) == set(_lib.SYMBOLS), "ctypes binding and header disagree"
+
+
+def test_struct_layout_matches_header():
+    from deepsir_amd import _lib
+    assert ctypes.sizeof(_lib.dsir_cfg) == 4 * (3 + 4 + 4 + 4)
+    assert ctypes.sizeof(_lib.dsir_pair_batch) == 16 + 11 * 8
+    assert ctypes.sizeof(_lib.dsir_pair_result) == 5 * 8
+
+
+def test_create_fails_loudly_without_gpu_or_with_bad_cfg():
+    import torch
+    from deepsir_amd import _lib
+    lib = _lib.load()
+    cfg = _lib.dsir_cfg()
+    h = ctypes.c_void_p()
+    cfg.num_knn = 8   # unsupported
+    assert lib.dsir_create(0, ctypes.byref(cfg), ctypes.byref(h)) != 0
+    assert b"num_knn" in lib.dsir_last_error(None)
+    if not torch.cuda.is_available():
+        from deepsir_amd.arch import NetConfig
+        from deepsir_amd.engine import Engine, EngineError
+        with pytest.raises(EngineError):
+            Engine(NetConfig(), 0)    # no device: must raise, never fall back to a CPU path
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "deepsir_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f"{f} imports the oracle"

@@ -1,0 +1,56 @@
+"""The N>1 path on CPU: world_size-2 gloo processes shard a pair list and gather the results."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from deepsir_amd.dist import gather_results, shard_range, shard_sizes
+
+
+def test_shard_partition():
+    for n in (0, 1, 7, 8, 1623):
+        for w in (1, 2, 3, 8):
+            parts = [list(shard_range(n, r, w)) for r in range(w)]
+            assert sum(parts, []) == list(range(n))
+            assert max(map(len, parts)) - min(map(len, parts)) <= 1
+            assert shard_sizes(n, w) == [len(p) for p in parts]
+
+
+def test_single_process_gather_is_identity():
+    x = torch.arange(24.0).reshape(2, 12)
+    assert torch.equal(gather_results(x), x)
+
+
+def _worker(rank, world, port, n_pairs, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = shard_range(n_pairs, rank, world)
+    # stand-in for the per-pair (R,t) results of this rank's shard: pair id encoded in the payload
+    local = torch.stack([torch.full((5, 3, 4), float(i)) for i in mine]) if len(mine) else torch.zeros(0, 5, 3, 4)
+    out = gather_results(local, dist, sizes=shard_sizes(n_pairs, world))
+    eq = gather_results(torch.full((3, 2), float(rank)), dist)
+    if rank == 0:
+        q.put((out[:, 0, 0, 0].tolist(), eq[:, 0].tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_shard_and_gather():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    n_pairs = 7   # unequal shards: 4 + 3
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_pairs, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    ids, eq = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert ids == [float(i) for i in range(n_pairs)]
+    assert eq == [0.0] * 3 + [1.0] * 3

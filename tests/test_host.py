@@ -1,0 +1,82 @@
+"""Host-side logic that needs no GPU: drop-in module surface, synthetic data, metrics, SE(3)."""
+import argparse
+
+import numpy as np
+import pytest
+import torch
+
+from deepsir_amd.arch import NetConfig
+from deepsir_amd.synth import make_batch, make_pair
+
+
+def _args(**kw):
+    d = dict(pipeline="align", num_sub=-1, num_knn=16, out_feat_dim=64, clip_weight_thresh=0.0, feat_len=3,
+             d_out=[16, 64, 128, 256], num_points=5000, sub_sampling_ratio=[4, 4, 4, 4], use_ppf=False)
+    d.update(kw)
+    return argparse.Namespace(**d)
+
+
+def test_network_module_surface():
+    from deepsir_amd.model import Network
+    from deepsir_amd.weights import generate_state_dict, to_torch_state_dict
+    net = Network(_args())
+    sd = net.state_dict()
+    ref = generate_state_dict(NetConfig(feat_len=3), 0)
+    assert list(sd.keys()) == list(ref.keys()) and len(sd) == 370
+    assert all(tuple(sd[k].shape) == ref[k].shape for k in ref)
+    net.load_state_dict(to_torch_state_dict(ref))
+    assert torch.equal(net.state_dict()["mlp_att.12.weight"], torch.from_numpy(ref["mlp_att.12.weight"]))
+    assert net.eval() is net
+    with pytest.raises(RuntimeError):   # strict loading, like nn.Module
+        net.load_state_dict({"nope": torch.zeros(1)})
+    with pytest.raises(NotImplementedError):
+        Network(_args(pipeline="feat"))
+
+
+def test_network_on_cpu_fails_loudly():
+    from deepsir_amd.engine import EngineError
+    from deepsir_amd.model import Network
+    net = Network(_args()).eval()
+    data = {k: torch.from_numpy(v) for k, v in make_pair(1024, 0).items()}
+    with pytest.raises(EngineError):
+        net(data, (5, True))
+
+
+def test_synthetic_pair_is_consistent():
+    p = make_pair(2048, 5, feat_len=4)
+    assert p["points_src"].shape == (1, 2048, 4) and p["points_src"].dtype == np.float32
+    T = p["transform_gt"][0].astype(np.float64)
+    R, t = T[:, :3], T[:, 3]
+    np.testing.assert_allclose(R @ R.T, np.eye(3), atol=1e-6)
+    assert np.linalg.det(R) > 0
+    moved = p["points_src"][0, :, :3].astype(np.float64) @ R.T + t
+    # same point set up to a permutation
+    a = np.sort(np.round(moved, 3), axis=0)
+    b = np.sort(np.round(p["points_ref"][0, :, :3].astype(np.float64), 3), axis=0)
+    np.testing.assert_allclose(a, b, atol=2e-3)
+    assert np.array_equal(make_pair(2048, 5, 4)["points_src"], p["points_src"])
+    assert make_batch(1024, [1, 2, 3])["points_ref"].shape == (3, 1024, 3)
+    q = make_pair(4096, 9, partial_overlap=True)
+    assert q["points_src"].shape == (1, 4096, 3)
+
+
+def test_metrics_and_se3():
+    from deepsir_amd import se3
+    from deepsir_amd.metrics import rte_rre
+    from deepsir_amd.synth import random_rotation
+    rng = np.random.default_rng(0)
+    R = random_rotation(rng)
+    T = np.concatenate([R, rng.uniform(-1, 1, (3, 1))], 1).astype(np.float32)
+    ok, rte, rre = rte_rre(T, T, 0.3, 15.0)
+    assert ok == 1 and rte == 0 and rre < 0.1
+    T2 = T.copy(); T2[:, 3] += np.float32(1.0)
+    assert rte_rre(T2, T, 0.3, 15.0)[0] == 0
+    assert np.isinf(rte_rre(None, T, 0.3, 15.0)[1])
+    a = torch.from_numpy(T)[None]
+    inv = se3.inverse(a)
+    comp = se3.concatenate(a, inv)
+    np.testing.assert_allclose(comp[0].numpy(), np.eye(3, 4), atol=1e-6)
+    pts = torch.randn(1, 10, 3)
+    back = se3.transform(inv, se3.transform(a, pts))
+    np.testing.assert_allclose(back.numpy(), pts.numpy(), atol=1e-5)
+    assert se3.identity(2).shape == (2, 3, 4)
