@@ -315,6 +315,9 @@ void launch_pw_gemm(const GemmArgs& a, hipStream_t st) {
   if (a.M <= 0 || a.clouds <= 0) return;
   static const bool no_stream = getenv("DSIR_NO_STREAM") != nullptr;   // A/B switch for tests and profiling
   if (!no_stream && launch_pw_stream(a, st)) return;
+  // pw_deep.hip is not yet faster than the LDS-tiled kernel below on MI355X (profiles/README.md): opt-in
+  static const bool use_deep = getenv("DSIR_DEEP") != nullptr;
+  if (use_deep && launch_pw_deep(a, st)) return;
   if (a.amode == A_LSE) {
     launch_bn<EPI_GN, A_LSE>(a, st);
     return;

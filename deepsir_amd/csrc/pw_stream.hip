@@ -99,10 +99,18 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const GemmArgs p) {
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int col = n0 + 16 * t + fr;
+    if ((KQ % 4) == 0 && p.Cin == 4 * KQ) {          // rows of W are 16-byte aligned: vector loads
+      if (col < p.Cout) vec_load<KQ>(p.W + (int64_t)col * p.Cin + c_lo, wf[t]);
+      else {
 #pragma unroll
-    for (int j = 0; j < KQ; ++j) {
-      const int k = c_lo + j;
-      wf[t][j] = (col < p.Cout && k < p.Cin) ? p.W[(int64_t)col * p.Cin + k] : 0.f;
+        for (int j = 0; j < KQ; ++j) wf[t][j] = 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < KQ; ++j) {
+        const int k = c_lo + j;
+        wf[t][j] = (col < p.Cout && k < p.Cin) ? p.W[(int64_t)col * p.Cin + k] : 0.f;
+      }
     }
     bv[t] = (p.bias && col < p.Cout) ? p.bias[col] : 0.f;
   }
@@ -116,18 +124,28 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const GemmArgs p) {
   const int ntiles = (p.M + 15) >> 4;
   const int wave0 = blockIdx.x * 4 + w, nwaves = gridDim.x * 4;
 
-  auto load_tile = [&](int tile, Chunk<KQ>& ch) {
+  // source row of this lane's A row in tile `tile` (gathered segments: one index load, issued a tile ahead)
+  auto tile_srow = [&](int tile) -> int {
+    const int row = tile * 16 + fr;
+    if (MODE != S_VEC || row >= p.M) return 0;
+    return src_row(myseg, cloud, row);
+  };
+  auto finish_tile = [&](int tile, Chunk<KQ>& ch) {
+    if (MODE != S_VEC) return;
+    const bool ok = tile * 16 + fr < p.M;
+#pragma unroll
+    for (int j = 0; j < KQ; ++j) {
+      const float v = fmaf(ch.v[j], sc[j], sh[j]);
+      ch.v[j] = ok ? ((my_act && v < 0.f) ? 0.2f * v : v) : 0.f;
+    }
+  };
+  auto load_tile = [&](int tile, int srow, Chunk<KQ>& ch) {
     const int row = tile * 16 + fr;
     const bool ok = row < p.M;
     if (MODE == S_VEC) {
       if (ok) {
-        const float* src = myseg.x + cloud * myseg.cloud_stride + (int64_t)src_row(myseg, cloud, row) * myseg.ld + seg_c;
-        vec_load<KQ>(src, ch.v);
-#pragma unroll
-        for (int j = 0; j < KQ; ++j) {
-          const float v = fmaf(ch.v[j], sc[j], sh[j]);
-          ch.v[j] = (my_act && v < 0.f) ? 0.2f * v : v;
-        }
+        const float* src = myseg.x + cloud * myseg.cloud_stride + (int64_t)srow * myseg.ld + seg_c;
+        vec_load<KQ>(src, ch.v);          // raw values; normalised by finish_tile() after the MFMA burst
       } else {
 #pragma unroll
         for (int j = 0; j < KQ; ++j) ch.v[j] = 0.f;
@@ -170,13 +188,23 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const GemmArgs p) {
 #pragma unroll
   for (int t = 0; t < NT; ++t) { g1[t] = 0.f; g2[t] = 0.f; }
 
+  // software pipeline: gather index two tiles ahead, A loads one tile ahead, normalise just before use
   Chunk<KQ> cur;
   int tile = wave0;
-  if (tile < ntiles) load_tile(tile, cur);
+  int srow_n = 0;
+  if (tile < ntiles) {
+    load_tile(tile, tile_srow(tile), cur);
+    finish_tile(tile, cur);
+    if (tile + nwaves < ntiles) srow_n = tile_srow(tile + nwaves);
+  }
   for (; tile < ntiles; tile += nwaves) {
     Chunk<KQ> nxt;
     const int tn = tile + nwaves;
-    if (tn < ntiles) load_tile(tn, nxt);
+    int srow_nn = 0;
+    if (tn < ntiles) {
+      load_tile(tn, srow_n, nxt);
+      if (tn + nwaves < ntiles) srow_nn = tile_srow(tn + nwaves);
+    }
 
     f32x4 acc[NT];
 #pragma unroll
@@ -274,7 +302,9 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const GemmArgs p) {
       }
       __builtin_amdgcn_wave_barrier();
     }
+    if (tn < ntiles) finish_tile(tn, nxt);
     cur = nxt;
+    srow_n = srow_nn;
   }
 
   if (EPI == EPI_GN) {
@@ -312,10 +342,10 @@ template <int KQ, int NT, int EPI, int MODE>
 void launch_s(const GemmArgs& a, hipStream_t st) {
   const int ntiles = (a.M + 15) / 16;
   const int gy = (a.Cout + NT * 16 - 1) / (NT * 16);
-  // ~4 tiles per wave.  The grid depends on (M, Cout) only — never on the number of clouds — so the
+  // ~8 tiles per wave.  The grid depends on (M, Cout) only — never on the number of clouds — so the
   // tile->wave assignment, hence the summation order of the GroupNorm statistics, is the same for a
   // cloud whether it is registered alone or inside a batch (bitwise batch invariance).
-  int blocks = (ntiles + 15) / 16;
+  int blocks = (ntiles + 31) / 32;
   if (blocks * gy < 64) {
     const int want = (64 + gy - 1) / gy, most = (ntiles + 3) / 4;
     blocks = want < most ? want : most;
