@@ -64,6 +64,8 @@ void launch_pw_gemm(const GemmArgs& a, hipStream_t st);
 bool launch_pw_stream(const GemmArgs& a, hipStream_t st);
 // wide-layer path (pw_deep.hip): Cin a multiple of 32 in [64,768], Cout >= 64; false => not applicable
 bool launch_pw_deep(const GemmArgs& a, hipStream_t st);
+// wide-layer path, LDS-tiled 128/64 x 64 x 32 (pw_tile.hip); same envelope as pw_deep
+bool launch_pw_tile(const GemmArgs& a, hipStream_t st);
 
 // y = LeakyReLU(GN_a(a) + GN_b(b))   (RandLANet.py:228-230)
 void launch_residual_combine(const float* a, GnRef ga, const float* b, GnRef gb, int C, int rows, int clouds,

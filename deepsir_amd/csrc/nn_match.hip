@@ -15,6 +15,7 @@
 // index regardless of arrival order (deterministic).
 #include "kernels.h"
 #include "device_utils.h"
+#include <cstdlib>
 
 namespace dsir {
 
@@ -46,8 +47,8 @@ __global__ __launch_bounds__(256) void nn_match_kernel(const float* __restrict__
                                                        const float* __restrict__ sa, const float* __restrict__ sb,
                                                        int J, int K, int cols_per_split,
                                                        unsigned long long* __restrict__ packed) {
-  __shared__ float Bs[BC * LDB];
-  __shared__ float sbs[BC];
+  __shared__ float Bs[2][BC * LDB];   // double-buffered ref tile
+  __shared__ float sbs[2][BC];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int fr = lane & 15, fq = lane >> 4;
   const int pair = blockIdx.z;
@@ -78,20 +79,39 @@ __global__ __launch_bounds__(256) void nn_match_kernel(const float* __restrict__
 
   const int c_begin = blockIdx.y * cols_per_split;
   const int c_end = min(K, c_begin + cols_per_split);
-  for (int c0 = c_begin; c0 < c_end; c0 += BC) {
-    // stage 64 ref rows: 1024 float4, 4 per thread, coalesced
+  // Pipeline: the next 64-column ref tile is fetched into registers while the MFMAs of the current
+  // tile run, then written to the other LDS buffer; one barrier per tile.
+  float4 pre[4];
+  float pre_sb = 0.f;
+  auto gload = [&](int c0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int f = tid + 256 * i;
       const int r = f >> 4, c4 = f & 15;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (c0 + r < c_end) v = *reinterpret_cast<const float4*>(Bp + (int64_t)(c0 + r) * 64 + c4 * 4);
-      float2* dst = reinterpret_cast<float2*>(&Bs[r * LDB + c4 * 4]);
-      dst[0] = make_float2(v.x, v.y);
-      dst[1] = make_float2(v.z, v.w);
+      pre[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c0 + r < c_end) pre[i] = *reinterpret_cast<const float4*>(Bp + (int64_t)(c0 + r) * 64 + c4 * 4);
     }
-    if (tid < BC) sbs[tid] = (c0 + tid < c_end) ? sb[(int64_t)pair * K + c0 + tid] : 0.f;
-    __syncthreads();
+    if (tid < BC) pre_sb = (c0 + tid < c_end) ? sb[(int64_t)pair * K + c0 + tid] : 0.f;
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int f = tid + 256 * i;
+      const int r = f >> 4, c4 = f & 15;
+      float2* dst = reinterpret_cast<float2*>(&Bs[buf][r * LDB + c4 * 4]);
+      dst[0] = make_float2(pre[i].x, pre[i].y);
+      dst[1] = make_float2(pre[i].z, pre[i].w);
+    }
+    if (tid < BC) sbs[buf][tid] = pre_sb;
+  };
+  gload(c_begin);
+  lstore(0);
+  __syncthreads();
+  int buf = 0;
+  for (int c0 = c_begin; c0 < c_end; c0 += BC) {
+    const bool has_next = c0 + BC < c_end;
+    if (has_next) gload(c0 + BC);
+    const float* Bt = Bs[buf];
 #pragma unroll
     for (int t = 0; t < BC / 16; ++t) {
       f32x4 acc[RT];
@@ -99,23 +119,26 @@ __global__ __launch_bounds__(256) void nn_match_kernel(const float* __restrict__
       for (int rt = 0; rt < RT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s = 0; s < 16; ++s) {
-        const float b = Bs[(16 * t + fr) * LDB + 4 * s + fq];
+        const float b = Bt[(16 * t + fr) * LDB + 4 * s + fq];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[rt][s], b, acc[rt], 0, 0, 0);
       }
       const int col = c0 + 16 * t + fr;
-      const float sbv = sbs[16 * t + fr];
+      const float sbv = sbs[buf][16 * t + fr];
       if (col < c_end) {
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float d = __fadd_rn(__fadd_rn(-2.f * acc[rt][r], san[rt][r]), sbv);
+            // fl(fl(-2*dot + |a|^2) + |b|^2): -2*dot is exact, so the fused form rounds exactly like the reference
+            const float d = __fadd_rn(__fmaf_rn(acc[rt][r], -2.f, san[rt][r]), sbv);
             if (d < best[rt][r]) { best[rt][r] = d; bidx[rt][r] = col; }
           }
       }
     }
+    if (has_next) lstore(buf ^ 1);   // last readers of that buffer finished before the previous barrier
     __syncthreads();
+    buf ^= 1;
   }
   // reduce over the 16 lanes that share a row; ties -> lower column
 #pragma unroll
@@ -161,23 +184,35 @@ void launch_nn_match_ws(const float* a, const float* b, int pairs, int J, int K,
   hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)((ra + 15) / 16)), dim3(256), 0, st, a, ra, sa);
   hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)((rb + 15) / 16)), dim3(256), 0, st, b, rb, sb);
   hipMemsetAsync(packed, 0xff, (size_t)pairs * J * 8, st);
-  // geometry: 2 row tiles per wave once there is enough work to fill the chip
-  const int rows_small = 64, rows_big = 128;
-  const bool big = (int64_t)pairs * ((J + rows_big - 1) / rows_big) >= 512;
-  const int rows_per_block = big ? rows_big : rows_small;
+  // geometry: 2 row tiles per wave (128-row blocks) once there is enough work, else 64-row blocks; the ref
+  // range is split so that the grid is a whole number of residency rounds (256 CUs x 4 blocks: 34 KB LDS each)
+  static const int force_rt = getenv("DSIR_MATCH_RT") ? atoi(getenv("DSIR_MATCH_RT")) : 0;   // tuning hook
+  int rt = (int64_t)pairs * ((J + 127) / 128) >= 256 ? 2 : 1;
+  if (force_rt == 1 || force_rt == 2 || force_rt == 4) rt = force_rt;
+  const int rows_per_block = 64 * rt;
+  const int resident = rt == 4 ? 768 : 1024;   // blocks the chip holds at once (VGPR- resp. LDS-limited)
   const int rb_count = (J + rows_per_block - 1) / rows_per_block;
-  int splits = (int)((768 + (int64_t)pairs * rb_count - 1) / ((int64_t)pairs * rb_count));
-  const int max_splits = (K + BC - 1) / BC;
-  if (splits < 1) splits = 1;
-  if (splits > 16) splits = 16;
-  if (splits > max_splits) splits = max_splits;
-  int cols = (K + splits - 1) / splits;
-  cols = (cols + BC - 1) / BC * BC;
+  const int64_t base = (int64_t)pairs * rb_count;
+  const int tiles = (K + BC - 1) / BC;
+  int splits = 1;
+  double best_eff = -1.0;
+  for (int sp = 1; sp <= 16 && sp <= tiles; ++sp) {
+    const int tiles_per = (tiles + sp - 1) / sp;
+    if (sp > 1 && tiles_per < 8) break;                    // keep the A-fragment preload amortised
+    const int nsp = (tiles + tiles_per - 1) / tiles_per;
+    const int64_t blocks = base * nsp;
+    const int64_t rounds = (blocks + resident - 1) / resident;
+    double eff = (double)blocks / (double)(rounds * resident);   // residency balance
+    eff *= (double)tiles / (double)(tiles_per * nsp);        // padding of the last split
+    if (eff > best_eff + 1e-9) { best_eff = eff; splits = sp; }
+  }
+  int cols = ((tiles + splits - 1) / splits) * BC;
   splits = (K + cols - 1) / cols;
   dim3 grid(rb_count, splits, pairs);
   if (ev0) hipEventRecord(ev0, st);
-  if (big) hipLaunchKernelGGL((nn_match_kernel<2>), grid, dim3(256), 0, st, a, b, sa, sb, J, K, cols, packed);
-  else     hipLaunchKernelGGL((nn_match_kernel<1>), grid, dim3(256), 0, st, a, b, sa, sb, J, K, cols, packed);
+  if (rt == 4)      hipLaunchKernelGGL((nn_match_kernel<4>), grid, dim3(256), 0, st, a, b, sa, sb, J, K, cols, packed);
+  else if (rt == 2) hipLaunchKernelGGL((nn_match_kernel<2>), grid, dim3(256), 0, st, a, b, sa, sb, J, K, cols, packed);
+  else              hipLaunchKernelGGL((nn_match_kernel<1>), grid, dim3(256), 0, st, a, b, sa, sb, J, K, cols, packed);
   if (ev1) hipEventRecord(ev1, st);
   hipLaunchKernelGGL(unpack_idx_kernel, dim3(256), dim3(256), 0, st, packed, ra, idx);
 }

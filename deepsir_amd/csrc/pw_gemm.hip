@@ -315,6 +315,8 @@ void launch_pw_gemm(const GemmArgs& a, hipStream_t st) {
   if (a.M <= 0 || a.clouds <= 0) return;
   static const bool no_stream = getenv("DSIR_NO_STREAM") != nullptr;   // A/B switch for tests and profiling
   if (!no_stream && launch_pw_stream(a, st)) return;
+  static const bool no_tile = getenv("DSIR_NO_TILE") != nullptr;
+  if (!no_tile && launch_pw_tile(a, st)) return;
   // pw_deep.hip is not yet faster than the LDS-tiled kernel below on MI355X (profiles/README.md): opt-in
   static const bool use_deep = getenv("DSIR_DEEP") != nullptr;
   if (use_deep && launch_pw_deep(a, st)) return;

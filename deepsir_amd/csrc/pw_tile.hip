@@ -1,0 +1,321 @@
+// LDS-tiled point-wise GEMM for the wide layers (Cin a multiple of 32 in [64,768],
+// Cout >= 64): pyramid levels 2/3, decoder, 128/256-wide aggregation MLP layers.
+//
+// Block = 4 waves, tile (64*RT rows) x 64 columns x 32-channel K chunks:
+//   * global -> registers as 16-byte loads (A: RT float4 per thread, same 4 channels of RT*... rows,
+//     W: 2 float4 per thread), the producer's GroupNorm + LeakyReLU applied in registers,
+//     then ds_write into the OTHER LDS buffer while the MFMAs of the current chunk run
+//     (double-buffered LDS, one barrier per 32-channel chunk);
+//   * LDS rows are [32+2] floats: the MFMA fragment reads (lane (r,q) reads row r, k = 4s+q) are
+//     bank-conflict free (34 r mod 32 = 2 r);
+//   * wave w owns rows [16*RT*w, 16*RT*(w+1)) and all four 16-column tiles: per k-step RT A reads +
+//     4 B reads feed 4*RT MFMAs (v_mfma_f32_16x16x4_f32, channels ascending = k-ordered fmaf chain);
+//   * a weight tile is re-read from L2 once per 64*RT rows.
+// Epilogues: GroupNorm statistics (wave-level reduction, one fp64 atomic per group per wave),
+// bias + LeakyReLU, linear (+residual), attentive pooling — as in pw_gemm.hip.
+#include "kernels.h"
+#include "device_utils.h"
+
+namespace dsir {
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int LDS_LD = BK + 2;
+constexpr int BN = 64;
+constexpr int NT = 4;
+constexpr int MAXC = 768;
+
+struct RowOff { int64_t o0, o1; };
+
+__device__ __forceinline__ RowOff row_off(const GemmArgs& p, int cloud, int row) {
+  RowOff r{-1, -1};
+  if (row >= p.M) return r;
+  {
+    const Seg& s = p.seg[0];
+    const int sr = s.idx ? s.idx[cloud * s.idx_cloud_stride + row] : row / s.row_div;
+    r.o0 = cloud * s.cloud_stride + (int64_t)sr * s.ld;
+  }
+  if (p.nseg > 1) {
+    const Seg& s = p.seg[1];
+    const int sr = s.idx ? s.idx[cloud * s.idx_cloud_stride + row] : row / s.row_div;
+    r.o1 = cloud * s.cloud_stride + (int64_t)sr * s.ld;
+  }
+  return r;
+}
+
+template <int RT, int EPI>
+__global__ __launch_bounds__(256) void pw_tile_kernel(const GemmArgs p) {
+  constexpr int BM = 64 * RT;
+  constexpr int AV = BM / 32;     // float4 A loads per thread per chunk (BM*32/4/256)
+  __shared__ float As[2][BM * LDS_LD];
+  __shared__ float Ws[2][BN * LDS_LD];
+  __shared__ float s_sc[MAXC];
+  __shared__ float s_sh[MAXC];
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int cloud = blockIdx.z;
+  const int m0 = blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+
+  for (int c = tid; c < p.Cin; c += 256) {
+    const Seg& s = (c < p.seg[0].C) ? p.seg[0] : p.seg[1];
+    const int lc = (c < p.seg[0].C) ? c : c - p.seg[0].C;
+    float scale = 1.f, shift = 0.f;
+    if (s.gn.stats) {
+      const int g = lc / (s.C / s.gn.groups);
+      const double* st = s.gn.stats + ((int64_t)cloud * s.gn.groups + g) * 2;
+      const double mean = st[0] * s.gn.inv_count;
+      double var = st[1] * s.gn.inv_count - mean * mean;
+      var = var > 0.0 ? var : 0.0;
+      const double rstd = 1.0 / sqrt(var + 1e-5);
+      const double scd = (double)s.gn.gamma[lc] * rstd;
+      scale = (float)scd;
+      shift = (float)((double)s.gn.beta[lc] - mean * scd);
+    }
+    s_sc[c] = scale;
+    s_sh[c] = shift;
+  }
+
+  // staging assignment: thread -> 4 consecutive channels (tid & 7) of rows (tid >> 3) + 32 i
+  const int c4 = (tid & 7) * 4;
+  const int sr0 = tid >> 3;
+  RowOff ro[AV];
+#pragma unroll
+  for (int i = 0; i < AV; ++i) ro[i] = row_off(p, cloud, m0 + sr0 + 32 * i);
+  const float* wrow[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int col = n0 + sr0 + 32 * i;
+    wrow[i] = col < p.Cout ? p.W + (int64_t)col * p.Cin + c4 : nullptr;
+  }
+  const int C0 = p.seg[0].C;
+  const int act0 = p.seg[0].act, act1 = p.nseg > 1 ? p.seg[1].act : 0;
+  __syncthreads();   // s_sc / s_sh ready
+
+  float4 ra[AV], rw[2];
+  auto gload = [&](int k0) {
+    const int c = k0 + c4;
+    const bool s1 = c >= C0;
+    const float* base = s1 ? p.seg[1].x : p.seg[0].x;
+    const int lc = s1 ? c - C0 : c;
+#pragma unroll
+    for (int i = 0; i < AV; ++i) {
+      const int64_t o = s1 ? ro[i].o1 : ro[i].o0;
+      ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (o >= 0) ra[i] = *reinterpret_cast<const float4*>(base + o + lc);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      rw[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (wrow[i]) rw[i] = *reinterpret_cast<const float4*>(wrow[i] + k0);
+    }
+  };
+  auto lstore = [&](int k0, int buf) {
+    const int c = k0 + c4;
+    const int act = (c >= C0) ? act1 : act0;
+    const float4 sc = *reinterpret_cast<const float4*>(&s_sc[c]);
+    const float4 sh = *reinterpret_cast<const float4*>(&s_sh[c]);
+#pragma unroll
+    for (int i = 0; i < AV; ++i) {
+      float4 v = ra[i];
+      if (ro[i].o0 >= 0) {
+        v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y); v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+        if (act) {
+          v.x = v.x < 0.f ? 0.2f * v.x : v.x; v.y = v.y < 0.f ? 0.2f * v.y : v.y;
+          v.z = v.z < 0.f ? 0.2f * v.z : v.z; v.w = v.w < 0.f ? 0.2f * v.w : v.w;
+        }
+      }
+      float2* d = reinterpret_cast<float2*>(&As[buf][(sr0 + 32 * i) * LDS_LD + c4]);
+      d[0] = make_float2(v.x, v.y);
+      d[1] = make_float2(v.z, v.w);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float2* d = reinterpret_cast<float2*>(&Ws[buf][(sr0 + 32 * i) * LDS_LD + c4]);
+      d[0] = make_float2(rw[i].x, rw[i].y);
+      d[1] = make_float2(rw[i].z, rw[i].w);
+    }
+  };
+
+  f32x4 acc[RT][NT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[rt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nchunks = p.Cin / BK;
+  gload(0);
+  lstore(0, 0);
+  __syncthreads();
+  int buf = 0;
+  for (int kc = 0; kc < nchunks; ++kc) {
+    const bool more = kc + 1 < nchunks;
+    if (more) gload((kc + 1) * BK);
+    const float* At = As[buf];
+    const float* Wt = Ws[buf];
+#pragma unroll
+    for (int s = 0; s < BK / 4; ++s) {
+      float a[RT], b[NT];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) a[rt] = At[(16 * RT * w + 16 * rt + fr) * LDS_LD + 4 * s + fq];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) b[t] = Wt[(16 * t + fr) * LDS_LD + 4 * s + fq];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt], b[t], acc[rt][t], 0, 0, 0);
+    }
+    if (more) lstore((kc + 1) * BK, buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  // ---- epilogues.  C layout: col = lane & 15, row = 4 * (lane >> 4) + reg.
+  const int r0 = m0 + 16 * RT * w;
+  float bv[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int col = n0 + 16 * t + fr;
+    bv[t] = (p.bias && col < p.Cout) ? p.bias[col] : 0.f;
+  }
+  if (EPI == EPI_GN) {
+    float* Y = p.Y + cloud * p.y_cloud_stride;
+    float s1[NT], s2[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      s1[t] = 0.f; s2[t] = 0.f;
+      const int col = n0 + 16 * t + fr;
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = r0 + 16 * rt + 4 * fq + r;
+          if (row < p.M && col < p.Cout) {
+            const float v = acc[rt][t][r] + bv[t];
+            Y[(int64_t)row * p.ldy + col] = v;
+            s1[t] += v;
+            s2[t] += v * v;
+          }
+        }
+    }
+    const int gw = p.Cout / p.groups_out;     // 8, 16, 32 or 64 channels per group
+    const int lw = gw < 16 ? gw : 16;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      s1[t] += __shfl_xor(s1[t], 16); s1[t] += __shfl_xor(s1[t], 32);
+      s2[t] += __shfl_xor(s2[t], 16); s2[t] += __shfl_xor(s2[t], 32);
+      for (int o = 1; o < lw; o <<= 1) { s1[t] += __shfl_xor(s1[t], o); s2[t] += __shfl_xor(s2[t], o); }
+    }
+    if (fq == 0 && (fr % lw) == 0 && r0 < p.M) {
+      const int tpg = gw > 16 ? gw / 16 : 1;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        if ((t % tpg) != 0) continue;
+        const int col = n0 + 16 * t + fr;
+        if (col >= p.Cout) continue;
+        double d1 = 0.0, d2 = 0.0;
+#pragma unroll
+        for (int u = 0; u < NT; ++u)
+          if (u >= t && u < t + tpg) { d1 += (double)s1[u]; d2 += (double)s2[u]; }
+        double* st = p.stats_out + ((int64_t)cloud * p.groups_out + col / gw) * 2;
+        atomicAdd(st, d1);
+        atomicAdd(st + 1, d2);
+      }
+    }
+  } else if (EPI == EPI_ACT || EPI == EPI_LINEAR) {
+    float* Y = p.Y + cloud * p.y_cloud_stride;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int col = n0 + 16 * t + fr;
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = r0 + 16 * rt + 4 * fq + r;
+          if (row < p.M && col < p.Cout) {
+            float v = acc[rt][t][r] + bv[t];
+            if (EPI == EPI_LINEAR && p.residual) v += p.residual[cloud * p.res_cloud_stride + (int64_t)row * p.ldres + col];
+            if (EPI == EPI_ACT && v < 0.f) v *= 0.2f;
+            Y[(int64_t)row * p.ldy + col] = v;
+          }
+        }
+    }
+  } else if (EPI == EPI_ATT) {
+    float* Y = p.Y + cloud * p.y_cloud_stride;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      const int trow = r0 + 16 * rt;
+      if (trow >= p.M) continue;
+      RowOff er[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) er[r] = row_off(p, cloud, trow + 4 * fq + r);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int col = n0 + 16 * t + fr;
+        const bool cs1 = col >= C0;
+        const float* base = cs1 ? p.seg[1].x : p.seg[0].x;
+        const int lc = cs1 ? col - C0 : col;
+        const int act = cs1 ? act1 : act0;
+        const float scv = s_sc[col < p.Cin ? col : 0], shv = s_sh[col < p.Cin ? col : 0];
+        float mx = fmaxf(fmaxf(acc[rt][t][0], acc[rt][t][1]), fmaxf(acc[rt][t][2], acc[rt][t][3]));
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float e[4], se = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { e[r] = expf(acc[rt][t][r] - mx); se += e[r]; }
+        se += __shfl_xor(se, 16); se += __shfl_xor(se, 32);
+        float o = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float f = 0.f;
+          if (col < p.Cin) {
+            const float v = fmaf(base[(cs1 ? er[r].o1 : er[r].o0) + lc], scv, shv);
+            f = (act && v < 0.f) ? 0.2f * v : v;
+          }
+          o += f * (e[r] / se);
+        }
+        o += __shfl_xor(o, 16); o += __shfl_xor(o, 32);
+        if (lane < 16 && col < p.Cout) Y[(int64_t)(trow >> 4) * p.ldy + col] = o;
+      }
+    }
+  }
+}
+
+template <int RT, int EPI>
+void launch_t(const GemmArgs& a, hipStream_t st) {
+  dim3 grid((a.M + 64 * RT - 1) / (64 * RT), (a.Cout + BN - 1) / BN, a.clouds);
+  hipLaunchKernelGGL((pw_tile_kernel<RT, EPI>), grid, dim3(256), 0, st, a);
+}
+
+template <int RT>
+bool launch_e(const GemmArgs& a, hipStream_t st) {
+  switch (a.epi) {
+    case EPI_GN: launch_t<RT, EPI_GN>(a, st); return true;
+    case EPI_ACT: launch_t<RT, EPI_ACT>(a, st); return true;
+    case EPI_LINEAR: launch_t<RT, EPI_LINEAR>(a, st); return true;
+    case EPI_ATT: launch_t<RT, EPI_ATT>(a, st); return true;
+    default: return false;
+  }
+}
+
+bool seg_ok(const Seg& s) {
+  return (s.ld % 4) == 0 && (s.cloud_stride % 4) == 0 && (reinterpret_cast<uintptr_t>(s.x) % 16) == 0;
+}
+
+}  // namespace
+
+// Returns false when the layer is outside this kernel's envelope (caller falls back to pw_gemm.hip).
+bool launch_pw_tile(const GemmArgs& a, hipStream_t st) {
+  if (a.amode != A_SEGS || a.Cin < 64 || a.Cin > MAXC || (a.Cin % BK) != 0 || a.Cout < 64) return false;
+  if (!seg_ok(a.seg[0]) || (a.nseg > 1 && (!seg_ok(a.seg[1]) || (a.seg[0].C % 4) != 0))) return false;
+  if ((reinterpret_cast<uintptr_t>(a.W) % 16) != 0) return false;
+  if (a.epi == EPI_GN && ((a.Cout / a.groups_out) % 8) != 0) return false;
+  // rows per block: a function of M only (batch-invariant tiling); 128-row tiles unless they waste > 25 %
+  const int pad128 = ((a.M + 127) / 128) * 128, pad64 = ((a.M + 63) / 64) * 64;
+  if (a.M >= 128 && pad128 * 3 <= pad64 * 4) return launch_e<2>(a, st);
+  return launch_e<1>(a, st);
+}
+
+}  // namespace dsir
