@@ -135,6 +135,25 @@ def main():
     dt = time.perf_counter() - t0
     match_ms, match_n = eng.match_timer(reset=True)
     eng.enable_match_timer(False)
+
+    # batch-1 latency (the reference's own evaluation mode, test.py:56 BATCH_SIZE = 1): one pair in flight,
+    # launch sequence replayed from a hipGraph.  Reported beside the throughput number, not as `value`.
+    latency = None
+    if rank == 0 and world == 1:
+        s1, r1 = src[:1].contiguous(), ref[:1].contiguous()
+        eng.enable_graph(True)
+        o1 = eng.register(s1, r1, n_iter, want_aux=False)
+        for _ in range(3):
+            eng.register(s1, r1, n_iter, want_aux=False, sync=False, out={"transforms": o1["transforms"]})
+        eng.sync()
+        reps = 20
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            eng.register(s1, r1, n_iter, want_aux=False, sync=False, out={"transforms": o1["transforms"]})
+        eng.sync()
+        ms = (time.perf_counter() - t1) / reps * 1e3
+        eng.enable_graph(False)
+        latency = {"pairs_in_flight": 1, "ms_per_pair": round(ms, 4), "pairs_per_s": round(1e3 / ms, 2), "hipgraph": True}
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -169,6 +188,8 @@ def main():
                          "launches": int(match_n), "avg_launch_ms": round(avg_match_s * 1e3, 5),
                          "flops_per_launch": match_flops(P, N, N)},
         }
+        if latency is not None:
+            line["batch1_latency"] = latency
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, sd, N, n_iter)
         print(json.dumps(line), flush=True)

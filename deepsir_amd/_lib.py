@@ -74,6 +74,7 @@ SYMBOLS = {
     "dsir_register": (C.c_int, [C.c_void_p, C.POINTER(dsir_pair_batch), C.c_int, C.POINTER(dsir_pair_result)]),
     "dsir_match_timer": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), c_i64_p]),
     "dsir_enable_match_timer": (C.c_int, [C.c_void_p, C.c_int]),
+    "dsir_enable_graph": (C.c_int, [C.c_void_p, C.c_int]),
 }
 
 _lib = None

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <unordered_map>
@@ -90,6 +91,10 @@ struct dsir_ctx {
   size_t stats_cap = 0, stats_top = 0;
   // nn_match timing
   bool time_match = false;
+  // hipGraph replay of dsir_register (launch-bound small batches)
+  bool use_graph = false;
+  hipGraphExec_t graph_exec = nullptr;
+  std::vector<unsigned char> graph_key;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> match_events;
   size_t match_events_used = 0;
   double match_ms = 0.0;
@@ -471,7 +476,18 @@ int build_pyramid(dsir_ctx* c, const float* points, int stride, int clouds, int 
   for (int l = 0; l < g.num_layers; ++l) {
     // every level's points are a prefix of the level above, hence of the input cloud (data_base.py:166-172)
     launch_copy_xyz(points, (int64_t)n * stride, stride, p.nl[l], clouds, xyz + (int64_t)p.off[l] * 3, xyz_cs, st);
-    launch_knn16(points, (int64_t)n * stride, stride, p.nl[l], clouds, neigh + (int64_t)p.off[l] * kKnn, neigh_cs, st);
+    static const bool no_grid = getenv("DSIR_NO_GRID") != nullptr;   // A/B switch
+    if (p.nl[l] >= 2048 && !no_grid) {
+      // large levels: exact grid-pruned search (knn_grid.hip); same bits as the brute force
+      const size_t mark = c->ws.mark();
+      void* scratch = c->ws.raw(knn_grid_scratch_bytes(clouds, p.nl[l]));
+      if (c->ws.overflow) return fail(c, "workspace exhausted in the KNN pyramid");
+      launch_knn16_grid(points, (int64_t)n * stride, stride, p.nl[l], clouds, neigh + (int64_t)p.off[l] * kKnn, neigh_cs,
+                        scratch, st);
+      c->ws.release(mark);   // stream-ordered: later users of this memory run after the query kernel
+    } else {
+      launch_knn16(points, (int64_t)n * stride, stride, p.nl[l], clouds, neigh + (int64_t)p.off[l] * kKnn, neigh_cs, st);
+    }
     launch_copy_rows_i32(neigh + (int64_t)p.off[l] * kKnn, neigh_cs, p.nl[l + 1], kKnn, clouds,
                          sub + (int64_t)p.soff[l] * kKnn, sub_cs, st);
     launch_nn1(points, (int64_t)n * stride, stride, p.nl[l], p.nl[l + 1], clouds, interp + p.off[l], p.S, st);
@@ -549,6 +565,7 @@ void dsir_destroy(dsir_ctx* c) {
   hipSetDevice(c->device);
   hipStreamSynchronize(c->stream);
   for (auto& e : c->match_events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+  if (c->graph_exec) hipGraphExecDestroy(c->graph_exec);
   if (c->dweights) hipFree(c->dweights);
   if (c->stats) hipFree(c->stats);
   if (c->ws.base) hipFree(c->ws.base);
@@ -624,6 +641,7 @@ int dsir_knn_pyramid(dsir_ctx* c, const float* points, int stride, int clouds, i
   if (!c) return 1;
   HIP_OK(c, hipSetDevice(c->device));
   if (clouds < 1 || stride < 3) return fail(c, "dsir_knn_pyramid: bad arguments");
+  c->ws.top = 0; c->ws.overflow = false;
   if (int r = build_pyramid(c, points, stride, clouds, n, xyz, neigh, sub, interp)) return r;
   return post(c);
 }
@@ -697,10 +715,7 @@ int dsir_kabsch(dsir_ctx* c, const float* src, const float* tgt, const float* w,
   return post(c);
 }
 
-int dsir_register(dsir_ctx* c, const dsir_pair_batch* in, int n_iter, const dsir_pair_result* out) {
-  if (check_ready(c)) return 1;
-  if (!in || !out || !out->transforms) return fail(c, "dsir_register: null argument");
-  HIP_OK(c, hipSetDevice(c->device));
+static int register_enqueue(dsir_ctx* c, const dsir_pair_batch* in, int n_iter, const dsir_pair_result* out) {
   const dsir_cfg& g = c->cfg;
   const int P = in->pairs, J = in->n_src, K = in->n_ref, cin = g.feat_len;
   if (P < 1 || P > g.max_pairs) return fail(c, "pairs=%d outside [1,%d]", P, g.max_pairs);
@@ -840,7 +855,47 @@ int dsir_register(dsir_ctx* c, const dsir_pair_batch* in, int n_iter, const dsir
     a.matched_out = (it == n_iter - 1) ? out->pt_ref_new : nullptr;
     launch_kabsch(a, st);
   }
+  if (c->ws.overflow) return fail(c, "workspace exhausted (raise max_points / max_pairs in dsir_cfg)");
+  return 0;
+}
+
+int dsir_register(dsir_ctx* c, const dsir_pair_batch* in, int n_iter, const dsir_pair_result* out) {
+  if (check_ready(c)) return 1;
+  if (!in || !out || !out->transforms) return fail(c, "dsir_register: null argument");
+  HIP_OK(c, hipSetDevice(c->device));
+  if (!c->use_graph || c->time_match) {
+    if (int r = register_enqueue(c, in, n_iter, out)) return r;
+    return post(c);
+  }
+  // Graph mode: the whole launch sequence (~450 kernels) is captured once per distinct call
+  // signature (sizes AND buffer addresses) and replayed with one hipGraphLaunch.
+  std::vector<unsigned char> key(sizeof(*in) + sizeof(*out) + sizeof(int));
+  std::memcpy(key.data(), in, sizeof(*in));
+  std::memcpy(key.data() + sizeof(*in), out, sizeof(*out));
+  std::memcpy(key.data() + sizeof(*in) + sizeof(*out), &n_iter, sizeof(int));
+  if (!c->graph_exec || key != c->graph_key) {
+    if (c->graph_exec) { hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
+    HIP_OK(c, hipStreamSynchronize(c->stream));
+    HIP_OK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+    const int rc = register_enqueue(c, in, n_iter, out);
+    hipGraph_t graph = nullptr;
+    const hipError_t e = hipStreamEndCapture(c->stream, &graph);
+    if (rc != 0) { if (graph) hipGraphDestroy(graph); return rc; }
+    if (e != hipSuccess || !graph) return fail(c, "hipStreamEndCapture: %s", hipGetErrorString(e));
+    const hipError_t e2 = hipGraphInstantiate(&c->graph_exec, graph, nullptr, nullptr, 0);
+    hipGraphDestroy(graph);
+    if (e2 != hipSuccess) { c->graph_exec = nullptr; return fail(c, "hipGraphInstantiate: %s", hipGetErrorString(e2)); }
+    c->graph_key = key;
+  }
+  HIP_OK(c, hipGraphLaunch(c->graph_exec, c->stream));
   return post(c);
+}
+
+int dsir_enable_graph(dsir_ctx* c, int enable) {
+  if (!c) return 1;
+  c->use_graph = enable != 0;
+  if (!c->use_graph && c->graph_exec) { hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; c->graph_key.clear(); }
+  return 0;
 }
 
 int dsir_enable_match_timer(dsir_ctx* c, int enable) {

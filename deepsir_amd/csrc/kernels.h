@@ -79,6 +79,10 @@ void launch_narrow_i64(const int64_t* src, int32_t* dst, int64_t n, hipStream_t 
 // KNN (data_base.py:153-183): one level.  support = first n_support points of `pts`.
 void launch_knn16(const float* pts, int64_t cloud_stride, int stride, int n, int clouds, int32_t* out,
                   int64_t out_cloud_stride, hipStream_t st);
+// exact grid-pruned variant for large levels (knn_grid.hip); scratch from knn_grid_scratch_bytes
+size_t knn_grid_scratch_bytes(int clouds, int n);
+void launch_knn16_grid(const float* pts, int64_t cloud_stride, int stride, int n, int clouds, int32_t* out,
+                       int64_t out_cloud_stride, void* scratch, hipStream_t st);
 void launch_nn1(const float* pts, int64_t cloud_stride, int stride, int n_query, int n_support, int clouds,
                 int32_t* out, int64_t out_cloud_stride, hipStream_t st);
 void launch_copy_xyz(const float* pts, int64_t cloud_stride, int stride, int n, int clouds, float* out,

@@ -1,0 +1,280 @@
+// Exact 16-NN through a uniform grid, for the large pyramid levels (n >= 2048).
+// Same result, bit for bit, as the brute force of knn.hip / oracle/knn.py: fp32
+// d = (dx*dx + dy*dy) + dz*dz without FMA contraction, neighbours ordered by
+// (d, then lower index).  The grid only prunes: a query visits the cells of growing
+// Chebyshev shells around its own cell and stops once its 16th best distance is
+// strictly (with a safety margin against fp32 rounding) inside the cube already
+// visited, so every point that could enter or tie the top 16 has been seen.
+//
+// Per level and cloud batch: bounding box + cell size (one block per cloud),
+// cell histogram, exclusive scan (one block per cloud), scatter into cell order
+// (xyz + original index packed in a float4), query (one lane per point, points
+// taken in cell order so that a wave's lanes walk neighbouring cells).
+// Candidates arrive in arbitrary index order, hence the lexicographic insertion.
+#include "kernels.h"
+#include "device_utils.h"
+
+namespace dsir {
+
+namespace {
+
+struct GridParams {
+  float ox, oy, oz, h, inv_h;
+  int gx, gy, gz;
+};
+
+constexpr int kPointsPerCell = 8;
+
+__device__ __forceinline__ float sqdist3(float qx, float qy, float qz, float sx, float sy, float sz) {
+  const float dx = __fsub_rn(sx, qx), dy = __fsub_rn(sy, qy), dz = __fsub_rn(sz, qz);
+  return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+}
+
+__device__ __forceinline__ int cell_coord(float p, float o, float inv_h, int g) {
+  int c = (int)floorf((p - o) * inv_h);
+  return c < 0 ? 0 : (c >= g ? g - 1 : c);
+}
+
+// one block per cloud: bounding box, then cell size / grid dimensions
+__global__ __launch_bounds__(1024) void grid_setup_kernel(const float* __restrict__ pts, int64_t cs, int stride, int n,
+                                                          int max_cells, GridParams* __restrict__ gp) {
+  __shared__ float red[6][16];
+  const int cloud = blockIdx.x;
+  const float* P = pts + cloud * cs;
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int i = threadIdx.x; i < n; i += blockDim.x)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float v = P[(int64_t)i * stride + k];
+      lo[k] = fminf(lo[k], v);
+      hi[k] = fmaxf(hi[k], v);
+    }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    float a = lo[k], b = hi[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a = fminf(a, __shfl_xor(a, o)); b = fmaxf(b, __shfl_xor(b, o)); }
+    if (lane == 0) { red[k][w] = a; red[3 + k][w] = b; }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float mn[3], mx[3];
+    for (int k = 0; k < 3; ++k) {
+      mn[k] = red[k][0]; mx[k] = red[3 + k][0];
+      for (int ww = 1; ww < (int)(blockDim.x >> 6); ++ww) { mn[k] = fminf(mn[k], red[k][ww]); mx[k] = fmaxf(mx[k], red[3 + k][ww]); }
+    }
+    float ext[3], emax = 0.f;
+    for (int k = 0; k < 3; ++k) { ext[k] = mx[k] - mn[k]; emax = fmaxf(emax, ext[k]); }
+    if (!(emax > 0.f) || !isfinite(emax)) emax = 1.f;     // all points coincide (or garbage): one cell
+    // cell size for ~kPointsPerCell points per occupied cell; flat / thin clouds are handled by
+    // flooring each extent at a fraction of the largest one before taking the volume
+    float vol = 1.f;
+    for (int k = 0; k < 3; ++k) vol *= fmaxf(ext[k], emax * 1e-3f);
+    const float target = fmaxf((float)n / (float)kPointsPerCell, 1.f);
+    float h = cbrtf(vol / target);
+    if (!(h > 0.f) || !isfinite(h)) h = emax;
+    int g[3];
+    for (int it = 0; it < 64; ++it) {
+      long long prod = 1;
+      for (int k = 0; k < 3; ++k) {
+        g[k] = (int)fminf(floorf(ext[k] / h) + 1.f, 1.0e6f);
+        if (g[k] < 1) g[k] = 1;
+        prod *= g[k];
+      }
+      if (prod <= max_cells) break;
+      h *= 1.26f;
+    }
+    GridParams q;
+    q.ox = mn[0]; q.oy = mn[1]; q.oz = mn[2]; q.h = h; q.inv_h = 1.f / h; q.gx = g[0]; q.gy = g[1]; q.gz = g[2];
+    gp[cloud] = q;
+  }
+}
+
+__global__ __launch_bounds__(256) void grid_count_kernel(const float* __restrict__ pts, int64_t cs, int stride, int n,
+                                                         const GridParams* __restrict__ gp, int max_cells,
+                                                         int* __restrict__ cell_of, int* __restrict__ counts) {
+  const int cloud = blockIdx.y;
+  const GridParams g = gp[cloud];
+  const float* P = pts + cloud * cs;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int cx = cell_coord(P[(int64_t)i * stride], g.ox, g.inv_h, g.gx);
+    const int cy = cell_coord(P[(int64_t)i * stride + 1], g.oy, g.inv_h, g.gy);
+    const int cz = cell_coord(P[(int64_t)i * stride + 2], g.oz, g.inv_h, g.gz);
+    const int c = (cz * g.gy + cy) * g.gx + cx;
+    cell_of[(int64_t)cloud * n + i] = c;
+    atomicAdd(&counts[(int64_t)cloud * max_cells + c], 1);
+  }
+}
+
+// one block per cloud: starts = exclusive scan(counts); cursor = starts (consumed by the scatter)
+__global__ __launch_bounds__(1024) void grid_scan_kernel(const int* __restrict__ counts, int max_cells,
+                                                         const GridParams* __restrict__ gp, int* __restrict__ starts,
+                                                         int* __restrict__ cursor) {
+  __shared__ int wsum[16];
+  __shared__ int carry_s;
+  const int cloud = blockIdx.x;
+  const GridParams g = gp[cloud];
+  const int ncell = g.gx * g.gy * g.gz;
+  const int* C = counts + (int64_t)cloud * max_cells;
+  int* S = starts + (int64_t)cloud * (max_cells + 1);
+  int* U = cursor + (int64_t)cloud * max_cells;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < ncell; base += 1024) {
+    const int i = base + threadIdx.x;
+    const int v = i < ncell ? C[i] : 0;
+    int x = v;                                   // inclusive scan inside the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o); if (lane >= o) x += y; }
+    if (lane == 63) wsum[w] = x;
+    __syncthreads();
+    int woff = 0;
+    for (int ww = 0; ww < w; ++ww) woff += wsum[ww];
+    const int excl = carry_s + woff + x - v;
+    if (i < ncell) { S[i] = excl; U[i] = excl; }
+    __syncthreads();
+    if (threadIdx.x == 1023) carry_s = excl + v;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) S[ncell] = carry_s;
+}
+
+__global__ __launch_bounds__(256) void grid_scatter_kernel(const float* __restrict__ pts, int64_t cs, int stride, int n,
+                                                           const int* __restrict__ cell_of, int max_cells,
+                                                           int* __restrict__ cursor, float4* __restrict__ sorted) {
+  const int cloud = blockIdx.y;
+  const float* P = pts + cloud * cs;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int c = cell_of[(int64_t)cloud * n + i];
+    const int pos = atomicAdd(&cursor[(int64_t)cloud * max_cells + c], 1);
+    sorted[(int64_t)cloud * n + pos] =
+        make_float4(P[(int64_t)i * stride], P[(int64_t)i * stride + 1], P[(int64_t)i * stride + 2], __int_as_float(i));
+  }
+}
+
+struct TopLex {
+  float d[kKnn];
+  int i[kKnn];
+  __device__ __forceinline__ void init() {
+#pragma unroll
+    for (int t = 0; t < kKnn; ++t) { d[t] = INFINITY; i[t] = 0x7fffffff; }
+  }
+  __device__ __forceinline__ void insert(float dist, int idx) {
+    if (dist < d[kKnn - 1] || (dist == d[kKnn - 1] && idx < i[kKnn - 1])) {
+      d[kKnn - 1] = dist; i[kKnn - 1] = idx;
+#pragma unroll
+      for (int t = kKnn - 1; t > 0; --t) {
+        const bool sw = d[t] < d[t - 1] || (d[t] == d[t - 1] && i[t] < i[t - 1]);
+        const float dl = sw ? d[t] : d[t - 1], dh = sw ? d[t - 1] : d[t];
+        const int il = sw ? i[t] : i[t - 1], ih = sw ? i[t - 1] : i[t];
+        d[t - 1] = dl; d[t] = dh; i[t - 1] = il; i[t] = ih;
+      }
+    }
+  }
+};
+
+__global__ __launch_bounds__(256) void grid_knn_kernel(const float4* __restrict__ sorted, const int* __restrict__ starts,
+                                                       const GridParams* __restrict__ gp, int max_cells, int n,
+                                                       int32_t* __restrict__ out, int64_t ocs) {
+  const int cloud = blockIdx.y;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const GridParams g = gp[cloud];
+  const float4* S = sorted + (int64_t)cloud * n;
+  const int* ST = starts + (int64_t)cloud * (max_cells + 1);
+  const float4 q = S[t];
+  const int qi = __float_as_int(q.w);
+  const int cx = cell_coord(q.x, g.ox, g.inv_h, g.gx);
+  const int cy = cell_coord(q.y, g.oy, g.inv_h, g.gy);
+  const int cz = cell_coord(q.z, g.oz, g.inv_h, g.gz);
+  TopLex top;
+  top.init();
+  const int rmax = max(max(max(cx, g.gx - 1 - cx), max(cy, g.gy - 1 - cy)), max(cz, g.gz - 1 - cz));
+  for (int r = 0; r <= rmax; ++r) {
+    const int z0 = max(cz - r, 0), z1 = min(cz + r, g.gz - 1);
+    const int y0 = max(cy - r, 0), y1 = min(cy + r, g.gy - 1);
+    const int x0 = max(cx - r, 0), x1 = min(cx + r, g.gx - 1);
+    for (int z = z0; z <= z1; ++z) {
+      const bool zshell = (z == cz - r) || (z == cz + r);
+      for (int y = y0; y <= y1; ++y) {
+        const bool yshell = zshell || (y == cy - r) || (y == cy + r);
+        const int rowbase = (z * g.gy + y) * g.gx;
+        if (yshell) {                               // whole x-run of this row lies on the shell: cells are contiguous
+          const int b = ST[rowbase + x0], e = ST[rowbase + x1 + 1];
+          for (int k = b; k < e; ++k) {
+            const float4 s = S[k];
+            top.insert(sqdist3(q.x, q.y, q.z, s.x, s.y, s.z), __float_as_int(s.w));
+          }
+        } else {                                    // interior row: only the two end cells are on the shell
+          if (cx - r >= 0) {
+            const int b = ST[rowbase + cx - r], e = ST[rowbase + cx - r + 1];
+            for (int k = b; k < e; ++k) {
+              const float4 s = S[k];
+              top.insert(sqdist3(q.x, q.y, q.z, s.x, s.y, s.z), __float_as_int(s.w));
+            }
+          }
+          if (cx + r <= g.gx - 1) {
+            const int b = ST[rowbase + cx + r], e = ST[rowbase + cx + r + 1];
+            for (int k = b; k < e; ++k) {
+              const float4 s = S[k];
+              top.insert(sqdist3(q.x, q.y, q.z, s.x, s.y, s.z), __float_as_int(s.w));
+            }
+          }
+        }
+      }
+    }
+    // distance from the query to the nearest face of the visited cube that still has cells behind it
+    float bound = INFINITY;
+    if (cx - r > 0) bound = fminf(bound, q.x - (g.ox + (float)(cx - r) * g.h));
+    if (cx + r < g.gx - 1) bound = fminf(bound, (g.ox + (float)(cx + r + 1) * g.h) - q.x);
+    if (cy - r > 0) bound = fminf(bound, q.y - (g.oy + (float)(cy - r) * g.h));
+    if (cy + r < g.gy - 1) bound = fminf(bound, (g.oy + (float)(cy + r + 1) * g.h) - q.y);
+    if (cz - r > 0) bound = fminf(bound, q.z - (g.oz + (float)(cz - r) * g.h));
+    if (cz + r < g.gz - 1) bound = fminf(bound, (g.oz + (float)(cz + r + 1) * g.h) - q.z);
+    if (bound == INFINITY) break;                   // the cube covers the whole grid
+    // Points binned by clamped/rounded coordinates can sit a few ulps outside their cell: keep a margin.
+    bound -= 1e-4f * g.h;
+    if (bound > 0.f && top.d[kKnn - 1] < bound * bound * 0.9999f) break;
+  }
+  int32_t* o = out + cloud * ocs + (int64_t)qi * kKnn;
+#pragma unroll
+  for (int k = 0; k < kKnn; k += 4) *reinterpret_cast<int4*>(o + k) = make_int4(top.i[k], top.i[k + 1], top.i[k + 2], top.i[k + 3]);
+}
+
+}  // namespace
+
+size_t knn_grid_scratch_bytes(int clouds, int n) {
+  const size_t max_cells = (size_t)n / 2 + 64;
+  size_t b = 0;
+  b += ((size_t)clouds * sizeof(GridParams) + 255) & ~(size_t)255;
+  b += ((size_t)clouds * n * sizeof(int) + 255) & ~(size_t)255;                 // cell_of
+  b += ((size_t)clouds * max_cells * sizeof(int) + 255) & ~(size_t)255;        // counts
+  b += ((size_t)clouds * (max_cells + 1) * sizeof(int) + 255) & ~(size_t)255;  // starts
+  b += ((size_t)clouds * max_cells * sizeof(int) + 255) & ~(size_t)255;        // cursor
+  b += ((size_t)clouds * n * sizeof(float4) + 255) & ~(size_t)255;             // sorted
+  return b;
+}
+
+void launch_knn16_grid(const float* pts, int64_t cs, int stride, int n, int clouds, int32_t* out, int64_t ocs,
+                       void* scratch, hipStream_t st) {
+  const int max_cells = n / 2 + 64;
+  char* p = reinterpret_cast<char*>(scratch);
+  auto take = [&](size_t bytes) { char* r = p; p += (bytes + 255) & ~(size_t)255; return r; };
+  GridParams* gp = reinterpret_cast<GridParams*>(take((size_t)clouds * sizeof(GridParams)));
+  int* cell_of = reinterpret_cast<int*>(take((size_t)clouds * n * sizeof(int)));
+  int* counts = reinterpret_cast<int*>(take((size_t)clouds * max_cells * sizeof(int)));
+  int* starts = reinterpret_cast<int*>(take((size_t)clouds * (max_cells + 1) * sizeof(int)));
+  int* cursor = reinterpret_cast<int*>(take((size_t)clouds * max_cells * sizeof(int)));
+  float4* sorted = reinterpret_cast<float4*>(take((size_t)clouds * n * sizeof(float4)));
+  hipMemsetAsync(counts, 0, (size_t)clouds * max_cells * sizeof(int), st);
+  hipLaunchKernelGGL(grid_setup_kernel, dim3(clouds), dim3(1024), 0, st, pts, cs, stride, n, max_cells, gp);
+  const int gx = (n + 255) / 256;
+  hipLaunchKernelGGL(grid_count_kernel, dim3(gx, clouds), dim3(256), 0, st, pts, cs, stride, n, gp, max_cells, cell_of, counts);
+  hipLaunchKernelGGL(grid_scan_kernel, dim3(clouds), dim3(1024), 0, st, counts, max_cells, gp, starts, cursor);
+  hipLaunchKernelGGL(grid_scatter_kernel, dim3(gx, clouds), dim3(256), 0, st, pts, cs, stride, n, cell_of, max_cells, cursor, sorted);
+  hipLaunchKernelGGL(grid_knn_kernel, dim3(gx, clouds), dim3(256), 0, st, sorted, starts, gp, max_cells, n, out, ocs);
+}
+
+}  // namespace dsir

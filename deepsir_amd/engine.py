@@ -254,6 +254,10 @@ class Engine:
         return out
 
     # ------------------------------------------------------------------ measurement hooks
+    def enable_graph(self, on=True):
+        """Replay dsir_register through a captured hipGraph (same buffers on every call)."""
+        self._call(self.lib.dsir_enable_graph(self.h, 1 if on else 0))
+
     def enable_match_timer(self, on=True):
         self._call(self.lib.dsir_enable_match_timer(self.h, 1 if on else 0))
 

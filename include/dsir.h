@@ -156,6 +156,10 @@ typedef struct dsir_pair_result {
  * inlier RandLA, weighted Kabsch, SE(3) update}. */
 int dsir_register(dsir_ctx* ctx, const dsir_pair_batch* in, int n_iter, const dsir_pair_result* out);
 
+/* Launch-bound small batches: capture the whole dsir_register launch sequence into a hipGraph once per
+ * call signature (sizes and buffer addresses) and replay it.  Off by default. */
+int dsir_enable_graph(dsir_ctx* ctx, int enable);
+
 /* Test/measurement hooks. */
 /* Wall-clock-free kernel timing of the dominant kernel (nn_match) accumulated
  * with HIP events on the engine stream since the last reset: total ms and

@@ -82,6 +82,33 @@ def test_knn_pyramid_bit_exact(n, seed):
         assert np.array_equal(interp[c].cpu().numpy(), ref["interp_idx"])
 
 
+def test_knn_grid_adversarial_clouds_bit_exact():
+    """The grid-pruned search (levels with >= 2048 points) must equal the brute-force oracle bit for bit
+    on clouds that stress the grid: planar, collinear, clustered with far outliers, all points identical,
+    KITTI-shaped extent."""
+    from deepsir_amd.arch import NetConfig
+    from deepsir_amd.weights import generate_state_dict
+    from oracle.knn import knn
+    cfg = NetConfig(feat_len=3)
+    eng = engine_for(cfg, generate_state_dict(cfg, 0), "w0knn", max_points=16384, max_pairs=1)
+    rng = np.random.default_rng(7)
+    n = 4096
+    planar = rng.uniform(0, 3, (n, 3)).astype(np.float32); planar[:, 2] = 0.5
+    line = np.zeros((n, 3), np.float32); line[:, 0] = rng.uniform(-5, 5, n)
+    blobs = (rng.standard_normal((n, 3)) * 0.05 + rng.integers(0, 4, (n, 1)) * 2.0).astype(np.float32)
+    blobs[:8] = rng.uniform(-500, 500, (8, 3))
+    same = np.tile(np.array([[1.25, -2.5, 0.75]], np.float32), (n, 1))
+    lattice = np.stack(np.meshgrid(*[np.arange(16, dtype=np.float32)] * 3, indexing="ij"), -1).reshape(-1, 3)  # exact ties
+    for name, pts in (("planar", planar), ("line", line), ("blobs", blobs), ("same", same), ("lattice", lattice)):
+        _, neigh, _, _ = eng.knn_pyramid(cu(pts[None]))
+        got = neigh[0, :n].cpu().numpy()
+        assert np.array_equal(got, knn(pts, pts, 16)), name
+    kitti = np.concatenate([rng.uniform(-50, 50, (16384, 2)), rng.uniform(-3, 3, (16384, 1))], 1).astype(np.float32)
+    _, neigh, _, _ = eng.knn_pyramid(cu(kitti[None]))
+    assert np.array_equal(neigh[0, :16384].cpu().numpy(), knn(kitti, kitti, 16))
+    assert np.array_equal(neigh[0, 16384:16384 + 4096].cpu().numpy(), knn(kitti[:4096], kitti[:4096], 16))
+
+
 def test_knn_rejects_small_cloud():
     from deepsir_amd.arch import NetConfig
     from deepsir_amd.engine import EngineError
@@ -258,6 +285,34 @@ def test_determinism_and_full_size_properties():
     Ti = o3["transforms"].cpu().numpy()
     eye = np.tile(np.eye(3, 4, dtype=np.float32), (2, 5, 1, 1))
     np.testing.assert_allclose(Ti, eye, atol=5e-6)
+
+
+def test_graph_replay_is_bitwise_identical():
+    """dsir_enable_graph: captured-and-replayed launches give the same bits as eager launches,
+    also after the inputs in the (same) buffers change."""
+    from deepsir_amd.arch import NetConfig
+    from deepsir_amd.engine import Engine
+    from deepsir_amd.synth import make_batch
+    from deepsir_amd.weights import generate_state_dict
+    cfg = NetConfig(feat_len=3)
+    eng = Engine(cfg, 0, max_points=2048, max_pairs=2)
+    eng.load_state_dict(generate_state_dict(cfg, 0))
+    b1, b2 = make_batch(2048, [31, 32], 3), make_batch(2048, [33, 34], 3)
+    src, ref = cu(b1["points_src"]), cu(b1["points_ref"])
+    eager1 = {k: v.clone() for k, v in eng.register(src, ref, 5).items() if isinstance(v, torch.Tensor)}
+    eng.enable_graph(True)
+    out = eng.register(src, ref, 5)                       # capture + first replay
+    keep = {k: v for k, v in out.items() if isinstance(v, torch.Tensor)}
+    for k in eager1:
+        assert torch.equal(eager1[k], keep[k]), k
+    src.copy_(cu(b2["points_src"])); ref.copy_(cu(b2["points_ref"]))
+    out2 = eng.register(src, ref, 5, out=keep)            # pure replay on new data in the same buffers
+    eng.enable_graph(False)
+    eager2 = eng.register(src, ref, 5)
+    for k in eager1:
+        assert torch.equal(eager2[k], out2[k]), k
+    assert not torch.equal(eager1["transforms"], eager2["transforms"])
+    eng.close()
 
 
 def test_nn_match_properties_full_size():
