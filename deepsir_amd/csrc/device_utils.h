@@ -23,6 +23,41 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// exp(x) for x <= 0 (softmax numerators, x = score - max) in ~6 instructions at ~2 ulp:
+// exp(x) = 2^(x*log2e); the product is split into its rounded value t and its exact
+// rounding error e (two fmas, log2e in hi+lo parts), then 2^(t+e) = exp2(t) * (1 + e ln2)
+// with the hardware v_exp_f32 (1 ulp).  Results below 2^-126 flush towards 0: such terms
+// are < 1e-38 of a softmax denominator that is >= 1.
+__device__ __forceinline__ float exp_neg(float x) {
+  const float kL2eHi = 1.44269502162933349609375f, kL2eLo = 1.925963033500011e-8f;
+  const float t = x * kL2eHi;
+  float e = fmaf(x, kL2eHi, -t);
+  e = fmaf(x, kL2eLo, e);
+  const float r = __builtin_amdgcn_exp2f(t);
+  return fmaf(r * e, 0.693147180559945309f, r);
+}
+
+// Attentive pooling of one 16x16 MFMA tile (reference RandLANet.py:152-155): column-wise softmax over
+// the tile's 16 rows (= the 16 neighbours of a point; C layout: col = lane & 15, row = 4*(lane>>4)+reg),
+// then sum_k f[k][c] * a[k][c].  `acc` = scores, `f` = the (normalised) features at the same positions.
+// Returns the pooled value of column (lane & 15), valid in lanes 0..15.
+// sum_k f_k e_k / sum_k e_k : one division per column instead of one per element.
+__device__ __forceinline__ float att_pool_tile(const f32x4& acc, const float (&f)[4]) {
+  float mx = fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3]));
+  mx = fmaxf(mx, __shfl_xor(mx, 16));
+  mx = fmaxf(mx, __shfl_xor(mx, 32));
+  float se = 0.f, o = 0.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float e = exp_neg(acc[r] - mx);
+    se += e;
+    o = fmaf(f[r], e, o);
+  }
+  se += __shfl_xor(se, 16); se += __shfl_xor(se, 32);
+  o += __shfl_xor(o, 16); o += __shfl_xor(o, 32);
+  return o / se;
+}
+
 // Order-preserving float max through integer atomics (target initialised to -inf).
 __device__ __forceinline__ void atomic_max_float(float* addr, float v) {
   if (v >= 0.f) atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));

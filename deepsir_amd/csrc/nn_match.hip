@@ -45,16 +45,25 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ x
 template <int RT>
 __global__ __launch_bounds__(256) void nn_match_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                        const float* __restrict__ sa, const float* __restrict__ sb,
-                                                       int J, int K, int cols_per_split,
+                                                       int J, int K, int cols_per_split, int rb_count, int splits,
                                                        unsigned long long* __restrict__ packed) {
   __shared__ float Bs[2][BC * LDB];   // double-buffered ref tile
   __shared__ float sbs[2][BC];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int fr = lane & 15, fq = lane >> 4;
-  const int pair = blockIdx.z;
+  // XCD-aware work mapping (speed only): workgroups are dealt round-robin over the 8 XCDs, each with
+  // its own L2.  The bijective remap below hands every XCD a CONTIGUOUS range of work items, ordered
+  // (pair, ref split, row block) with the row block fastest, so the workgroups that stream the same
+  // ref descriptors share one L2 instead of re-fetching them through eight.
+  const int nwg = gridDim.x, id = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = id & 7;
+  const int wi = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3);
+  const int rb = wi % rb_count;
+  const int split = (wi / rb_count) % splits;
+  const int pair = wi / (rb_count * splits);
   const float* Ap = A + (int64_t)pair * J * 64;
   const float* Bp = B + (int64_t)pair * K * 64;
-  const int row0 = (blockIdx.x * 4 + w) * (16 * RT);
+  const int row0 = (rb * 4 + w) * (16 * RT);
 
   // A fragments: lane holds A[row = fr][k = 4 s + fq]
   float af[RT][16];
@@ -77,7 +86,7 @@ __global__ __launch_bounds__(256) void nn_match_kernel(const float* __restrict__
 #pragma unroll
     for (int r = 0; r < 4; ++r) { best[rt][r] = INFINITY; bidx[rt][r] = 0x7fffffff; }
 
-  const int c_begin = blockIdx.y * cols_per_split;
+  const int c_begin = split * cols_per_split;
   const int c_end = min(K, c_begin + cols_per_split);
   // Pipeline: the next 64-column ref tile is fetched into registers while the MFMAs of the current
   // tile run, then written to the other LDS buffer; one barrier per tile.
@@ -208,11 +217,11 @@ void launch_nn_match_ws(const float* a, const float* b, int pairs, int J, int K,
   }
   int cols = ((tiles + splits - 1) / splits) * BC;
   splits = (K + cols - 1) / cols;
-  dim3 grid(rb_count, splits, pairs);
+  dim3 grid((unsigned)((int64_t)rb_count * splits * pairs));
   if (ev0) hipEventRecord(ev0, st);
-  if (rt == 4)      hipLaunchKernelGGL((nn_match_kernel<4>), grid, dim3(256), 0, st, a, b, sa, sb, J, K, cols, packed);
-  else if (rt == 2) hipLaunchKernelGGL((nn_match_kernel<2>), grid, dim3(256), 0, st, a, b, sa, sb, J, K, cols, packed);
-  else              hipLaunchKernelGGL((nn_match_kernel<1>), grid, dim3(256), 0, st, a, b, sa, sb, J, K, cols, packed);
+  if (rt == 4)      hipLaunchKernelGGL((nn_match_kernel<4>), grid, dim3(256), 0, st, a, b, sa, sb, J, K, cols, rb_count, splits, packed);
+  else if (rt == 2) hipLaunchKernelGGL((nn_match_kernel<2>), grid, dim3(256), 0, st, a, b, sa, sb, J, K, cols, rb_count, splits, packed);
+  else              hipLaunchKernelGGL((nn_match_kernel<1>), grid, dim3(256), 0, st, a, b, sa, sb, J, K, cols, rb_count, splits, packed);
   if (ev1) hipEventRecord(ev1, st);
   hipLaunchKernelGGL(unpack_idx_kernel, dim3(256), dim3(256), 0, st, packed, ra, idx);
 }

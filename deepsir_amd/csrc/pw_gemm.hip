@@ -276,20 +276,10 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const GemmArgs p) {
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const int col = n0 + 16 * t + fr;
-        float mx = fmaxf(fmaxf(acc[t][0], acc[t][1]), fmaxf(acc[t][2], acc[t][3]));
-        mx = fmaxf(mx, __shfl_xor(mx, 16));
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        float e[4], se = 0.f;
+        float f[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { e[r] = expf(acc[t][r] - mx); se += e[r]; }
-        se += __shfl_xor(se, 16); se += __shfl_xor(se, 32);
-        float o = 0.f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float f = seg_elem(p, er[r], col, s_sc, s_sh);
-          o += f * (e[r] / se);
-        }
-        o += __shfl_xor(o, 16); o += __shfl_xor(o, 32);
+        for (int r = 0; r < 4; ++r) f[r] = seg_elem(p, er[r], col, s_sc, s_sh);
+        const float o = att_pool_tile(acc[t], f);
         if (lane < 16 && col < p.Cout) Y[(int64_t)point * p.ldy + col] = o;
       }
     }

@@ -259,24 +259,16 @@ __global__ __launch_bounds__(256) void pw_tile_kernel(const GemmArgs p) {
         const int lc = cs1 ? col - C0 : col;
         const int act = cs1 ? act1 : act0;
         const float scv = s_sc[col < p.Cin ? col : 0], shv = s_sh[col < p.Cin ? col : 0];
-        float mx = fmaxf(fmaxf(acc[rt][t][0], acc[rt][t][1]), fmaxf(acc[rt][t][2], acc[rt][t][3]));
-        mx = fmaxf(mx, __shfl_xor(mx, 16));
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        float e[4], se = 0.f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { e[r] = expf(acc[rt][t][r] - mx); se += e[r]; }
-        se += __shfl_xor(se, 16); se += __shfl_xor(se, 32);
-        float o = 0.f;
+        float f[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float f = 0.f;
+          f[r] = 0.f;
           if (col < p.Cin) {
             const float v = fmaf(base[(cs1 ? er[r].o1 : er[r].o0) + lc], scv, shv);
-            f = (act && v < 0.f) ? 0.2f * v : v;
+            f[r] = (act && v < 0.f) ? 0.2f * v : v;
           }
-          o += f * (e[r] / se);
         }
-        o += __shfl_xor(o, 16); o += __shfl_xor(o, 32);
+        const float o = att_pool_tile(acc[rt][t], f);
         if (lane < 16 && col < p.Cout) Y[(int64_t)(trow >> 4) * p.ldy + col] = o;
       }
     }
