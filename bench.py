@@ -76,6 +76,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pairs", type=int, default=int(os.environ.get("DSIR_BENCH_PAIRS", "64")), help="pairs per step per GPU")
     ap.add_argument("--points", type=int, default=5000)
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("DSIR_BENCH_STREAMS", "2")),
+                    help="engine streams per GPU; the batch is split across them and registered concurrently")
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
@@ -95,14 +97,16 @@ def main():
 
     from deepsir_amd.arch import NetConfig
     from deepsir_amd.dist import gather_results
-    from deepsir_amd.engine import Engine
+    from deepsir_amd.engine import Engine, EnginePool
     from deepsir_amd.synth import make_batch
     from deepsir_amd.weights import generate_state_dict
 
     cfg = NetConfig(feat_len=3)
     sd = generate_state_dict(cfg, 0)
     P, N, n_iter = a.pairs, a.points, a.iters
-    eng = Engine(cfg, local_rank, max_points=N, max_pairs=P)
+    S = max(1, a.streams)
+    eng = EnginePool(cfg, local_rank, max_points=N, max_pairs=P, streams=S) if S > 1 else Engine(cfg, local_rank, max_points=N, max_pairs=P)
+    P_launch = (P + S - 1) // S   # pairs per nn_match launch
     eng.load_state_dict(sd)
     # every rank registers different pairs (weak scaling): seeds partitioned by rank
     batch = make_batch(N, [10_000 + rank * P + i for i in range(P)], cfg.feat_len)
@@ -136,6 +140,25 @@ def main():
     match_ms, match_n = eng.match_timer(reset=True)
     eng.enable_match_timer(False)
 
+    # the same nn_match launch with nothing else on the GPU (the timed region above overlaps it with the other
+    # stream's RandLA kernels, which lengthens it): reported as roofline.achieved_isolated
+    isolated = None
+    if rank == 0:
+        e0 = eng.engines[0] if hasattr(eng, "engines") else eng
+        g = torch.Generator(device="cpu").manual_seed(1)
+        da = torch.nn.functional.normalize(torch.randn(P_launch, N, 64, generator=g), dim=2).to(dev)
+        db = torch.nn.functional.normalize(torch.randn(P_launch, N, 64, generator=g), dim=2).to(dev)
+        e0.nn_match(da, db)
+        e0.enable_match_timer(True)
+        e0.match_timer(reset=True)
+        for _ in range(5):
+            e0.nn_match(da, db, sync=False)
+        ims, icnt = e0.match_timer(reset=True)
+        e0.enable_match_timer(False)
+        if icnt:
+            isolated = match_flops(P_launch, N, N) / (ims / 1e3 / icnt) / 1e12
+        del da, db
+
     # batch-1 latency (the reference's own evaluation mode, test.py:56 BATCH_SIZE = 1): one pair in flight,
     # launch sequence replayed from a hipGraph.  Reported beside the throughput number, not as `value`.
     latency = None
@@ -163,14 +186,14 @@ def main():
     if rank == 0:
         total_pairs = world * P * a.steps
         avg_match_s = (match_ms / 1e3) / max(match_n, 1)
-        achieved = match_flops(P, N, N) / avg_match_s / 1e12 if match_n else None
+        achieved = match_flops(P_launch, N, N) / avg_match_s / 1e12 if match_n else None
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "nn_match_pmc.json")
         if os.path.exists(pmc):
             try:
                 with open(pmc) as f:
                     j = json.load(f)
-                if j.get("pairs") == P and j.get("points") == N:
+                if j.get("pairs") == P_launch and j.get("points") == N:
                     traffic = j.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -186,7 +209,9 @@ def main():
                          "achieved": None if achieved is None else round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": None if achieved is None else round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                          "launches": int(match_n), "avg_launch_ms": round(avg_match_s * 1e3, 5),
-                         "flops_per_launch": match_flops(P, N, N)},
+                         "flops_per_launch": match_flops(P_launch, N, N), "pairs_per_launch": P_launch, "concurrent_streams": S,
+                         "achieved_isolated": None if isolated is None else round(isolated, 3),
+                         "frac_isolated": None if isolated is None else round(isolated / PEAK_F32_MFMA_TFLOPS, 4)},
         }
         if latency is not None:
             line["batch1_latency"] = latency

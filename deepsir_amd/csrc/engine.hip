@@ -346,6 +346,23 @@ struct Sched {
     Act y;
     y.p = c->ws.get<float>((size_t)clouds * n * w.d);
     y.C = w.d; y.rows = n;
+    static const bool no_att2 = getenv("DSIR_NO_ATT2") != nullptr;   // A/B switch
+    if (!no_att2 && w.d >= 64 && f.C * 2 == w.d && enc.C * 2 == w.d) {   // d = 16: the extra gathers cost more than the MFMAs saved
+      // score GEMM split by linearity: fc [gather(f); enc] = gather(W1 f) + W2 enc  (kernels.h, EPI_ATT2).
+      // G = W1 f runs on n rows instead of 16 n; the pooling launch contracts only the enc half.
+      float* G = c->ws.get<float>((size_t)clouds * n * w.d);
+      GemmArgs g;
+      g.amode = A_SEGS; g.nseg = 1; g.seg[0] = seg_of(f);
+      g.W = w.fc; g.ldw = w.d; g.bias = nullptr; g.Cin = w.d / 2; g.Cout = w.d; g.M = n; g.clouds = clouds;
+      g.epi = EPI_LINEAR; g.Y = G; g.y_cloud_stride = (int64_t)n * w.d; g.ldy = w.d;
+      launch_pw_gemm(g, st);
+      GemmArgs a2;
+      a2.amode = A_SEGS; a2.nseg = 1; a2.seg[0] = seg_of(enc);
+      a2.W = w.fc + w.d / 2; a2.ldw = w.d; a2.bias = nullptr; a2.Cin = w.d / 2; a2.Cout = w.d; a2.M = n * kKnn;
+      a2.clouds = clouds; a2.epi = EPI_ATT2; a2.Y = y.p; a2.y_cloud_stride = (int64_t)n * w.d; a2.ldy = w.d;
+      a2.g = G; a2.g_cloud_stride = (int64_t)n * w.d; a2.fseg = seg_of(f, neigh, neigh_cs);
+      if (launch_pw_stream(a2, st) || launch_pw_tile(a2, st)) return y;
+    }
     GemmArgs a;
     a.amode = A_SEGS; a.nseg = 2;
     a.seg[0] = seg_of(f, neigh, neigh_cs);

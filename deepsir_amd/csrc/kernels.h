@@ -31,7 +31,11 @@ struct Seg {
 };
 
 enum AMode { A_SEGS = 0, A_LSE = 1 };
-enum Epilogue { EPI_GN = 0, EPI_ACT = 1, EPI_LINEAR = 2, EPI_L2NORM = 3, EPI_ATT = 4 };
+// EPI_ATT2 = attentive pooling with the score GEMM split by linearity:
+//   fc [gather(f); enc] = gather(W1 f) + W2 enc.   G = W1 f is a per-POINT GEMM (16x fewer rows) done
+//   beforehand; this launch contracts only the enc half (A = enc, W = fc[:, d/2:], ldw = d), adds the
+//   gathered G rows to the scores, and pools [gather(f); enc] exactly as EPI_ATT does.
+enum Epilogue { EPI_GN = 0, EPI_ACT = 1, EPI_LINEAR = 2, EPI_L2NORM = 3, EPI_ATT = 4, EPI_ATT2 = 5 };
 
 struct GemmArgs {
   int amode = A_SEGS;
@@ -43,9 +47,14 @@ struct GemmArgs {
   const int32_t* neigh = nullptr;  // [clouds][n][16]
   int64_t neigh_cloud_stride = 0;
 
-  const float* W = nullptr;     // [Cout][Cin] row-major
+  const float* W = nullptr;     // [Cout][ldw] row-major, Cin columns used
+  int ldw = 0;                  // weight row stride in floats (0 => Cin)
   const float* bias = nullptr;  // [Cout] or nullptr
   int Cin = 0, Cout = 0;
+  // EPI_ATT2 only: G = W1 f  [clouds][n][Cout] and the gathered-feature half of the pooled operand
+  const float* g = nullptr;
+  int64_t g_cloud_stride = 0;
+  Seg fseg = {};                // f [clouds][n][Cout/2] with its lazy GroupNorm; fseg.idx = neighbour index of every A row
   int M = 0;                    // rows per cloud
   int clouds = 1;
   int epi = EPI_GN;

@@ -215,6 +215,8 @@ void launch_nn_match_ws(const float* a, const float* b, int pairs, int J, int K,
     eff *= (double)tiles / (double)(tiles_per * nsp);        // padding of the last split
     if (eff > best_eff + 1e-9) { best_eff = eff; splits = sp; }
   }
+  static const int force_splits = getenv("DSIR_MATCH_SPLITS") ? atoi(getenv("DSIR_MATCH_SPLITS")) : 0;   // tuning hook
+  if (force_splits > 0) splits = force_splits < tiles ? force_splits : tiles;
   int cols = ((tiles + splits - 1) / splits) * BC;
   splits = (K + cols - 1) / cols;
   dim3 grid((unsigned)((int64_t)rb_count * splits * pairs));

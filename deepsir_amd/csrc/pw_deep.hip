@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void pw_deep_kernel(const GemmArgs p, int ctb 
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int col = n0 + 16 * t + fr;
-    Wl[t] = (col < p.Cout) ? p.W + (int64_t)col * p.Cin + KQ * fq : nullptr;
+    Wl[t] = (col < p.Cout) ? p.W + (int64_t)col * (p.ldw ? p.ldw : p.Cin) + KQ * fq : nullptr;
   }
 
   float a_cur[RT][KQ], a_nxt[RT][KQ], w_cur[NT][KQ], w_nxt[NT][KQ];

@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const GemmArgs p) {
     for (int i = 0; i < NT; ++i) {
       const int col = n0 + r0 + 16 * i;
       const int k = k0 + kk;
-      rw[i] = (col < p.Cout && k < p.Cin) ? p.W[(int64_t)col * p.Cin + k] : 0.f;
+      rw[i] = (col < p.Cout && k < p.Cin) ? p.W[(int64_t)col * (p.ldw ? p.ldw : p.Cin) + k] : 0.f;
     }
   };
 

@@ -58,12 +58,35 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const GemmArgs p) {
   __shared__ float s_sc[CP];
   __shared__ float s_sh[CP];
   __shared__ float s_red[EPI == EPI_GN ? 4 * BN * 2 : 1];
-  __shared__ float s_att[EPI == EPI_ATT ? 4 * 16 * (CP + 4) : 1];
+  __shared__ float s_att[(EPI == EPI_ATT || EPI == EPI_ATT2) ? 4 * 16 * (CP + 4) : 1];
+  __shared__ float s_fsc[EPI == EPI_ATT2 ? 64 : 1];   // EPI_ATT2: GroupNorm scale/shift of the gathered-feature half
+  __shared__ float s_fsh[EPI == EPI_ATT2 ? 64 : 1];
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int fr = lane & 15, fq = lane >> 4;
   const int cloud = blockIdx.z;
   const int n0 = blockIdx.y * BN;
+  const int ldw = p.ldw ? p.ldw : p.Cin;
+
+  if (EPI == EPI_ATT2) {
+    const Seg& s = p.fseg;
+    for (int c = tid; c < s.C; c += 256) {
+      float scale = 1.f, shift = 0.f;
+      if (s.gn.stats) {
+        const int g = c / (s.C / s.gn.groups);
+        const double* st = s.gn.stats + ((int64_t)cloud * s.gn.groups + g) * 2;
+        const double mean = st[0] * s.gn.inv_count;
+        double var = st[1] * s.gn.inv_count - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        const double rstd = 1.0 / sqrt(var + 1e-5);
+        const double scd = (double)s.gn.gamma[c] * rstd;
+        scale = (float)scd;
+        shift = (float)((double)s.gn.beta[c] - mean * scd);
+      }
+      s_fsc[c] = scale;
+      s_fsh[c] = shift;
+    }
+  }
 
   if (MODE != S_LSE) {
     for (int c = tid; c < CP; c += 256) {
@@ -100,7 +123,7 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const GemmArgs p) {
   for (int t = 0; t < NT; ++t) {
     const int col = n0 + 16 * t + fr;
     if ((KQ % 4) == 0 && p.Cin == 4 * KQ) {          // rows of W are 16-byte aligned: vector loads
-      if (col < p.Cout) vec_load<KQ>(p.W + (int64_t)col * p.Cin + c_lo, wf[t]);
+      if (col < p.Cout) vec_load<KQ>(p.W + (int64_t)col * ldw + c_lo, wf[t]);
       else {
 #pragma unroll
         for (int j = 0; j < KQ; ++j) wf[t][j] = 0.f;
@@ -109,7 +132,7 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const GemmArgs p) {
 #pragma unroll
       for (int j = 0; j < KQ; ++j) {
         const int k = c_lo + j;
-        wf[t][j] = (col < p.Cout && k < p.Cin) ? p.W[(int64_t)col * p.Cin + k] : 0.f;
+        wf[t][j] = (col < p.Cout && k < p.Cin) ? p.W[(int64_t)col * ldw + k] : 0.f;
       }
     }
     bv[t] = (p.bias && col < p.Cout) ? p.bias[col] : 0.f;
@@ -188,23 +211,58 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const GemmArgs p) {
 #pragma unroll
   for (int t = 0; t < NT; ++t) { g1[t] = 0.f; g2[t] = 0.f; }
 
-  // software pipeline: gather index two tiles ahead, A loads one tile ahead, normalise just before use
-  Chunk<KQ> cur;
-  int tile = wave0;
-  int srow_n = 0;
-  if (tile < ntiles) {
-    load_tile(tile, tile_srow(tile), cur);
-    finish_tile(tile, cur);
-    if (tile + nwaves < ntiles) srow_n = tile_srow(tile + nwaves);
-  }
-  for (; tile < ntiles; tile += nwaves) {
-    Chunk<KQ> nxt;
-    const int tn = tile + nwaves;
-    int srow_nn = 0;
-    if (tn < ntiles) {
-      load_tile(tn, srow_n, nxt);
-      if (tn + nwaves < ntiles) srow_nn = tile_srow(tn + nwaves);
+  // Memory-level parallelism: a narrow tile is only 16 rows x 8..64 bytes, far too little to cover the
+  // HBM/L2 latency with the few waves a CU holds.  Tiles are therefore processed in GROUPS of D: first the
+  // gather indices of all D tiles, then all their row loads (D independent vector loads in flight per
+  // lane), then the D MFMA + epilogue passes.  D shrinks as the per-tile register footprint grows.
+  constexpr bool kAtt = (EPI == EPI_ATT || EPI == EPI_ATT2);
+  constexpr int D = kAtt ? (NT == 1 ? 4 : 1) : (KQ * NT <= 4 ? 8 : (KQ * NT <= 16 ? 4 : (KQ * NT <= 32 ? 2 : 1)));
+  constexpr int GA = EPI == EPI_ATT2 ? D : 1, GN_ = EPI == EPI_ATT2 ? NT : 1;
+  for (int tile0 = wave0; tile0 < ntiles; tile0 += D * nwaves) {
+    int srow[D];
+    Chunk<KQ> buf[D];
+    float gpre_all[GA][GN_][4], fpre_all[GA][GN_][4];
+    int gi_all[GA][4];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const int tl = tile0 + d * nwaves;
+      srow[d] = tl < ntiles ? tile_srow(tl) : 0;
+      if (EPI == EPI_ATT2) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          gi_all[d][r] = tl < ntiles ? p.fseg.idx[cloud * p.fseg.idx_cloud_stride + tl * 16 + 4 * fq + r] : 0;
+      }
     }
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const int tl = tile0 + d * nwaves;
+      if (tl < ntiles) load_tile(tl, srow[d], buf[d]);
+      if (EPI == EPI_ATT2) {
+        // the gathered rows of G = W1 f (added to the scores) and of f (pooled operand) for this lane's
+        // 4 rows x NT columns
+        const int ch = p.fseg.C;   // = Cout / 2
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int col = n0 + 16 * t + fr;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int64_t go = cloud * p.g_cloud_stride + (int64_t)gi_all[d][r] * p.Cout;
+            const int64_t fo = cloud * p.fseg.cloud_stride + (int64_t)gi_all[d][r] * p.fseg.ld;
+            gpre_all[d][t][r] = (tl < ntiles && col < p.Cout) ? p.g[go + col] : 0.f;
+            fpre_all[d][t][r] = (tl < ntiles && col < ch) ? p.fseg.x[fo + col] : 0.f;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+    const int tile = tile0 + d * nwaves;
+    if (tile < ntiles) {
+    Chunk<KQ>& cur = buf[d];
+    finish_tile(tile, cur);
+    float (&gpre)[GN_][4] = gpre_all[EPI == EPI_ATT2 ? d : 0];
+    float (&fpre)[GN_][4] = fpre_all[EPI == EPI_ATT2 ? d : 0];
+    const int rbase = tile * 16 + 4 * fq;   // C layout: col = lane & 15, row = 4 * (lane >> 4) + reg
 
     f32x4 acc[NT];
 #pragma unroll
@@ -214,7 +272,6 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const GemmArgs p) {
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.v[s], wf[t][s], acc[t], 0, 0, 0);
 
-    const int rbase = tile * 16 + 4 * fq;   // C layout: col = lane & 15, row = 4 * (lane >> 4) + reg
     if (EPI == EPI_GN) {
       float* Y = p.Y + cloud * p.y_cloud_stride;
 #pragma unroll
@@ -294,11 +351,39 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const GemmArgs p) {
         if (lane < 16 && col < p.Cout) Y[(int64_t)tile * p.ldy + col] = o;
       }
       __builtin_amdgcn_wave_barrier();
+    } else if (EPI == EPI_ATT2) {
+      // split attentive pooling: scores = acc (enc half of the contraction) + gathered G rows;
+      // pooled operand = [gathered f (first Cout/2 columns) ; enc (last Cout/2, from the A fragments via LDS)]
+      float* Y = p.Y + cloud * p.y_cloud_stride;
+      float* T = &s_att[w * 16 * (CP + 4)];
+      const int ch = p.fseg.C;
+      const int fact = p.fseg.act;
+#pragma unroll
+      for (int j = 0; j < KQ; ++j) T[fr * (CP + 4) + c_lo + j] = cur.v[j];
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int col = n0 + 16 * t + fr;
+        float f[4];
+        f32x4 sc4 = acc[t];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          sc4[r] += gpre[t][r];
+          if (col < ch) {
+            const float v = fmaf(fpre[t][r], s_fsc[col], s_fsh[col]);
+            f[r] = (fact && v < 0.f) ? 0.2f * v : v;
+          } else {
+            f[r] = (col < p.Cout) ? T[(4 * fq + r) * (CP + 4) + (col - ch)] : 0.f;
+          }
+        }
+        const float o = att_pool_tile(sc4, f);
+        if (lane < 16 && col < p.Cout) Y[(int64_t)tile * p.ldy + col] = o;
+      }
+      __builtin_amdgcn_wave_barrier();
     }
-    if (tn < ntiles) finish_tile(tn, nxt);
-    cur = nxt;
-    srow_n = srow_nn;
-  }
+    }  // tile < ntiles
+    }  // d
+  }    // tile groups
 
   if (EPI == EPI_GN) {
 #pragma unroll
@@ -393,6 +478,13 @@ bool launch_pw_stream(const GemmArgs& a, hipStream_t st) {
     }
     if (a.epi == EPI_L2NORM) {
       if (KQ == 16 && a.Cout == 64) { launch_s<16, 4, EPI_L2NORM, S_VEC>(a, st); return true; }
+      return false;
+    }
+    if (a.epi == EPI_ATT2) {   // A = enc (Cin = d/2), Cout = d
+      if (a.nseg != 1 || a.Cout != 2 * a.Cin || !a.g || !a.fseg.idx) return false;
+      if (KQ == 2) { launch_s<2, 1, EPI_ATT2, S_VEC>(a, st); return true; }     // d = 16
+      if (KQ == 8) { launch_s<8, 4, EPI_ATT2, S_VEC>(a, st); return true; }     // d = 64
+      if (KQ == 16) { launch_s<16, 4, EPI_ATT2, S_VEC>(a, st); return true; }   // d = 128 (two column blocks)
       return false;
     }
     switch (KQ) {

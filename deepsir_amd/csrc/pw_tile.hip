@@ -52,12 +52,34 @@ __global__ __launch_bounds__(256) void pw_tile_kernel(const GemmArgs p) {
   __shared__ float Ws[2][BN * LDS_LD];
   __shared__ float s_sc[MAXC];
   __shared__ float s_sh[MAXC];
+  __shared__ float s_fsc[EPI == EPI_ATT2 ? 128 : 1];   // EPI_ATT2: GroupNorm scale/shift of the gathered-feature half
+  __shared__ float s_fsh[EPI == EPI_ATT2 ? 128 : 1];
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int fr = lane & 15, fq = lane >> 4;
   const int cloud = blockIdx.z;
   const int m0 = blockIdx.x * BM;
   const int n0 = blockIdx.y * BN;
+
+  if (EPI == EPI_ATT2) {
+    const Seg& s = p.fseg;
+    for (int c = tid; c < s.C; c += 256) {
+      float scale = 1.f, shift = 0.f;
+      if (s.gn.stats) {
+        const int g = c / (s.C / s.gn.groups);
+        const double* st = s.gn.stats + ((int64_t)cloud * s.gn.groups + g) * 2;
+        const double mean = st[0] * s.gn.inv_count;
+        double var = st[1] * s.gn.inv_count - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        const double rstd = 1.0 / sqrt(var + 1e-5);
+        const double scd = (double)s.gn.gamma[c] * rstd;
+        scale = (float)scd;
+        shift = (float)((double)s.gn.beta[c] - mean * scd);
+      }
+      s_fsc[c] = scale;
+      s_fsh[c] = shift;
+    }
+  }
 
   for (int c = tid; c < p.Cin; c += 256) {
     const Seg& s = (c < p.seg[0].C) ? p.seg[0] : p.seg[1];
@@ -88,7 +110,7 @@ __global__ __launch_bounds__(256) void pw_tile_kernel(const GemmArgs p) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int col = n0 + sr0 + 32 * i;
-    wrow[i] = col < p.Cout ? p.W + (int64_t)col * p.Cin + c4 : nullptr;
+    wrow[i] = col < p.Cout ? p.W + (int64_t)col * (p.ldw ? p.ldw : p.Cin) + c4 : nullptr;
   }
   const int C0 = p.seg[0].C;
   const int act0 = p.seg[0].act, act1 = p.nseg > 1 ? p.seg[1].act : 0;
@@ -272,6 +294,48 @@ __global__ __launch_bounds__(256) void pw_tile_kernel(const GemmArgs p) {
         if (lane < 16 && col < p.Cout) Y[(int64_t)(trow >> 4) * p.ldy + col] = o;
       }
     }
+  } else if (EPI == EPI_ATT2) {
+    // split attentive pooling (kernels.h): scores = acc (enc half) + gathered G rows; pooled operand =
+    // [gathered f (columns < Cout/2) ; enc (columns >= Cout/2)], both re-read from L2 with their GroupNorm applied
+    float* Y = p.Y + cloud * p.y_cloud_stride;
+    const int ch = p.fseg.C;
+    const int fact = p.fseg.act;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      const int trow = r0 + 16 * rt;
+      if (trow >= p.M) continue;
+      int64_t go[4], fo[4], eo[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = trow + 4 * fq + r;
+        const int gi = p.fseg.idx[cloud * p.fseg.idx_cloud_stride + row];
+        go[r] = cloud * p.g_cloud_stride + (int64_t)gi * p.Cout;
+        fo[r] = cloud * p.fseg.cloud_stride + (int64_t)gi * p.fseg.ld;
+        eo[r] = row_off(p, cloud, row).o0;
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int col = n0 + 16 * t + fr;
+        f32x4 sc4 = acc[rt][t];
+        float f[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          f[r] = 0.f;
+          if (col < p.Cout) {
+            sc4[r] += p.g[go[r] + col];
+            if (col < ch) {
+              const float v = fmaf(p.fseg.x[fo[r] + col], s_fsc[col], s_fsh[col]);
+              f[r] = (fact && v < 0.f) ? 0.2f * v : v;
+            } else {
+              const float v = fmaf(p.seg[0].x[eo[r] + (col - ch)], s_sc[col - ch], s_sh[col - ch]);
+              f[r] = (act0 && v < 0.f) ? 0.2f * v : v;
+            }
+          }
+        }
+        const float o = att_pool_tile(sc4, f);
+        if (lane < 16 && col < p.Cout) Y[(int64_t)(trow >> 4) * p.ldy + col] = o;
+      }
+    }
   }
 }
 
@@ -288,6 +352,10 @@ bool launch_e(const GemmArgs& a, hipStream_t st) {
     case EPI_ACT: launch_t<RT, EPI_ACT>(a, st); return true;
     case EPI_LINEAR: launch_t<RT, EPI_LINEAR>(a, st); return true;
     case EPI_ATT: launch_t<RT, EPI_ATT>(a, st); return true;
+    case EPI_ATT2:
+      if (a.nseg != 1 || a.Cout != 2 * a.Cin || a.Cin > 128 || !a.g || !a.fseg.idx) return false;
+      launch_t<RT, EPI_ATT2>(a, st);
+      return true;
     default: return false;
   }
 }

@@ -315,6 +315,29 @@ def test_graph_replay_is_bitwise_identical():
     eng.close()
 
 
+def test_engine_pool_matches_single_engine():
+    """Two engines on two HIP streams registering halves of a batch concurrently == one engine, bitwise."""
+    from deepsir_amd.arch import NetConfig
+    from deepsir_amd.engine import Engine, EnginePool
+    from deepsir_amd.synth import make_batch
+    from deepsir_amd.weights import generate_state_dict
+    cfg = NetConfig(feat_len=3)
+    sd = generate_state_dict(cfg, 0)
+    b = make_batch(2048, [41, 42, 43], 3)
+    src, ref = cu(b["points_src"]), cu(b["points_ref"])
+    one = Engine(cfg, 0, max_points=2048, max_pairs=3)
+    one.load_state_dict(sd)
+    pool = EnginePool(cfg, 0, max_points=2048, max_pairs=3, streams=2)
+    pool.load_state_dict(sd)
+    a = one.register(src, ref, 5)
+    p = pool.register(src, ref, 5)
+    for k in ("transforms", "idx", "logits", "pt_ref_new", "invalid"):
+        assert torch.equal(a[k], p[k]), k
+    q = pool.register(src, ref, 5, want_aux=False)
+    assert torch.equal(q["transforms"], a["transforms"])
+    one.close(); pool.close()
+
+
 def test_nn_match_properties_full_size():
     """5000 x 5000 and ragged 4999 x 5003: exact agreement with a float64 arg-min
     wherever the fp64 top-2 gap exceeds fp32 resolution; self-match is the identity."""
