@@ -314,11 +314,13 @@ struct Sched {
     return s;
   }
   // MLP2D: conv1x1 + GroupNorm (lazy) [+ LeakyReLU (lazy)]
-  Act mlp2d(const Mlp2dW& w, const Seg& s0, const Seg* s1, int M, bool act) {
+  // out_buf / st_buf: caller-owned storage (persistent across launches) instead of the per-pass arenas
+  Act mlp2d(const Mlp2dW& w, const Seg& s0, const Seg* s1, int M, bool act, float* out_buf = nullptr,
+            double* st_buf = nullptr) {
     Act y;
-    y.p = c->ws.get<float>((size_t)clouds * M * w.cout);
+    y.p = out_buf ? out_buf : c->ws.get<float>((size_t)clouds * M * w.cout);
     y.C = w.cout; y.rows = M; y.act = act ? 1 : 0;
-    double* st_out = stats_slot(w.groups);
+    double* st_out = st_buf ? st_buf : stats_slot(w.groups);
     y.gn = GnRef{st_out, w.gamma, w.beta, w.groups, 1.0 / ((double)(w.cout / w.groups) * (double)M)};
     GemmArgs a;
     a.amode = A_SEGS; a.nseg = s1 ? 2 : 1; a.seg[0] = s0; if (s1) a.seg[1] = *s1;
@@ -327,12 +329,13 @@ struct Sched {
     launch_pw_gemm(a, st);
     return y;
   }
-  Act mlp2d_lse(const Mlp2dW& w, const float* xyz, int64_t xyz_cs, const int32_t* neigh, int64_t neigh_cs, int n) {
+  Act mlp2d_lse(const Mlp2dW& w, const float* xyz, int64_t xyz_cs, const int32_t* neigh, int64_t neigh_cs, int n,
+                float* out_buf = nullptr, double* st_buf = nullptr) {
     const int M = n * kKnn;
     Act y;
-    y.p = c->ws.get<float>((size_t)clouds * M * w.cout);
+    y.p = out_buf ? out_buf : c->ws.get<float>((size_t)clouds * M * w.cout);
     y.C = w.cout; y.rows = M; y.act = 1;
-    double* st_out = stats_slot(w.groups);
+    double* st_out = st_buf ? st_buf : stats_slot(w.groups);
     y.gn = GnRef{st_out, w.gamma, w.beta, w.groups, 1.0 / ((double)(w.cout / w.groups) * (double)M)};
     GemmArgs a;
     a.amode = A_LSE; a.xyz = xyz; a.xyz_cloud_stride = xyz_cs; a.neigh = neigh; a.neigh_cloud_stride = neigh_cs;
@@ -395,8 +398,21 @@ Seg plain_seg(const float* x, int64_t cloud_stride, int C, int ld, const int32_t
 }
 
 // RandLA.forward (RandLANet.py:311-372).  in0/in1: the (possibly concatenated / gathered) input features.
+// The position-encoding branch of every level (lfa.mlp1 on the relative position code, lfa.mlp2 on top of it)
+// depends only on the pyramid and the weights.  The inlier model runs on the SAME (src) pyramid in every
+// registration iteration (model.py:575), so that branch is computed in iteration 0 into caller-owned
+// storage and re-used afterwards: same kernels, same inputs, same bits (SURVEY §7.2 loop invariants).
+struct EncCache {
+  bool valid = false;
+  float* enc_buf[DSIR_MAX_LEVELS] = {};
+  float* enc2_buf[DSIR_MAX_LEVELS] = {};
+  double* enc_stats[DSIR_MAX_LEVELS] = {};
+  double* enc2_stats[DSIR_MAX_LEVELS] = {};
+  Act enc[DSIR_MAX_LEVELS], enc2[DSIR_MAX_LEVELS];
+};
+
 int randla_forward(dsir_ctx* c, const RandlaW& w, const Seg& in0, const Seg* in1, const Pyramid& py, float* feat_out,
-                   float* logits_out) {
+                   float* logits_out, EncCache* cache = nullptr) {
   const dsir_cfg& g = c->cfg;
   const int L = g.num_layers;
   hipStream_t st = c->stream;
@@ -417,10 +433,16 @@ int randla_forward(dsir_ctx* c, const RandlaW& w, const Seg& in0, const Seg* in1
     const int32_t* nb_l = py.neigh + (int64_t)py.off[l] * kKnn;
     const Seg xin = Sched::seg_of(x);
     Act f = s.mlp2d(b.mlp1, xin, nullptr, n, true);
-    Act enc = s.mlp2d_lse(b.lfa1, xyz_l, xyz_cs, nb_l, neigh_cs, n);
+    const bool reuse = cache && cache->valid;
+    Act enc = reuse ? cache->enc[l]
+                    : s.mlp2d_lse(b.lfa1, xyz_l, xyz_cs, nb_l, neigh_cs, n, cache ? cache->enc_buf[l] : nullptr,
+                                  cache ? cache->enc_stats[l] : nullptr);
     Act agg = s.att(b.att1, f, enc, nb_l, neigh_cs, n);
     Act a1 = s.mlp2d(b.att1.mlp, Sched::seg_of(agg), nullptr, n, true);
-    Act enc2 = s.mlp2d(b.lfa2, Sched::seg_of(enc), nullptr, n * kKnn, true);
+    Act enc2 = reuse ? cache->enc2[l]
+                     : s.mlp2d(b.lfa2, Sched::seg_of(enc), nullptr, n * kKnn, true, cache ? cache->enc2_buf[l] : nullptr,
+                               cache ? cache->enc2_stats[l] : nullptr);
+    if (cache && !reuse) { cache->enc[l] = enc; cache->enc2[l] = enc2; }
     Act agg2 = s.att(b.att2, a1, enc2, nb_l, neigh_cs, n);
     Act a2 = s.mlp2d(b.att2.mlp, Sched::seg_of(agg2), nullptr, n, true);
     Act mainb = s.mlp2d(b.mlp2, Sched::seg_of(a2), nullptr, n, false);
@@ -455,6 +477,7 @@ int randla_forward(dsir_ctx* c, const RandlaW& w, const Seg& in0, const Seg* in1
     s.linear(w.fc[2], Sched::seg_of(h), nullptr, n0, EPI_LINEAR, logits_out);
   }
   if (c->ws.overflow) return fail(c, "workspace exhausted in randla_forward (raise max_points / max_pairs)");
+  if (cache) cache->valid = true;
   return 0;
 }
 
@@ -821,6 +844,25 @@ static int register_enqueue(dsir_ctx* c, const dsir_pair_batch* in, int n_iter, 
   int32_t* idx_it = ws.get<int32_t>((size_t)P * J);
   float* T_it = ws.get<float>((size_t)P * 12);
   void* match_scratch = ws.raw(nn_match_scratch_bytes(P, J, K));
+  // persistent storage of the inlier model's position-encoding branch (EncCache), alive across the iterations
+  EncCache enc_cache;
+  static const bool no_hoist = getenv("DSIR_NO_HOIST") != nullptr;   // A/B switch
+  const bool hoist = !no_hoist && n_iter > 1;
+  if (hoist) {
+    size_t nstats = 0;
+    for (int l = 0; l < g.num_layers; ++l) {
+      const size_t rows = (size_t)P * ps.nl[l] * kKnn, ch = (size_t)g.d_out[l] / 2;
+      enc_cache.enc_buf[l] = ws.get<float>(rows * ch);
+      enc_cache.enc2_buf[l] = ws.get<float>(rows * ch);
+      nstats += 2 * (size_t)P * 16;
+    }
+    double* cst = ws.get<double>(nstats);
+    if (!ws.overflow) HIP_OK(c, hipMemsetAsync(cst, 0, nstats * sizeof(double), st));
+    for (int l = 0; l < g.num_layers; ++l) {
+      enc_cache.enc_stats[l] = cst + (size_t)(2 * l) * P * 16;
+      enc_cache.enc2_stats[l] = cst + (size_t)(2 * l + 1) * P * 16;
+    }
+  }
   if (ws.overflow) return fail(c, "workspace exhausted (raise max_points / max_pairs)");
   const size_t mark1 = ws.mark();
   {
@@ -860,7 +902,7 @@ static int register_enqueue(dsir_ctx* c, const dsir_pair_batch* in, int n_iter, 
     // inlier RandLA on [xyz_src(t); xyz_ref[idx]] with the SRC pyramid (model.py:574-577)
     const Seg s0 = plain_seg(xyz_cur, (int64_t)J * 3, 3, 3);
     const Seg s1 = plain_seg(rxyz, (int64_t)pr.S * 3, 3, 3, idx_out, J);
-    if (int r = randla_forward(c, c->net.inl, s0, &s1, ps, nullptr, logit_out)) return r;
+    if (int r = randla_forward(c, c->net.inl, s0, &s1, ps, nullptr, logit_out, hoist ? &enc_cache : nullptr)) return r;
     ws.release(mark1);
     // weighted Kabsch + transform update (model.py:586-595)
     KabschArgs a{};
