@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void nn_match_kernel(const float* __restrict__
                                                        unsigned long long* __restrict__ packed) {
   __shared__ float Bs[2][BC * LDB];   // double-buffered ref tile
   __shared__ float sbs[2][BC];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform
   const int fr = lane & 15, fq = lane >> 4;
   // XCD-aware work mapping (speed only): workgroups are dealt round-robin over the 8 XCDs, each with
   // its own L2.  The bijective remap below hands every XCD a CONTIGUOUS range of work items, ordered

@@ -62,7 +62,10 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const GemmArgs p) {
   __shared__ float s_fsc[EPI == EPI_ATT2 ? 64 : 1];   // EPI_ATT2: GroupNorm scale/shift of the gathered-feature half
   __shared__ float s_fsh[EPI == EPI_ATT2 ? 64 : 1];
 
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  // the wave index is uniform across the wave, but only readfirstlane lets the compiler KNOW it: tile indices
+  // derived from it then live in SGPRs and the per-tile bounds checks become scalar branches instead of
+  // exec-mask save/restore sequences
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fq = lane >> 4;
   const int cloud = blockIdx.z;
   const int n0 = blockIdx.y * BN;
@@ -148,31 +151,26 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const GemmArgs p) {
   const int wave0 = blockIdx.x * 4 + w, nwaves = gridDim.x * 4;
 
   // source row of this lane's A row in tile `tile` (gathered segments: one index load, issued a tile ahead)
+  // Rows past M (last, partial tile) are CLAMPED to row M-1 rather than predicated: their MFMA results are
+  // never stored nor counted, and unconditional loads keep the exec mask (and the branch count) out of the loop.
   auto tile_srow = [&](int tile) -> int {
-    const int row = tile * 16 + fr;
-    if (MODE != S_VEC || row >= p.M) return 0;
-    return src_row(myseg, cloud, row);
+    if (MODE != S_VEC) return 0;
+    return src_row(myseg, cloud, min(tile * 16 + fr, p.M - 1));
   };
   auto finish_tile = [&](int tile, Chunk<KQ>& ch) {
     if (MODE != S_VEC) return;
-    const bool ok = tile * 16 + fr < p.M;
 #pragma unroll
     for (int j = 0; j < KQ; ++j) {
       const float v = fmaf(ch.v[j], sc[j], sh[j]);
-      ch.v[j] = ok ? ((my_act && v < 0.f) ? 0.2f * v : v) : 0.f;
+      ch.v[j] = (my_act && v < 0.f) ? 0.2f * v : v;
     }
   };
   auto load_tile = [&](int tile, int srow, Chunk<KQ>& ch) {
     const int row = tile * 16 + fr;
     const bool ok = row < p.M;
     if (MODE == S_VEC) {
-      if (ok) {
-        const float* src = myseg.x + cloud * myseg.cloud_stride + (int64_t)srow * myseg.ld + seg_c;
-        vec_load<KQ>(src, ch.v);          // raw values; normalised by finish_tile() after the MFMA burst
-      } else {
-#pragma unroll
-        for (int j = 0; j < KQ; ++j) ch.v[j] = 0.f;
-      }
+      const float* src = myseg.x + cloud * myseg.cloud_stride + (int64_t)srow * myseg.ld + seg_c;
+      vec_load<KQ>(src, ch.v);          // raw values; normalised by finish_tile() after the MFMA burst
     } else if (MODE == S_ELEM) {
 #pragma unroll
       for (int j = 0; j < KQ; ++j) {
@@ -248,8 +246,10 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const GemmArgs p) {
           for (int r = 0; r < 4; ++r) {
             const int64_t go = cloud * p.g_cloud_stride + (int64_t)gi_all[d][r] * p.Cout;
             const int64_t fo = cloud * p.fseg.cloud_stride + (int64_t)gi_all[d][r] * p.fseg.ld;
-            gpre_all[d][t][r] = (tl < ntiles && col < p.Cout) ? p.g[go + col] : 0.f;
-            fpre_all[d][t][r] = (tl < ntiles && col < ch) ? p.fseg.x[fo + col] : 0.f;
+            // EPI_ATT2 launches have Cout == 2 Cin == 8 KQ, a multiple of the 16-column tiles: every column is
+            // valid, and "column in the gathered half" is uniform per (block, t) — scalar conditions only
+            gpre_all[d][t][r] = (tl < ntiles) ? p.g[go + col] : 0.f;
+            fpre_all[d][t][r] = (tl < ntiles && n0 + 16 * t < ch) ? p.fseg.x[fo + col] : 0.f;
           }
         }
       }
@@ -369,11 +369,11 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const GemmArgs p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           sc4[r] += gpre[t][r];
-          if (col < ch) {
+          if (n0 + 16 * t < ch) {   // uniform per (block, t): ch is a multiple of 16 here
             const float v = fmaf(fpre[t][r], s_fsc[col], s_fsh[col]);
             f[r] = (fact && v < 0.f) ? 0.2f * v : v;
           } else {
-            f[r] = (col < p.Cout) ? T[(4 * fq + r) * (CP + 4) + (col - ch)] : 0.f;
+            f[r] = T[(4 * fq + r) * (CP + 4) + (col - ch)];
           }
         }
         const float o = att_pool_tile(sc4, f);
@@ -482,7 +482,6 @@ bool launch_pw_stream(const GemmArgs& a, hipStream_t st) {
     }
     if (a.epi == EPI_ATT2) {   // A = enc (Cin = d/2), Cout = d
       if (a.nseg != 1 || a.Cout != 2 * a.Cin || !a.g || !a.fseg.idx) return false;
-      if (KQ == 2) { launch_s<2, 1, EPI_ATT2, S_VEC>(a, st); return true; }     // d = 16
       if (KQ == 8) { launch_s<8, 4, EPI_ATT2, S_VEC>(a, st); return true; }     // d = 64
       if (KQ == 16) { launch_s<16, 4, EPI_ATT2, S_VEC>(a, st); return true; }   // d = 128 (two column blocks)
       return false;

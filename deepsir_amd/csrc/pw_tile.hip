@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void pw_tile_kernel(const GemmArgs p) {
   __shared__ float s_fsc[EPI == EPI_ATT2 ? 128 : 1];   // EPI_ATT2: GroupNorm scale/shift of the gathered-feature half
   __shared__ float s_fsh[EPI == EPI_ATT2 ? 128 : 1];
 
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform
   const int fr = lane & 15, fq = lane >> 4;
   const int cloud = blockIdx.z;
   const int m0 = blockIdx.x * BM;
@@ -105,12 +105,14 @@ __global__ __launch_bounds__(256) void pw_tile_kernel(const GemmArgs p) {
   const int sr0 = tid >> 3;
   RowOff ro[AV];
 #pragma unroll
-  for (int i = 0; i < AV; ++i) ro[i] = row_off(p, cloud, m0 + sr0 + 32 * i);
+  // rows past M / columns past Cout are CLAMPED, not predicated: their products are never stored nor counted,
+  // and unconditional loads keep exec-mask juggling out of the K loop
+  for (int i = 0; i < AV; ++i) ro[i] = row_off(p, cloud, min(m0 + sr0 + 32 * i, p.M - 1));
   const float* wrow[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int col = n0 + sr0 + 32 * i;
-    wrow[i] = col < p.Cout ? p.W + (int64_t)col * (p.ldw ? p.ldw : p.Cin) + c4 : nullptr;
+    const int col = min(n0 + sr0 + 32 * i, p.Cout - 1);
+    wrow[i] = p.W + (int64_t)col * (p.ldw ? p.ldw : p.Cin) + c4;
   }
   const int C0 = p.seg[0].C;
   const int act0 = p.seg[0].act, act1 = p.nseg > 1 ? p.seg[1].act : 0;
@@ -125,14 +127,10 @@ __global__ __launch_bounds__(256) void pw_tile_kernel(const GemmArgs p) {
 #pragma unroll
     for (int i = 0; i < AV; ++i) {
       const int64_t o = s1 ? ro[i].o1 : ro[i].o0;
-      ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (o >= 0) ra[i] = *reinterpret_cast<const float4*>(base + o + lc);
+      ra[i] = *reinterpret_cast<const float4*>(base + o + lc);
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      rw[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (wrow[i]) rw[i] = *reinterpret_cast<const float4*>(wrow[i] + k0);
-    }
+    for (int i = 0; i < 2; ++i) rw[i] = *reinterpret_cast<const float4*>(wrow[i] + k0);
   };
   auto lstore = [&](int k0, int buf) {
     const int c = k0 + c4;
@@ -142,12 +140,10 @@ __global__ __launch_bounds__(256) void pw_tile_kernel(const GemmArgs p) {
 #pragma unroll
     for (int i = 0; i < AV; ++i) {
       float4 v = ra[i];
-      if (ro[i].o0 >= 0) {
-        v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y); v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
-        if (act) {
-          v.x = v.x < 0.f ? 0.2f * v.x : v.x; v.y = v.y < 0.f ? 0.2f * v.y : v.y;
-          v.z = v.z < 0.f ? 0.2f * v.z : v.z; v.w = v.w < 0.f ? 0.2f * v.w : v.w;
-        }
+      v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y); v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+      if (act) {
+        v.x = v.x < 0.f ? 0.2f * v.x : v.x; v.y = v.y < 0.f ? 0.2f * v.y : v.y;
+        v.z = v.z < 0.f ? 0.2f * v.z : v.z; v.w = v.w < 0.f ? 0.2f * v.w : v.w;
       }
       float2* d = reinterpret_cast<float2*>(&As[buf][(sr0 + 32 * i) * LDS_LD + c4]);
       d[0] = make_float2(v.x, v.y);
@@ -320,16 +316,15 @@ __global__ __launch_bounds__(256) void pw_tile_kernel(const GemmArgs p) {
         float f[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          f[r] = 0.f;
-          if (col < p.Cout) {
-            sc4[r] += p.g[go[r] + col];
-            if (col < ch) {
-              const float v = fmaf(p.fseg.x[fo[r] + col], s_fsc[col], s_fsh[col]);
-              f[r] = (fact && v < 0.f) ? 0.2f * v : v;
-            } else {
-              const float v = fmaf(p.seg[0].x[eo[r] + (col - ch)], s_sc[col - ch], s_sh[col - ch]);
-              f[r] = (act0 && v < 0.f) ? 0.2f * v : v;
-            }
+          // EPI_ATT2: Cout == 2 Cin is a multiple of 64, so every column is valid and "gathered half or enc
+          // half" is uniform per (block, t): scalar branches only
+          sc4[r] += p.g[go[r] + col];
+          if (n0 + 16 * t < ch) {
+            const float v = fmaf(p.fseg.x[fo[r] + col], s_fsc[col], s_fsh[col]);
+            f[r] = (fact && v < 0.f) ? 0.2f * v : v;
+          } else {
+            const float v = fmaf(p.seg[0].x[eo[r] + (col - ch)], s_sc[col - ch], s_sh[col - ch]);
+            f[r] = (act0 && v < 0.f) ? 0.2f * v : v;
           }
         }
         const float o = att_pool_tile(sc4, f);
