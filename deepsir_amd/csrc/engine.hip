@@ -449,13 +449,20 @@ int randla_forward(dsir_ctx* c, const RandlaW& w, const Seg& in0, const Seg* in1
     Act skipb = s.mlp2d(b.skip, xin, nullptr, n, false);
     Act enc_out;
     enc_out.C = 2 * b.d; enc_out.rows = n;
-    enc_out.p = c->ws.get<float>((size_t)py.clouds * n * enc_out.C);
-    launch_residual_combine(mainb.p, mainb.gn, skipb.p, skipb.gn, enc_out.C, n, py.clouds, enc_out.p, st);
     Act samp;
     samp.C = enc_out.C; samp.rows = py.nl[l + 1];
     samp.p = c->ws.get<float>((size_t)py.clouds * samp.rows * samp.C);
-    launch_gather_max(enc_out.p, (int64_t)n * enc_out.C, py.sub + (int64_t)py.soff[l] * kKnn, sub_cs, samp.C, samp.rows,
-                      py.clouds, samp.p, st);
+    if (l == 0) {
+      // the level-0 block output is also the decoder's last skip connection: materialise it
+      enc_out.p = c->ws.get<float>((size_t)py.clouds * n * enc_out.C);
+      launch_residual_combine(mainb.p, mainb.gn, skipb.p, skipb.gn, enc_out.C, n, py.clouds, enc_out.p, st);
+      launch_gather_max(enc_out.p, (int64_t)n * enc_out.C, py.sub + (int64_t)py.soff[l] * kKnn, sub_cs, samp.C, samp.rows,
+                        py.clouds, samp.p, st);
+    } else {
+      // deeper levels: only the pooled ("randomly sampled") rows are ever read — combine inside the pooling kernel
+      launch_gather_max_combine(mainb.p, mainb.gn, skipb.p, skipb.gn, n, py.sub + (int64_t)py.soff[l] * kKnn, sub_cs,
+                                samp.C, samp.rows, py.clouds, samp.p, st);
+    }
     if (l == 0) skips.push_back(enc_out);
     skips.push_back(samp);
     x = samp;

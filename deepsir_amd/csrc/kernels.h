@@ -83,6 +83,10 @@ void launch_residual_combine(const float* a, GnRef ga, const float* b, GnRef gb,
 void launch_gather_max(const float* in, int64_t in_cloud_stride, const int32_t* idx, int64_t idx_cloud_stride, int C,
                        int rows_out, int clouds, float* out, hipStream_t st);
 
+// both fused: out[i][c] = max_k LeakyReLU(GN_a(a)[idx[i][k]][c] + GN_b(b)[idx[i][k]][c]); a, b: [clouds][rows_in][C]
+void launch_gather_max_combine(const float* a, GnRef ga, const float* b, GnRef gb, int rows_in, const int32_t* idx,
+                               int64_t idx_cloud_stride, int C, int rows_out, int clouds, float* out, hipStream_t st);
+
 void launch_narrow_i64(const int64_t* src, int32_t* dst, int64_t n, hipStream_t st);
 
 // KNN (data_base.py:153-183): one level.  support = first n_support points of `pts`.

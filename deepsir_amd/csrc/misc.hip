@@ -54,6 +54,36 @@ __global__ __launch_bounds__(256) void gather_max_kernel(const float* __restrict
   }
 }
 
+// Same pooling with the residual combine fused in: the block output LeakyReLU(GN(a) + GN(b)) is evaluated on
+// the fly for the 16 pooled neighbours and never materialised (levels >= 1, where nothing else reads it).
+__global__ __launch_bounds__(256) void gather_max_combine_kernel(const float* __restrict__ a, GnRef ga,
+                                                                 const float* __restrict__ b, GnRef gb, int rows_in,
+                                                                 const int32_t* __restrict__ idx, int64_t idx_cs, int C,
+                                                                 int rows_out, float* __restrict__ out) {
+  __shared__ float sa[512], ha[512], sb[512], hb[512];
+  const int cloud = blockIdx.y;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    gn_scale_shift(ga, cloud, c, C, sa[c], ha[c]);
+    gn_scale_shift(gb, cloud, c, C, sb[c], hb[c]);
+  }
+  __syncthreads();
+  const int64_t in_base = (int64_t)cloud * rows_in * C;
+  const int64_t total = (int64_t)rows_out * C;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int i = (int)(e / C), c = (int)(e % C);
+    const int32_t* nb = idx + cloud * idx_cs + (int64_t)i * kKnn;
+    const float s1 = sa[c], h1 = ha[c], s2 = sb[c], h2 = hb[c];
+    float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < kKnn; ++k) {
+      const int64_t o = in_base + (int64_t)nb[k] * C + c;
+      const float v = fmaf(a[o], s1, h1) + fmaf(b[o], s2, h2);
+      m = fmaxf(m, v < 0.f ? 0.2f * v : v);
+    }
+    out[(int64_t)cloud * total + e] = m;
+  }
+}
+
 __global__ void narrow_i64_kernel(const int64_t* __restrict__ src, int32_t* __restrict__ dst, int64_t n) {
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
     dst[e] = (int32_t)src[e];
@@ -91,6 +121,13 @@ void launch_gather_max(const float* in, int64_t in_cs, const int32_t* idx, int64
   if (rows_out <= 0) return;
   dim3 grid(grid_for((int64_t)rows_out * C), clouds);
   hipLaunchKernelGGL(gather_max_kernel, grid, dim3(256), 0, st, in, in_cs, idx, idx_cs, C, rows_out, out);
+}
+
+void launch_gather_max_combine(const float* a, GnRef ga, const float* b, GnRef gb, int rows_in, const int32_t* idx,
+                               int64_t idx_cs, int C, int rows_out, int clouds, float* out, hipStream_t st) {
+  if (rows_out <= 0) return;
+  dim3 grid(grid_for((int64_t)rows_out * C), clouds);
+  hipLaunchKernelGGL(gather_max_combine_kernel, grid, dim3(256), 0, st, a, ga, b, gb, rows_in, idx, idx_cs, C, rows_out, out);
 }
 
 void launch_narrow_i64(const int64_t* src, int32_t* dst, int64_t n, hipStream_t st) {
