@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdsir.so")
+# DSIR_LIB selects another build of the SAME library (kernel-variant A/B runs); never a different backend.
+LIB_PATH = os.environ.get("DSIR_LIB", os.path.join(_HERE, "libdsir.so"))
 
 c_float_p = C.POINTER(C.c_float)
 c_i32_p = C.POINTER(C.c_int32)

@@ -20,6 +20,7 @@
 // 6-channel inlier input), and the relative position encoding (RandLANet.py:197-212).
 #include "kernels.h"
 #include "device_utils.h"
+#include <cstdlib>
 
 namespace dsir {
 
@@ -216,11 +217,20 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const GemmArgs p) {
   constexpr bool kAtt = (EPI == EPI_ATT || EPI == EPI_ATT2);
   constexpr int D = kAtt ? (NT == 1 ? 4 : 1) : (KQ * NT <= 4 ? 8 : (KQ * NT <= 16 ? 4 : (KQ * NT <= 32 ? 2 : 1)));
   constexpr int GA = EPI == EPI_ATT2 ? D : 1, GN_ = EPI == EPI_ATT2 ? NT : 1;
-  for (int tile0 = wave0; tile0 < ntiles; tile0 += D * nwaves) {
+  // Two groups are alive at a time (ping-pong): the loads of group g+1 are issued before group g is computed,
+  // so index -> row -> use latencies overlap with MFMA / epilogue work even at one wave per SIMD.
+  struct Group {
     int srow[D];
     Chunk<KQ> buf[D];
     float gpre_all[GA][GN_][4], fpre_all[GA][GN_][4];
     int gi_all[GA][4];
+  };
+  auto issue_group = [&](Group& G, int tile0) {
+    int (&srow)[D] = G.srow;
+    Chunk<KQ> (&buf)[D] = G.buf;
+    float (&gpre_all)[GA][GN_][4] = G.gpre_all;
+    float (&fpre_all)[GA][GN_][4] = G.fpre_all;
+    int (&gi_all)[GA][4] = G.gi_all;
 #pragma unroll
     for (int d = 0; d < D; ++d) {
       const int tl = tile0 + d * nwaves;
@@ -254,14 +264,16 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const GemmArgs p) {
         }
       }
     }
+  };
+  auto compute_group = [&](Group& G, int tile0) {
 #pragma unroll
     for (int d = 0; d < D; ++d) {
     const int tile = tile0 + d * nwaves;
     if (tile < ntiles) {
-    Chunk<KQ>& cur = buf[d];
+    Chunk<KQ>& cur = G.buf[d];
     finish_tile(tile, cur);
-    float (&gpre)[GN_][4] = gpre_all[EPI == EPI_ATT2 ? d : 0];
-    float (&fpre)[GN_][4] = fpre_all[EPI == EPI_ATT2 ? d : 0];
+    float (&gpre)[GN_][4] = G.gpre_all[EPI == EPI_ATT2 ? d : 0];
+    float (&fpre)[GN_][4] = G.fpre_all[EPI == EPI_ATT2 ? d : 0];
     const int rbase = tile * 16 + 4 * fq;   // C layout: col = lane & 15, row = 4 * (lane >> 4) + reg
 
     f32x4 acc[NT];
@@ -383,7 +395,23 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const GemmArgs p) {
     }
     }  // tile < ntiles
     }  // d
-  }    // tile groups
+  };
+  {
+    const int gstride = D * nwaves;
+    Group ga, gb;
+    int t0 = wave0;
+    if (t0 < ntiles) issue_group(ga, t0);
+    while (t0 < ntiles) {
+      const int t1 = t0 + gstride;
+      if (t1 < ntiles) issue_group(gb, t1);
+      compute_group(ga, t0);
+      if (t1 >= ntiles) break;
+      const int t2 = t1 + gstride;
+      if (t2 < ntiles) issue_group(ga, t2);
+      compute_group(gb, t1);
+      t0 = t2;
+    }
+  }
 
   if (EPI == EPI_GN) {
 #pragma unroll
@@ -424,8 +452,12 @@ void launch_s(const GemmArgs& a, hipStream_t st) {
   // tile->wave assignment, hence the summation order of the GroupNorm statistics, is the same for a
   // cloud whether it is registered alone or inside a batch (bitwise batch invariance).
   int blocks = (ntiles + 31) / 32;
-  if (blocks * gy < 64) {
-    const int want = (64 + gy - 1) / gy, most = (ntiles + 3) / 4;
+  // small layers: at least `floor_blocks` workgroups per cloud so that a single pair still spreads over the
+  // chip; DSIR_STREAM_MIN_BLOCKS trades batch-1 latency (more, shorter waves) against throughput at large
+  // batches (fewer waves, per-wave setup amortised over more tiles)
+  static const int floor_blocks = getenv("DSIR_STREAM_MIN_BLOCKS") ? atoi(getenv("DSIR_STREAM_MIN_BLOCKS")) : 16;
+  if (blocks * gy < floor_blocks) {
+    const int want = (floor_blocks + gy - 1) / gy, most = (ntiles + 3) / 4;
     blocks = want < most ? want : most;
   }
   if (blocks < 1) blocks = 1;
