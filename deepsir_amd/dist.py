@@ -34,6 +34,9 @@ def gather_results(local: torch.Tensor, dist=None, sizes: Optional[Sequence[int]
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return local if sizes is None else local[: sizes[0]]
     world = dist.get_world_size()
+    on_gpu = local.is_cuda
+    if on_gpu and dist.get_backend() == "gloo":     # CPU rehearsal backend: stage through host memory
+        return gather_results(local.cpu(), dist, sizes).to(local.device)
     if sizes is None:
         out = [torch.empty_like(local) for _ in range(world)]
         dist.all_gather(out, local.contiguous())

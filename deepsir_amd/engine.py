@@ -296,7 +296,8 @@ class EnginePool:
         per = (P + self.streams - 1) // self.streams
         return [(a, min(P, a + per)) for a in range(0, P, per)]
 
-    def register(self, points_src, points_ref, n_iter: int = 5, want_aux: bool = True, sync: bool = True, out: Optional[dict] = None):
+    def register(self, points_src, points_ref, n_iter: int = 5, want_aux: bool = True, sync: bool = True,
+                 out: Optional[dict] = None, pyramids: Optional[dict] = None):
         P = points_src.shape[0]
         sl = self._slices(P)
         if out is None:
@@ -304,7 +305,9 @@ class EnginePool:
         parts = []
         for e, (a, b) in zip(self.engines, sl):
             o = {"transforms": out["transforms"][a:b]} if not want_aux else None
-            parts.append(e.register(points_src[a:b], points_ref[a:b], n_iter, want_aux=want_aux, sync=False, out=o))
+            pyr = None if pyramids is None else {k: v[a:b] for k, v in pyramids.items()}
+            parts.append(e.register(points_src[a:b], points_ref[a:b], n_iter, want_aux=want_aux, sync=False, out=o,
+                                    pyramids=pyr))
         if sync or want_aux:
             self.sync()
         if want_aux:
