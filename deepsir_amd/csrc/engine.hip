@@ -964,6 +964,18 @@ int dsir_enable_graph(dsir_ctx* c, int enable) {
   return 0;
 }
 
+int dsir_eval_metrics(dsir_ctx* c, const float* pred_T, int64_t pred_stride, const float* gt_T, const float* points_src,
+                      const float* points_ref, int pairs, int n, int stride, float rte_thresh, float rre_thresh,
+                      double* out) {
+  if (!c) return 1;
+  if (!pred_T || !gt_T || !points_src || !points_ref || !out || pairs < 1 || n < 1 || stride < 3 || pred_stride < 12)
+    return fail(c, "dsir_eval_metrics: bad arguments");
+  HIP_OK(c, hipSetDevice(c->device));
+  launch_eval_metrics(pred_T, pred_stride, gt_T, points_src, points_ref, pairs, n, stride, rte_thresh, rre_thresh, out,
+                      c->stream);
+  return post(c);
+}
+
 int dsir_enable_match_timer(dsir_ctx* c, int enable) {
   if (!c) return 1;
   c->time_match = enable != 0;

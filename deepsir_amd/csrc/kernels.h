@@ -139,4 +139,8 @@ struct KabschArgs {
 };
 void launch_kabsch(const KabschArgs& a, hipStream_t st);
 
+// evaluation metrics (metrics_util.py:27-85); out [pairs][8] float64
+void launch_eval_metrics(const float* pred, int64_t pred_stride, const float* gt, const float* src, const float* ref,
+                         int pairs, int n, int stride, float rte_thresh, float rre_thresh, double* out, hipStream_t st);
+
 }  // namespace dsir

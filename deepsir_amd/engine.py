@@ -253,6 +253,25 @@ class Engine:
         out["_keep"] = keep
         return out
 
+    # ------------------------------------------------------------------ after the path: metrics
+    METRIC_NAMES = ("r_mse", "r_mae", "t_mse", "t_mae", "err_r_deg", "err_t", "succ", "chamfer_dist")
+
+    def eval_metrics(self, pred, gt, points_src, points_ref, rte_thresh: float, rre_thresh: float):
+        """compute_metrics counterpart (reference common/metrics_util.py:27-85).
+        pred [P,3,4] (may be a strided view such as transforms[:, i]), gt [P,3,4], points_* [P,N,>=3]
+        -> dict of float64 tensors [P] keyed by METRIC_NAMES."""
+        points_src, points_ref = _chk(points_src, torch.float32, "points_src"), _chk(points_ref, torch.float32, "points_ref")
+        gt = _chk(gt, torch.float32, "transform_gt")
+        if not pred.is_cuda or pred.dtype != torch.float32 or pred.stride(-1) != 1 or pred.stride(-2) != 4:
+            pred = pred.float().contiguous().to(self.device)
+        P, n, stride = points_src.shape
+        out = self._empty((P, 8), torch.float64)
+        self._pre()
+        self._call(self.lib.dsir_eval_metrics(self.h, _ptr(pred), pred.stride(0) if P > 1 else 12, _ptr(gt), _ptr(points_src),
+                                              _ptr(points_ref), P, n, stride, float(rte_thresh), float(rre_thresh), _ptr(out)))
+        self.sync()
+        return {k: out[:, i] for i, k in enumerate(self.METRIC_NAMES)}
+
     # ------------------------------------------------------------------ measurement hooks
     def enable_graph(self, on=True):
         """Replay dsir_register through a captured hipGraph (same buffers on every call)."""

@@ -73,3 +73,47 @@ def summarize(stats: np.ndarray) -> Dict[str, float]:
         "time_mean": float(stats[:, 3].mean()) if len(stats) else 0.0,
         "pairs_per_sec": float(1.0 / stats[:, 3].mean()) if len(stats) and stats[:, 3].mean() > 0 else 0.0,
     }
+
+
+@torch.no_grad()
+def evaluate_align(pred_transforms: np.ndarray, pairs: Sequence[Dict[str, np.ndarray]], engine, dataset_type: str = "3DMatch",
+                   batch: int = 64, device: Optional[torch.device] = None):
+    """Counterpart of the reference's ``test.py::evaluate_align`` (test.py:308-355): per registration
+    iteration, the metrics of ``compute_metrics`` (common/metrics_util.py:27-85) on the first 1024 points of
+    each cloud (test.py:331-332), computed on device by ``dsir_eval_metrics``.
+
+    pred_transforms [n_pairs, n_iter(+1), 3, 4]; pairs as for ``inference_align``; ``engine`` a
+    ``deepsir_amd.engine.Engine``.  Returns (metrics_for_iter: list of dicts of arrays, summary of the last iteration)."""
+    device = device or torch.device("cuda", torch.cuda.current_device())
+    rte_t, rre_t = THRESHOLDS[dataset_type]
+    pred = torch.from_numpy(np.ascontiguousarray(pred_transforms, dtype=np.float32)).to(device)
+    if pred.dim() == 3:
+        pred = pred[:, None]
+    n_it = pred.shape[1]
+    acc = [dict((k, []) for k in engine.METRIC_NAMES) for _ in range(n_it)]
+    for b0 in range(0, len(pairs), batch):
+        ids = range(b0, min(len(pairs), b0 + batch))
+        src = torch.from_numpy(np.concatenate([pairs[i]["points_src"][:, :1024] for i in ids], 0)).to(device)
+        ref = torch.from_numpy(np.concatenate([pairs[i]["points_ref"][:, :1024] for i in ids], 0)).to(device)
+        gt = torch.from_numpy(np.concatenate([pairs[i]["transform_gt"] for i in ids], 0)).float().to(device)
+        for it in range(n_it):
+            m = engine.eval_metrics(pred[b0:b0 + len(ids), it], gt, src, ref, rte_t, rre_t)
+            for k, v in m.items():
+                acc[it][k].append(v.cpu().numpy())
+    metrics_for_iter = [{k: np.concatenate(v) for k, v in a.items()} for a in acc]
+    return metrics_for_iter, summarize_metrics(metrics_for_iter[-1])
+
+
+def summarize_metrics(metrics: Dict[str, np.ndarray]) -> Dict[str, float]:
+    """Mean over instances with the reference's naming (common/metrics_util.py:88-101):
+    ``*mse`` -> ``*rmse``; ``err_*`` -> ``_mean`` and ``_rmse``; everything else -> mean."""
+    out = {}
+    for k, v in metrics.items():
+        if k.endswith("mse"):
+            out[k[:-3] + "rmse"] = float(np.sqrt(np.mean(v)))
+        elif k.startswith("err"):
+            out[k + "_mean"] = float(np.mean(v))
+            out[k + "_rmse"] = float(np.sqrt(np.mean(v ** 2)))
+        else:
+            out[k] = float(np.mean(v))
+    return out

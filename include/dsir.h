@@ -156,6 +156,17 @@ typedef struct dsir_pair_result {
  * inlier RandLA, weighted Kabsch, SE(3) update}. */
 int dsir_register(dsir_ctx* ctx, const dsir_pair_batch* in, int n_iter, const dsir_pair_result* out);
 
+/* ---- after the path: evaluation metrics ------------- */
+
+/* Replaces common/metrics_util.py:27-85 compute_metrics as called per iteration by test.py:308-355
+ * evaluate_align.  pred_T: [pairs] transforms of 12 floats each, `pred_stride` floats apart (so one
+ * iteration of a [P][n_iter][3][4] result can be addressed in place); gt_T [pairs][3][4];
+ * points_src / points_ref [pairs][n][stride] (xyz first; the first min(n,2048) points are used).
+ * out [pairs][8] float64: r_mse, r_mae, t_mse, t_mae, err_r_deg, err_t, succ (0/1), chamfer_dist. */
+int dsir_eval_metrics(dsir_ctx* ctx, const float* pred_T, int64_t pred_stride, const float* gt_T,
+                      const float* points_src, const float* points_ref, int pairs, int n, int stride,
+                      float rte_thresh, float rre_thresh, double* out);
+
 /* Launch-bound small batches: capture the whole dsir_register launch sequence into a hipGraph once per
  * call signature (sizes and buffer addresses) and replay it.  Off by default. */
 int dsir_enable_graph(dsir_ctx* ctx, int enable);

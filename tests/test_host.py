@@ -80,3 +80,11 @@ def test_metrics_and_se3():
     back = se3.transform(inv, se3.transform(a, pts))
     np.testing.assert_allclose(back.numpy(), pts.numpy(), atol=1e-5)
     assert se3.identity(2).shape == (2, 3, 4)
+
+
+def test_summarize_metrics_naming():
+    from deepsir_amd.harness import summarize_metrics
+    m = {"r_mse": np.array([1.0, 9.0]), "t_mae": np.array([0.5, 1.5]), "err_t": np.array([3.0, 4.0]), "succ": np.array([1.0, 0.0])}
+    s = summarize_metrics(m)
+    assert s["r_rmse"] == pytest.approx(np.sqrt(5.0)) and s["t_mae"] == 1.0
+    assert s["err_t_mean"] == 3.5 and s["err_t_rmse"] == pytest.approx(np.sqrt(12.5)) and s["succ"] == 0.5
