@@ -76,6 +76,10 @@ SYMBOLS = {
     "dsir_match_timer": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), c_i64_p]),
     "dsir_enable_match_timer": (C.c_int, [C.c_void_p, C.c_int]),
     "dsir_enable_graph": (C.c_int, [C.c_void_p, C.c_int]),
+    "dsir_voxel_downsample": (C.c_int, [C.c_void_p, C.c_void_p, c_i64_p, C.c_int, C.c_int, C.c_float, c_float_p, C.c_int,
+                                        C.c_void_p, C.c_void_p]),
+    "dsir_resample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64,
+                                C.c_void_p]),
     "dsir_eval_metrics": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                     C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]),
 }

@@ -964,6 +964,40 @@ int dsir_enable_graph(dsir_ctx* c, int enable) {
   return 0;
 }
 
+int dsir_voxel_downsample(dsir_ctx* c, const float* points, const int64_t* offsets, int clouds, int stride, float voxel_size,
+                          const float* crop, int cap, float* out, int32_t* counts) {
+  if (!c) return 1;
+  if (!points || !offsets || !out || !counts || clouds < 1 || clouds > 1000 || stride < 3 || stride > 16 || cap < 1 ||
+      !(voxel_size > 0.f))
+    return fail(c, "dsir_voxel_downsample: bad arguments");
+  HIP_OK(c, hipSetDevice(c->device));
+  const int64_t total = offsets[clouds];
+  if (total <= 0 || total > 0x7fffffffll) return fail(c, "dsir_voxel_downsample: %lld points unsupported", (long long)total);
+  c->ws.top = 0; c->ws.overflow = false;
+  void* scratch = c->ws.raw(voxel_downsample_scratch_bytes(total, clouds));
+  if (c->ws.overflow) return fail(c, "workspace too small for %lld raw points (raise max_points / max_pairs)", (long long)total);
+  // the host offsets are consumed by an async copy: make the call self-contained
+  HIP_OK(c, hipStreamSynchronize(c->stream));
+  if (int r = launch_voxel_downsample(points, offsets, clouds, stride, voxel_size, crop, cap, out, counts, scratch, c->stream))
+    return fail(c, "dsir_voxel_downsample: launch failed (%d)", r);
+  HIP_OK(c, hipStreamSynchronize(c->stream));
+  return post(c);
+}
+
+int dsir_resample(dsir_ctx* c, const float* in, const int32_t* counts, int clouds, int cap, int stride, int k, int mode,
+                  uint64_t seed, float* out) {
+  if (!c) return 1;
+  if (!in || !counts || !out || clouds < 1 || cap < 1 || stride < 1 || k < 1 || (mode != 0 && mode != 1))
+    return fail(c, "dsir_resample: bad arguments");
+  HIP_OK(c, hipSetDevice(c->device));
+  c->ws.top = 0; c->ws.overflow = false;
+  void* scratch = c->ws.raw(resample_scratch_bytes(clouds, cap));
+  if (c->ws.overflow) return fail(c, "workspace too small for dsir_resample");
+  if (int r = launch_resample(in, counts, clouds, cap, stride, k, mode, seed, out, scratch, c->stream))
+    return fail(c, "dsir_resample: launch failed (%d)", r);
+  return post(c);
+}
+
 int dsir_eval_metrics(dsir_ctx* c, const float* pred_T, int64_t pred_stride, const float* gt_T, const float* points_src,
                       const float* points_ref, int pairs, int n, int stride, float rte_thresh, float rre_thresh,
                       double* out) {

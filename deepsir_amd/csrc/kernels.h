@@ -139,6 +139,14 @@ struct KabschArgs {
 };
 void launch_kabsch(const KabschArgs& a, hipStream_t st);
 
+// pre-processing on ragged batches (preprocess.hip); return 0 on success
+size_t voxel_downsample_scratch_bytes(int64_t total, int clouds);
+int launch_voxel_downsample(const float* pts, const int64_t* offsets_host, int clouds, int stride, float voxel,
+                            const float* crop_host, int cap, float* out, int32_t* counts, void* scratch, hipStream_t st);
+size_t resample_scratch_bytes(int clouds, int cap);
+int launch_resample(const float* in, const int32_t* counts, int clouds, int cap, int stride, int k, int mode, uint64_t seed,
+                    float* out, void* scratch, hipStream_t st);
+
 // evaluation metrics (metrics_util.py:27-85); out [pairs][8] float64
 void launch_eval_metrics(const float* pred, int64_t pred_stride, const float* gt, const float* src, const float* ref,
                          int pairs, int n, int stride, float rte_thresh, float rre_thresh, double* out, hipStream_t st);

@@ -253,6 +253,41 @@ class Engine:
         out["_keep"] = keep
         return out
 
+    # ------------------------------------------------------------------ in front of the path: pre-processing
+    def voxel_downsample(self, clouds: Sequence[torch.Tensor], voxel_size: float, crop: Optional[Sequence[float]] = None,
+                         cap: Optional[int] = None):
+        """open3d voxel_down_sample (+ process_point_cloud crop) counterpart for a ragged list of [n_i, C] CUDA
+        clouds -> (voxels [clouds, cap, C], counts [clouds] i32).  See include/dsir.h for the ordering rule."""
+        pts = torch.cat([_chk(c, torch.float32, "cloud") for c in clouds], 0)
+        n = [int(c.shape[0]) for c in clouds]
+        stride = pts.shape[1]
+        offs = (C.c_int64 * (len(n) + 1))(*np.concatenate([[0], np.cumsum(n)]).tolist())
+        cap = int(cap or max(n))
+        out = self._empty((len(n), cap, stride))
+        counts = self._empty((len(n),), torch.int32)
+        crop_arr = None if crop is None else (C.c_float * 4)(*[float(x) for x in crop])
+        self._pre()
+        self._call(self.lib.dsir_voxel_downsample(self.h, _ptr(pts), offs, len(n), stride, float(voxel_size), crop_arr, cap,
+                                                  _ptr(out), _ptr(counts)))
+        return out, counts
+
+    def resample(self, voxels: torch.Tensor, counts: torch.Tensor, k: int, seed: int = 0, mode: str = "random"):
+        """Resampler / FixedResampler counterpart: [clouds, cap, C] + counts -> [clouds, k, C]."""
+        voxels, counts = _chk(voxels, torch.float32, "voxels"), _chk(counts, torch.int32, "counts")
+        c, cap, stride = voxels.shape
+        out = self._empty((c, k, stride))
+        self._pre()
+        self._call(self.lib.dsir_resample(self.h, _ptr(voxels), _ptr(counts), c, cap, stride, int(k),
+                                          {"random": 0, "fixed": 1}[mode], int(seed) & ((1 << 64) - 1), _ptr(out)))
+        self.sync()
+        return out
+
+    def preprocess(self, clouds: Sequence[torch.Tensor], voxel_size: float, k: int, seed: int = 0,
+                   crop: Optional[Sequence[float]] = None, mode: str = "random"):
+        """Raw clouds -> [clouds, k, C] network input (crop, voxel average, resample in random order)."""
+        vox, counts = self.voxel_downsample(clouds, voxel_size, crop)
+        return self.resample(vox, counts, k, seed, mode), counts
+
     # ------------------------------------------------------------------ after the path: metrics
     METRIC_NAMES = ("r_mse", "r_mae", "t_mse", "t_mae", "err_r_deg", "err_t", "succ", "chamfer_dist")
 

@@ -156,6 +156,25 @@ typedef struct dsir_pair_result {
  * inlier RandLA, weighted Kabsch, SE(3) update}. */
 int dsir_register(dsir_ctx* ctx, const dsir_pair_batch* in, int n_iter, const dsir_pair_result* out);
 
+/* ---- in front of the path: pre-processing ----------- */
+
+/* Replaces the range/height crop of process_point_cloud (dataloader/data_base.py:299-312) and open3d's
+ * voxel_down_sample as called at dataloader/threeDMatch_loader.py:168-175 / kitti_loader.py:335-338, for a
+ * RAGGED batch: points [total][stride] (xyz first, every channel is voxel-averaged), offsets = HOST array
+ * [clouds+1] of row offsets, crop = HOST [r_min, r_max, z_min, z_max] or NULL.
+ * out [clouds][cap][stride] (voxels in ascending (ix,iy,iz) order; rows beyond cap are dropped),
+ * counts [clouds] i32 on device = number of voxels of every cloud (may exceed cap: caller's overflow check).
+ * The output order / arithmetic rule is this engine's own (open3d is unpinned): oracle/preprocess.py. */
+int dsir_voxel_downsample(dsir_ctx* ctx, const float* points, const int64_t* offsets, int clouds, int stride,
+                          float voxel_size, const float* crop, int cap, float* out, int32_t* counts);
+
+/* Replaces Resampler._resample (mode 0: seeded random order, no repeats while points last, then draws with
+ * replacement) and FixedResampler._resample (mode 1: tile / prefix) of dataloader/transformation.py:72-93.
+ * in [clouds][cap][stride] with counts [clouds] (device, as written by dsir_voxel_downsample)
+ * -> out [clouds][k][stride].  The random order makes the prefix sub-sampling of the pyramid a random sample. */
+int dsir_resample(dsir_ctx* ctx, const float* in, const int32_t* counts, int clouds, int cap, int stride, int k,
+                  int mode, uint64_t seed, float* out);
+
 /* ---- after the path: evaluation metrics ------------- */
 
 /* Replaces common/metrics_util.py:27-85 compute_metrics as called per iteration by test.py:308-355
