@@ -396,3 +396,54 @@ def test_network_dropin_api():
         assert_pose_close(torch.stack(transforms, 1).cpu().numpy(), g["transforms"], 1e-4, 1e-4)
     with pytest.raises(RuntimeError):
         net.load_state_dict({"bogus": torch.zeros(1)})
+
+
+def test_kitti_shaped_16k_feat4_vs_oracle():
+    """BASELINE config 3 shape: 16384-point clouds with reflectance (feat_len 4), KITTI-like extent.
+    The engine's own correspondences are forced into the CPU oracle: (R,t) of every iteration within 1e-4."""
+    from deepsir_amd.arch import NetConfig
+    from deepsir_amd.engine import Engine
+    from deepsir_amd.synth import make_pair
+    from deepsir_amd.weights import generate_state_dict
+    from oracle.knn import add_pyramids
+    from oracle.network import OracleNet, to_torch
+    cfg = NetConfig(feat_len=4)
+    sd = generate_state_dict(cfg, 1)
+    raw = make_pair(16384, 77, 4, shape="kitti")
+    eng = Engine(cfg, 0, max_points=16384, max_pairs=1)
+    eng.load_state_dict(sd)
+    out = eng.register(cu(raw["points_src"]), cu(raw["points_ref"]), 3)
+    data = to_torch(add_pyramids(raw, cfg.num_knn, cfg.sub_sampling_ratio))
+    # pyramid built on device == oracle pyramid (bit-exact), checked through a second call with supplied pyramids
+    sup = eng.register(cu(raw["points_src"]), cu(raw["points_ref"]), 3, pyramids={k: v.cuda() for k, v in data.items() if k.endswith(("_xyz", "_idx"))})
+    assert torch.equal(sup["transforms"], out["transforms"]) and torch.equal(sup["idx"], out["idx"])
+    torch.set_num_threads(max(1, min(16, torch.get_num_threads())))
+    idx = out["idx"].cpu()
+    T_forced, ep = OracleNet(cfg, sd).register(data, 3, forced_idx=[idx[i].long() for i in range(3)])
+    assert_pose_close(out["transforms"].cpu().numpy()[0], np.stack([t.numpy()[0] for t in T_forced]), 1e-4, 1e-4, "16k")
+    np.testing.assert_allclose(out["logits"].cpu().numpy()[:, 0], np.stack([l.numpy()[0] for l in ep["perm_matrices"]]), rtol=2e-3, atol=2e-3)
+    eng.close()
+
+
+def test_64k_partial_overlap_properties():
+    """BASELINE config 5 shape: 65536-point clouds, 50 % overlap + jitter.  Size-independent properties:
+    bitwise determinism, rotations stay in SO(3), arg-min indices in range, finite logits."""
+    from deepsir_amd.arch import NetConfig
+    from deepsir_amd.engine import Engine
+    from deepsir_amd.synth import make_pair
+    from deepsir_amd.weights import generate_state_dict
+    cfg = NetConfig(feat_len=3)
+    eng = Engine(cfg, 0, max_points=65536, max_pairs=1)
+    eng.load_state_dict(generate_state_dict(cfg, 0))
+    raw = make_pair(65536, 5, 3, partial_overlap=True)
+    src, ref = cu(raw["points_src"]), cu(raw["points_ref"])
+    a = eng.register(src, ref, 2)
+    b = eng.register(src, ref, 2)
+    assert torch.equal(a["transforms"], b["transforms"]) and torch.equal(a["idx"], b["idx"])
+    T = a["transforms"].cpu().numpy().astype(np.float64)[0]
+    for R in T[:, :, :3]:
+        np.testing.assert_allclose(R @ R.T, np.eye(3), atol=5e-5)
+    idx = a["idx"].cpu().numpy()
+    assert idx.min() >= 0 and idx.max() < 65536 and np.isfinite(a["logits"].cpu().numpy()).all()
+    assert int(a["invalid"][0]) == 0
+    eng.close()
