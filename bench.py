@@ -79,6 +79,9 @@ def main():
     ap.add_argument("--streams", type=int, default=int(os.environ.get("DSIR_BENCH_STREAMS", "2")),
                     help="engine streams per GPU; the batch is split across them and registered concurrently")
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--feat-len", type=int, default=3, help="3 = xyz (3DMatch), 4 = xyz + reflectance (KITTI)")
+    ap.add_argument("--shape", default="3dmatch", choices=["3dmatch", "kitti"], help="extent of the synthetic clouds")
+    ap.add_argument("--partial-overlap", action="store_true", help="config 5: 50 %% overlap crops + jitter")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -107,7 +110,7 @@ def main():
     from deepsir_amd.synth import make_batch
     from deepsir_amd.weights import generate_state_dict
 
-    cfg = NetConfig(feat_len=3)
+    cfg = NetConfig(feat_len=a.feat_len)
     sd = generate_state_dict(cfg, 0)
     P, N, n_iter = a.pairs, a.points, a.iters
     S = max(1, a.streams)
@@ -115,7 +118,7 @@ def main():
     P_launch = (P + S - 1) // S   # pairs per nn_match launch
     eng.load_state_dict(sd)
     # every rank registers different pairs (weak scaling): seeds partitioned by rank
-    batch = make_batch(N, [10_000 + rank * P + i for i in range(P)], cfg.feat_len)
+    batch = make_batch(N, [10_000 + rank * P + i for i in range(P)], cfg.feat_len, a.shape, a.partial_overlap)
     src = torch.from_numpy(batch["points_src"]).to(dev)
     ref = torch.from_numpy(batch["points_ref"]).to(dev)
     outs = [None] * max(a.steps, 1)

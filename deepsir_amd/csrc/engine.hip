@@ -476,9 +476,20 @@ int randla_forward(dsir_ctx* c, const RandlaW& w, const Seg& in0, const Seg* in1
     x = s.mlp2d(w.dec[j], s0, &s1, py.nl[lvl], true);
   }
   const int n0 = py.nl[0];
+  bool fused = false;
+  static const bool no_head = getenv("DSIR_NO_HEAD") != nullptr;   // A/B switch
+  if (logits_out && !no_head &&w.dec_out == 32 && g.out_feat_dim == 64 && w.fc[0].cout == 64 && w.fc[1].cout == 32) {
+    // mlp_out + fc_label in one launch (head_mlp.hip); bit-identical to the four launches below
+    HeadArgs h;
+    h.in = Sched::seg_of(x);
+    h.W1 = w.out_w; h.W2 = w.fc[0].W; h.b2 = w.fc[0].b; h.W3 = w.fc[1].W; h.b3 = w.fc[1].b; h.W4 = w.fc[2].W; h.b4 = w.fc[2].b;
+    h.ncls = w.ncls; h.M = n0; h.clouds = py.clouds; h.feat_out = feat_out; h.logits_out = logits_out;
+    fused = launch_head_mlp(h, st);
+  }
   LinW ow; ow.W = w.out_w; ow.b = nullptr; ow.cin = w.dec_out; ow.cout = g.out_feat_dim;
-  Act feat = s.linear(ow, Sched::seg_of(x), nullptr, n0, EPI_LINEAR, feat_out);
-  if (logits_out) {
+  Act feat;
+  if (!fused) feat = s.linear(ow, Sched::seg_of(x), nullptr, n0, EPI_LINEAR, feat_out);
+  if (logits_out && !fused) {
     Act h = s.linear(w.fc[0], Sched::seg_of(feat), nullptr, n0, EPI_ACT);
     h = s.linear(w.fc[1], Sched::seg_of(h), nullptr, n0, EPI_ACT);
     s.linear(w.fc[2], Sched::seg_of(h), nullptr, n0, EPI_LINEAR, logits_out);

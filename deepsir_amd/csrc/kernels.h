@@ -76,6 +76,19 @@ bool launch_pw_deep(const GemmArgs& a, hipStream_t st);
 // wide-layer path, LDS-tiled 128/64 x 64 x 32 (pw_tile.hip); same envelope as pw_deep
 bool launch_pw_tile(const GemmArgs& a, hipStream_t st);
 
+// mlp_out + fc_label fused (head_mlp.hip): x[32] -> feat[64] -> 64 -> 32 -> ncls   (RandLANet.py:363-367)
+struct HeadArgs {
+  Seg in = {};                  // last decoder block, [clouds][M][32], lazy GroupNorm + LeakyReLU
+  const float *W1 = nullptr;    // mlp_out      [64][32]
+  const float *W2 = nullptr, *b2 = nullptr;   // fc_label.0 (BN folded) [64][64]
+  const float *W3 = nullptr, *b3 = nullptr;   // fc_label.3 (BN folded) [32][64]
+  const float *W4 = nullptr, *b4 = nullptr;   // fc_label.6 [ncls][32]
+  int ncls = 0, M = 0, clouds = 1;
+  float* feat_out = nullptr;    // [clouds][M][64] or nullptr
+  float* logits_out = nullptr;  // [clouds][M][ncls]
+};
+bool launch_head_mlp(const HeadArgs& a, hipStream_t st);   // false => shape outside the fused envelope
+
 // y = LeakyReLU(GN_a(a) + GN_b(b))   (RandLANet.py:228-230)
 void launch_residual_combine(const float* a, GnRef ga, const float* b, GnRef gb, int C, int rows, int clouds,
                              float* y, hipStream_t st);
