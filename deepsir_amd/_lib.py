@@ -29,6 +29,7 @@ class dsir_cfg(C.Structure):
         ("num_classes", C.c_int32),
         ("max_points", C.c_int32),
         ("max_pairs", C.c_int32),
+        ("pipeline", C.c_int32),
     ]
 
 
@@ -46,6 +47,13 @@ class dsir_pair_result(C.Structure):
     _fields_ = [
         ("transforms", C.c_void_p), ("idx", C.c_void_p), ("logits", C.c_void_p), ("pt_ref_new", C.c_void_p),
         ("invalid", C.c_void_p),
+    ]
+
+
+class dsir_cloud_out(C.Structure):
+    _fields_ = [
+        ("xyz", C.c_void_p), ("feat", C.c_void_p), ("logits", C.c_void_p), ("score", C.c_void_p), ("label", C.c_void_p),
+        ("index", C.c_void_p),
     ]
 
 
@@ -73,6 +81,8 @@ SYMBOLS = {
     "dsir_kabsch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                               C.c_void_p]),
     "dsir_register": (C.c_int, [C.c_void_p, C.POINTER(dsir_pair_batch), C.c_int, C.POINTER(dsir_pair_result)]),
+    "dsir_forward_pair": (C.c_int, [C.c_void_p, C.POINTER(dsir_pair_batch), C.c_int, C.POINTER(dsir_cloud_out),
+                                    C.POINTER(dsir_cloud_out)]),
     "dsir_match_timer": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), c_i64_p]),
     "dsir_enable_match_timer": (C.c_int, [C.c_void_p, C.c_int]),
     "dsir_enable_graph": (C.c_int, [C.c_void_p, C.c_int]),

@@ -132,12 +132,20 @@ def network_specs(cfg: NetConfig) -> List[ParamSpec]:
     """Key order follows module registration order at model.py:133-193:
     feat_extractor, mlp_feat, mlp_att, mlp_proj, inlier_model."""
     D = cfg.out_feat_dim
+    if cfg.pipeline not in PIPELINES:
+        raise ValueError(f"pipeline must be one of {PIPELINES} (reference model.py:131)")
     out = randla_specs("feat_extractor", cfg.feat_len, cfg.num_classes, cfg)
-    out += _mlp1d("mlp_feat", [D, D, 128, D])
-    out += _mlp1d("mlp_att", [4, 32, 64, 128, 256, D])
-    out += _mlp1d("mlp_proj", [D, D])
-    out += randla_specs("inlier_model", 6, 1, cfg)
+    if cfg.pipeline != "label":          # model.py:135
+        out += _mlp1d("mlp_feat", [D, D, 128, D])
+        out += _mlp1d("mlp_att", [4, 32, 64, 128, 256, D])
+        out += _mlp1d("mlp_proj", [D, D])
+    if cfg.pipeline == "align":          # model.py:181-191
+        out += randla_specs("inlier_model", 6, 1, cfg)
     return out
+
+
+PIPELINES = ("align", "feat", "label")
+"""args.pipeline values (reference model.py:131); the index is DSIR_PIPELINE_* of include/dsir.h."""
 
 
 def level_sizes(n: int, ratios: Sequence[int]) -> List[int]:

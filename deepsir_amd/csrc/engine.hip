@@ -584,6 +584,7 @@ int dsir_create(int device, const dsir_cfg* cfg, dsir_ctx** out) {
   }
   if (cfg->feat_len < 3 || cfg->feat_len > 16) return fail(nullptr, "feat_len must be in [3,16]");
   if (cfg->max_points < kKnn * 64 || cfg->max_pairs < 1) return fail(nullptr, "max_points must be >= %d and max_pairs >= 1", kKnn * 64);
+  if (cfg->pipeline < DSIR_PIPELINE_ALIGN || cfg->pipeline > DSIR_PIPELINE_LABEL) return fail(nullptr, "unknown pipeline %d", cfg->pipeline);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, "no HIP device available");
   if (device < 0 || device >= ndev) return fail(nullptr, "device %d out of range (%d devices)", device, ndev);
@@ -593,11 +594,14 @@ int dsir_create(int device, const dsir_cfg* cfg, dsir_ctx** out) {
     delete c;
     return fail(nullptr, "cannot initialise device %d", device);
   }
+  // which sub-networks exist follows args.pipeline (model.py:131-193)
   add_randla(c, "feat_extractor", cfg->feat_len, cfg->num_classes);
-  add_mlp1d(c, "mlp_feat", {64, 64, 128, 64});
-  add_mlp1d(c, "mlp_att", {4, 32, 64, 128, 256, 64});
-  add_mlp1d(c, "mlp_proj", {64, 64});
-  add_randla(c, "inlier_model", 6, 1);
+  if (cfg->pipeline != DSIR_PIPELINE_LABEL) {
+    add_mlp1d(c, "mlp_feat", {64, 64, 128, 64});
+    add_mlp1d(c, "mlp_att", {4, 32, 64, 128, 256, 64});
+    add_mlp1d(c, "mlp_proj", {64, 64});
+  }
+  if (cfg->pipeline == DSIR_PIPELINE_ALIGN) add_randla(c, "inlier_model", 6, 1);
   // workspace: ~1.4k floats per point per cloud for one RandLA pass, 2P clouds, plus per-pair state
   const size_t clouds = (size_t)2 * cfg->max_pairs;
   const size_t per_cloud = (size_t)cfg->max_points * 2560 * sizeof(float) + ((size_t)1 << 22);
@@ -666,12 +670,17 @@ int dsir_finalize_weights(dsir_ctx* c) {
   for (auto& p : c->params)
     if (!p.loaded && !p.ignored) return fail(c, "missing key in state_dict: %s", p.name.c_str());
   Uploader u;
+  const bool has_agg = c->cfg.pipeline != DSIR_PIPELINE_LABEL, has_inl = c->cfg.pipeline == DSIR_PIPELINE_ALIGN;
   RandlaOff fo = up_randla(c, u, "feat_extractor");
-  RandlaOff io = up_randla(c, u, "inlier_model");
-  LinOff mf[3] = {up_lin(c, u, "mlp_feat", 0, true), up_lin(c, u, "mlp_feat", 3, true), up_lin(c, u, "mlp_feat", 6, false)};
-  LinOff ma[5] = {up_lin(c, u, "mlp_att", 0, true), up_lin(c, u, "mlp_att", 3, true), up_lin(c, u, "mlp_att", 6, true),
-                  up_lin(c, u, "mlp_att", 9, true), up_lin(c, u, "mlp_att", 12, false)};
-  LinOff mp = up_lin(c, u, "mlp_proj", 0, false);
+  RandlaOff io{};
+  if (has_inl) io = up_randla(c, u, "inlier_model");
+  LinOff mf[3] = {}, ma[5] = {}, mp{};
+  if (has_agg) {
+    mf[0] = up_lin(c, u, "mlp_feat", 0, true); mf[1] = up_lin(c, u, "mlp_feat", 3, true); mf[2] = up_lin(c, u, "mlp_feat", 6, false);
+    ma[0] = up_lin(c, u, "mlp_att", 0, true); ma[1] = up_lin(c, u, "mlp_att", 3, true); ma[2] = up_lin(c, u, "mlp_att", 6, true);
+    ma[3] = up_lin(c, u, "mlp_att", 9, true); ma[4] = up_lin(c, u, "mlp_att", 12, false);
+    mp = up_lin(c, u, "mlp_proj", 0, false);
+  }
   HIP_OK(c, hipSetDevice(c->device));
   HIP_OK(c, hipStreamSynchronize(c->stream));
   if (c->dweights) { hipFree(c->dweights); c->dweights = nullptr; }
@@ -679,10 +688,12 @@ int dsir_finalize_weights(dsir_ctx* c) {
   HIP_OK(c, hipMemcpy(c->dweights, u.blob.data(), u.blob.size() * sizeof(float), hipMemcpyHostToDevice));
   const float* b = c->dweights;
   c->net.feat = bind_randla(b, fo, c->cfg);
-  c->net.inl = bind_randla(b, io, c->cfg);
-  for (int k = 0; k < 3; ++k) c->net.mlp_feat[k] = bind_lin(b, mf[k]);
-  for (int k = 0; k < 5; ++k) c->net.mlp_att[k] = bind_lin(b, ma[k]);
-  c->net.mlp_proj = bind_lin(b, mp);
+  if (has_inl) c->net.inl = bind_randla(b, io, c->cfg);
+  if (has_agg) {
+    for (int k = 0; k < 3; ++k) c->net.mlp_feat[k] = bind_lin(b, mf[k]);
+    for (int k = 0; k < 5; ++k) c->net.mlp_att[k] = bind_lin(b, ma[k]);
+    c->net.mlp_proj = bind_lin(b, mp);
+  }
   c->finalized = true;
   return 0;
 }
@@ -708,6 +719,7 @@ int dsir_randla_forward(dsir_ctx* c, int which, const float* features, int cin, 
                         const int32_t* neigh, const int32_t* sub, const int32_t* interp, float* feat, float* logits) {
   if (check_ready(c)) return 1;
   HIP_OK(c, hipSetDevice(c->device));
+  if (which != 0 && c->cfg.pipeline != DSIR_PIPELINE_ALIGN) return fail(c, "randla_forward: this context has no inlier_model (pipeline != align)");
   const RandlaW& w = which == 0 ? c->net.feat : c->net.inl;
   if (cin != w.cin) return fail(c, "randla_forward: expected %d input channels, got %d", w.cin, cin);
   if (clouds > 2 * c->cfg.max_pairs || n > c->cfg.max_points) return fail(c, "randla_forward: batch exceeds max_pairs/max_points");
@@ -735,6 +747,7 @@ int dsir_score(dsir_ctx* c, const float* feat, const float* logits, const float*
 int dsir_aggregate(dsir_ctx* c, const float* xyz, int64_t xyz_cs, const float* feat0, const float* score, int clouds,
                    int n, float* desc) {
   if (check_ready(c)) return 1;
+  if (c->cfg.pipeline == DSIR_PIPELINE_LABEL) return fail(c, "dsir_aggregate: a label-pipeline context has no aggregation layers");
   HIP_OK(c, hipSetDevice(c->device));
   float* F = run_mlp_feat(c, feat0, clouds, n);
   run_att_proj(c, xyz, xyz_cs, score, F, clouds, n, desc);
@@ -773,12 +786,19 @@ int dsir_kabsch(dsir_ctx* c, const float* src, const float* tgt, const float* w,
   return post(c);
 }
 
-static int register_enqueue(dsir_ctx* c, const dsir_pair_batch* in, int n_iter, const dsir_pair_result* out) {
+// Pyramids + forward_pair (model.py:609-648) of P pairs: everything both dsir_register and dsir_forward_pair need.
+struct PairStage {
+  Pyramid ps, pr;
+  float *feat_s, *feat_r, *logit_s, *logit_r, *score_s, *score_r;
+  int32_t *label_s, *label_r;     // only when want_label
+  float *rxyz;                    // == pr.xyz
+};
+static int forward_pair_stage(dsir_ctx* c, const dsir_pair_batch* in, bool want_score, bool want_label, PairStage& S) {
   const dsir_cfg& g = c->cfg;
   const int P = in->pairs, J = in->n_src, K = in->n_ref, cin = g.feat_len;
   if (P < 1 || P > g.max_pairs) return fail(c, "pairs=%d outside [1,%d]", P, g.max_pairs);
   if (J > g.max_points || K > g.max_points) return fail(c, "cloud larger than max_points=%d", g.max_points);
-  if (n_iter < 1) return fail(c, "n_iter must be >= 1");
+  if (!in->points_src || !in->points_ref) return fail(c, "null point clouds");
   const bool have_py = in->src_xyz && in->src_neigh && in->src_sub && in->src_interp && in->ref_xyz && in->ref_neigh &&
                        in->ref_sub && in->ref_interp;
   const bool any_py = in->src_xyz || in->src_neigh || in->src_sub || in->src_interp || in->ref_xyz || in->ref_neigh ||
@@ -788,7 +808,7 @@ static int register_enqueue(dsir_ctx* c, const dsir_pair_batch* in, int n_iter, 
   Arena& ws = c->ws;
 
   // ---- pyramids of src and ref (engine-owned when built here)
-  Pyramid ps, pr;
+  Pyramid& ps = S.ps; Pyramid& pr = S.pr;
   fill_pyramid_layout(g, P, J, ps);
   fill_pyramid_layout(g, P, K, pr);
   if (ps.nl[3] < kKnn || pr.nl[3] < kKnn) return fail(c, "cloud too small: need at least %d points", kKnn * 64);
@@ -796,9 +816,11 @@ static int register_enqueue(dsir_ctx* c, const dsir_pair_batch* in, int n_iter, 
   float* feat_all = ws.get<float>((size_t)P * (J + K) * 64);
   float* logit_all = ws.get<float>((size_t)P * (J + K) * g.num_classes);
   float* score_all = ws.get<float>((size_t)P * (J + K));
+  int32_t* label_all = want_label ? ws.get<int32_t>((size_t)P * (J + K)) : nullptr;
   float* feat_s = feat_all; float* feat_r = feat_all + (size_t)P * J * 64;
   float* score_s = score_all; float* score_r = score_all + (size_t)P * J;
   float* logit_s = logit_all; float* logit_r = logit_all + (size_t)P * J * g.num_classes;
+  int32_t* label_s = label_all; int32_t* label_r = label_all ? label_all + (size_t)P * J : nullptr;
 
   // pyramid storage: [src clouds | ref clouds] contiguous when joint
   float* pxyz = ws.get<float>((size_t)P * (ps.S + pr.S) * 3);
@@ -838,20 +860,40 @@ static int register_enqueue(dsir_ctx* c, const dsir_pair_batch* in, int n_iter, 
     Pyramid pa = ps;
     pa.clouds = 2 * P;
     if (int r = randla_forward(c, c->net.feat, plain_seg(feats_in, (int64_t)J * cin, cin, cin), nullptr, pa, feat_all, logit_all)) return r;
-    sc.red = ws.get<float>((size_t)2 * P * 4); sc.prob = ws.get<float>((size_t)2 * P * J); sc.label = ws.get<int32_t>((size_t)2 * P * J);
-    launch_score(feat_all, logit_all, g.num_classes, pxyz, (int64_t)ps.S * 3, pneigh, (int64_t)ps.S * kKnn, 2 * P, J, sc,
-                 score_all, nullptr, st);
+    if (want_score) {
+      sc.red = ws.get<float>((size_t)2 * P * 4); sc.prob = ws.get<float>((size_t)2 * P * J); sc.label = ws.get<int32_t>((size_t)2 * P * J);
+      launch_score(feat_all, logit_all, g.num_classes, pxyz, (int64_t)ps.S * 3, pneigh, (int64_t)ps.S * kKnn, 2 * P, J, sc,
+                   score_all, label_all, st);
+    }
   } else {
     if (int r = randla_forward(c, c->net.feat, plain_seg(feats_in, (int64_t)J * cin, cin, cin), nullptr, ps, feat_s, logit_s)) return r;
     ws.release(mark0);
     if (int r = randla_forward(c, c->net.feat, plain_seg(feats_in + (size_t)P * J * cin, (int64_t)K * cin, cin, cin), nullptr, pr, feat_r, logit_r)) return r;
     ws.release(mark0);
-    const int nmax = J > K ? J : K;
-    sc.red = ws.get<float>((size_t)P * 4); sc.prob = ws.get<float>((size_t)P * nmax); sc.label = ws.get<int32_t>((size_t)P * nmax);
-    launch_score(feat_s, logit_s, g.num_classes, pxyz, (int64_t)ps.S * 3, pneigh, (int64_t)ps.S * kKnn, P, J, sc, score_s, nullptr, st);
-    launch_score(feat_r, logit_r, g.num_classes, rxyz, (int64_t)pr.S * 3, rneigh, (int64_t)pr.S * kKnn, P, K, sc, score_r, nullptr, st);
+    if (want_score) {
+      const int nmax = J > K ? J : K;
+      sc.red = ws.get<float>((size_t)P * 4); sc.prob = ws.get<float>((size_t)P * nmax); sc.label = ws.get<int32_t>((size_t)P * nmax);
+      launch_score(feat_s, logit_s, g.num_classes, pxyz, (int64_t)ps.S * 3, pneigh, (int64_t)ps.S * kKnn, P, J, sc, score_s, label_s, st);
+      launch_score(feat_r, logit_r, g.num_classes, rxyz, (int64_t)pr.S * 3, rneigh, (int64_t)pr.S * kKnn, P, K, sc, score_r, label_r, st);
+    }
   }
   ws.release(mark0);
+  S.feat_s = feat_s; S.feat_r = feat_r; S.logit_s = logit_s; S.logit_r = logit_r; S.score_s = score_s; S.score_r = score_r;
+  S.label_s = label_s; S.label_r = label_r; S.rxyz = rxyz;
+  return 0;
+}
+
+static int register_enqueue(dsir_ctx* c, const dsir_pair_batch* in, int n_iter, const dsir_pair_result* out) {
+  const dsir_cfg& g = c->cfg;
+  const int P = in->pairs, J = in->n_src, K = in->n_ref;
+  if (n_iter < 1) return fail(c, "n_iter must be >= 1");
+  hipStream_t st = c->stream;
+  Arena& ws = c->ws;
+  PairStage S;
+  if (int r = forward_pair_stage(c, in, true, false, S)) return r;
+  const Pyramid& ps = S.ps; const Pyramid& pr = S.pr;
+  float *feat_s = S.feat_s, *feat_r = S.feat_r, *score_s = S.score_s, *score_r = S.score_r, *rxyz = S.rxyz;
+  const float* pxyz = ps.xyz;
 
   // ---- loop invariants of Network.aggregation: the whole ref side and mlp_feat(feat_src)
   float* desc_r = ws.get<float>((size_t)P * K * 64);
@@ -939,6 +981,7 @@ static int register_enqueue(dsir_ctx* c, const dsir_pair_batch* in, int n_iter, 
 int dsir_register(dsir_ctx* c, const dsir_pair_batch* in, int n_iter, const dsir_pair_result* out) {
   if (check_ready(c)) return 1;
   if (!in || !out || !out->transforms) return fail(c, "dsir_register: null argument");
+  if (c->cfg.pipeline != DSIR_PIPELINE_ALIGN) return fail(c, "dsir_register needs an align-pipeline context");
   HIP_OK(c, hipSetDevice(c->device));
   if (!c->use_graph || c->time_match) {
     if (int r = register_enqueue(c, in, n_iter, out)) return r;
@@ -965,6 +1008,78 @@ int dsir_register(dsir_ctx* c, const dsir_pair_batch* in, int n_iter, const dsir
     c->graph_key = key;
   }
   HIP_OK(c, hipGraphLaunch(c->graph_exec, c->stream));
+  return post(c);
+}
+
+// One side of forward_pair's endpoints (model.py:637-666).
+static int emit_cloud_out(dsir_ctx* c, const Pyramid& py, const float* feat0, const float* logits, const float* score,
+                          const int32_t* label, int P, int n, int num_sub, const dsir_cloud_out* o) {
+  const dsir_cfg& g = c->cfg;
+  hipStream_t st = c->stream;
+  Arena& ws = c->ws;
+  const int M = num_sub > 0 ? num_sub : n;
+  const int64_t xyz_cs = (int64_t)py.S * 3;
+  if (o->logits) HIP_OK(c, hipMemcpyAsync(o->logits, logits, sizeof(float) * P * n * g.num_classes, hipMemcpyDeviceToDevice, st));
+  if (g.pipeline == DSIR_PIPELINE_LABEL) {
+    if (o->xyz) launch_copy_xyz(py.xyz, xyz_cs, 3, n, P, o->xyz, (int64_t)n * 3, st);
+    if (o->feat) launch_l2norm64(feat0, (int64_t)P * n, o->feat, st);
+    return 0;
+  }
+  const size_t mark = ws.mark();
+  const int32_t* sel = nullptr;
+  const float* xyz_m = py.xyz; int64_t xyz_m_cs = xyz_cs;
+  const float* feat_m = feat0; const float* score_m = score;
+  if (num_sub > 0) {
+    int32_t* idx = ws.get<int32_t>((size_t)P * M);
+    float* sc = ws.get<float>((size_t)P * M);
+    float* xs = ws.get<float>((size_t)P * M * 3);
+    float* fs = ws.get<float>((size_t)P * M * 64);
+    void* scratch = ws.raw(topk_scratch_bytes(P, n));
+    if (ws.overflow) return fail(c, "workspace exhausted in forward_pair");
+    if (int r = launch_topk(score, P, n, M, idx, sc, scratch, st)) return fail(c, "top-k selection failed (%d)", r);
+    launch_gather_rows(py.xyz, xyz_cs, 3, idx, 3, M, P, xs, st);
+    launch_gather_rows(feat0, (int64_t)n * 64, 64, idx, 64, M, P, fs, st);
+    sel = idx; xyz_m = xs; xyz_m_cs = (int64_t)M * 3; feat_m = fs; score_m = sc;
+  }
+  if (o->xyz) {
+    if (sel) HIP_OK(c, hipMemcpyAsync(o->xyz, xyz_m, sizeof(float) * P * M * 3, hipMemcpyDeviceToDevice, st));
+    else launch_copy_xyz(py.xyz, xyz_cs, 3, n, P, o->xyz, (int64_t)n * 3, st);
+  }
+  if (o->score) HIP_OK(c, hipMemcpyAsync(o->score, score_m, sizeof(float) * P * M, hipMemcpyDeviceToDevice, st));
+  if (o->label) launch_gather_i32(label, n, sel, M, P, o->label, st);
+  if (o->index && sel) HIP_OK(c, hipMemcpyAsync(o->index, sel, sizeof(int32_t) * P * M, hipMemcpyDeviceToDevice, st));
+  if (o->feat) {
+    if (g.pipeline == DSIR_PIPELINE_ALIGN) {
+      HIP_OK(c, hipMemcpyAsync(o->feat, feat_m, sizeof(float) * P * M * 64, hipMemcpyDeviceToDevice, st));
+    } else {
+      // aggregation (already L2-normalised, model.py:232-233), then the second F.normalize of :650-651
+      float* desc = ws.get<float>((size_t)P * M * 64);
+      if (ws.overflow) return fail(c, "workspace exhausted in forward_pair");
+      const size_t m2 = ws.mark();
+      float* F = run_mlp_feat(c, feat_m, P, M);
+      run_att_proj(c, xyz_m, xyz_m_cs, score_m, F, P, M, desc);
+      ws.release(m2);
+      launch_l2norm64(desc, (int64_t)P * M, o->feat, st);
+    }
+  }
+  ws.release(mark);
+  return 0;
+}
+
+int dsir_forward_pair(dsir_ctx* c, const dsir_pair_batch* in, int num_sub, const dsir_cloud_out* src, const dsir_cloud_out* ref) {
+  if (check_ready(c)) return 1;
+  if (!in || !src || !ref) return fail(c, "dsir_forward_pair: null argument");
+  HIP_OK(c, hipSetDevice(c->device));
+  const dsir_cfg& g = c->cfg;
+  if (num_sub > 0) {
+    if (g.pipeline != DSIR_PIPELINE_FEAT) return fail(c, "num_sub > 0 is only meaningful for the feat pipeline");
+    if (num_sub > in->n_src || num_sub > in->n_ref) return fail(c, "num_sub=%d exceeds the cloud size", num_sub);
+  }
+  const bool scored = g.pipeline != DSIR_PIPELINE_LABEL;
+  PairStage S;
+  if (int r = forward_pair_stage(c, in, scored, scored, S)) return r;
+  if (int r = emit_cloud_out(c, S.ps, S.feat_s, S.logit_s, S.score_s, S.label_s, in->pairs, in->n_src, num_sub, src)) return r;
+  if (int r = emit_cloud_out(c, S.pr, S.feat_r, S.logit_r, S.score_r, S.label_r, in->pairs, in->n_ref, num_sub, ref)) return r;
   return post(c);
 }
 

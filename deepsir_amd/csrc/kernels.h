@@ -89,6 +89,16 @@ struct HeadArgs {
 };
 bool launch_head_mlp(const HeadArgs& a, hipStream_t st);   // false => shape outside the fused envelope
 
+// select.hip — feat / label pipelines (model.py:650-651, :682-697)
+size_t topk_scratch_bytes(int clouds, int n);
+// idx_out [clouds][k] = the k highest scores of every cloud, descending, ties in ascending index; score_out optional
+int launch_topk(const float* score, int clouds, int n, int k, int32_t* idx_out, float* score_out, void* scratch, hipStream_t st);
+void launch_gather_rows(const float* in, int64_t in_cloud_stride, int ld, const int32_t* idx, int C, int m, int clouds, float* out,
+                        hipStream_t st);
+void launch_gather_i32(const int32_t* in, int64_t in_cloud_stride, const int32_t* idx, int m, int clouds, int32_t* out,
+                       hipStream_t st);
+void launch_l2norm64(const float* x, int64_t rows, float* y, hipStream_t st);   // F.normalize over 64 channels
+
 // y = LeakyReLU(GN_a(a) + GN_b(b))   (RandLANet.py:228-230)
 void launch_residual_combine(const float* a, GnRef ga, const float* b, GnRef gb, int C, int rows, int clouds,
                              float* y, hipStream_t st);

@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .arch import NetConfig, level_sizes
+from .arch import PIPELINES, NetConfig, level_sizes
 
 
 class EngineError(RuntimeError):
@@ -49,6 +49,7 @@ class Engine:
             c.d_out[i] = cfg.d_out[i]
         c.out_feat_dim, c.num_classes = cfg.out_feat_dim, cfg.num_classes
         c.max_points, c.max_pairs = self.max_points, self.max_pairs
+        c.pipeline = PIPELINES.index(cfg.pipeline)
         h = C.c_void_p()
         if self.lib.dsir_create(device, C.byref(c), C.byref(h)) != 0:
             raise EngineError("dsir_create: " + self.lib.dsir_last_error(None).decode())
@@ -205,14 +206,8 @@ class Engine:
         return T, bad
 
     # ------------------------------------------------------------------ the whole path
-    def register(self, points_src, points_ref, n_iter: int = 5, pyramids: Optional[dict] = None,
-                 forced_idx: Optional[torch.Tensor] = None, want_aux: bool = True, sync: bool = True, out: Optional[dict] = None):
-        """forward_align_4 counterpart for P pairs.
-
-        points_* [P, N, feat_len].  pyramids: optional dict with the reference's
-        data-dict keys (points_{src,ref}_{xyz,neigh_idx,sub_idx,interp_idx}),
-        int32 or int64.  Returns dict(transforms [P,n_iter,3,4], idx [n_iter,P,J],
-        logits [n_iter,P,J], pt_ref_new [P,J,3], invalid [P])."""
+    def _pair_batch(self, points_src, points_ref, pyramids):
+        """dsir_pair_batch of P pairs (+ the tensors that must stay alive while it is in use)."""
         points_src, points_ref = _chk(points_src, torch.float32, "points_src"), _chk(points_ref, torch.float32, "points_ref")
         P, J, cin = points_src.shape
         K = points_ref.shape[1]
@@ -221,7 +216,7 @@ class Engine:
         b = _lib.dsir_pair_batch()
         b.pairs, b.n_src, b.n_ref = P, J, K
         b.points_src, b.points_ref = _ptr(points_src), _ptr(points_ref)
-        keep = []
+        keep = [points_src, points_ref]
         if pyramids is not None:
             for side, fld in (("src", "src"), ("ref", "ref")):
                 x = _chk(pyramids[f"points_{side}_xyz"], torch.float32, "xyz")
@@ -231,6 +226,17 @@ class Engine:
                 keep += [x, nb, sb, ip]
                 setattr(b, fld + "_xyz", _ptr(x)); setattr(b, fld + "_neigh", _ptr(nb))
                 setattr(b, fld + "_sub", _ptr(sb)); setattr(b, fld + "_interp", _ptr(ip))
+        return b, keep, (P, J, K)
+
+    def register(self, points_src, points_ref, n_iter: int = 5, pyramids: Optional[dict] = None,
+                 forced_idx: Optional[torch.Tensor] = None, want_aux: bool = True, sync: bool = True, out: Optional[dict] = None):
+        """forward_align_4 counterpart for P pairs.
+
+        points_* [P, N, feat_len].  pyramids: optional dict with the reference's
+        data-dict keys (points_{src,ref}_{xyz,neigh_idx,sub_idx,interp_idx}),
+        int32 or int64.  Returns dict(transforms [P,n_iter,3,4], idx [n_iter,P,J],
+        logits [n_iter,P,J], pt_ref_new [P,J,3], invalid [P])."""
+        b, keep, (P, J, K) = self._pair_batch(points_src, points_ref, pyramids)
         if forced_idx is not None:
             forced_idx = _chk(forced_idx, torch.int32, "forced_idx")
             assert tuple(forced_idx.shape) == (n_iter, P, J)
@@ -252,6 +258,35 @@ class Engine:
             self.sync()
         out["_keep"] = keep
         return out
+
+    def forward_pair(self, points_src, points_ref, num_sub: Optional[int] = None, pyramids: Optional[dict] = None,
+                     sync: bool = True):
+        """Network.forward_pair counterpart (reference model.py:609-666) for P pairs, point-major:
+        returns {side: {xyz [P,M,3], feat [P,M,64], logits [P,N,ncls], score [P,M], label [P,M], index [P,M]}}
+        with M = num_sub if num_sub > 0 else N; score/label/index only where the pipeline produces them."""
+        num_sub = self.cfg.num_sub if num_sub is None else int(num_sub)
+        b, keep, (P, J, K) = self._pair_batch(points_src, points_ref, pyramids)
+        res, structs = {}, []
+        for side, n in (("src", J), ("ref", K)):
+            M = num_sub if num_sub > 0 else n
+            o = {"xyz": self._empty((P, M, 3)), "feat": self._empty((P, M, 64)),
+                 "logits": self._empty((P, n, self.cfg.num_classes))}
+            if self.cfg.pipeline != "label":
+                o["score"] = self._empty((P, M))
+                o["label"] = self._empty((P, M), torch.int32)
+                if num_sub > 0:
+                    o["index"] = self._empty((P, M), torch.int32)
+            c = _lib.dsir_cloud_out()
+            for k in ("xyz", "feat", "logits", "score", "label", "index"):
+                setattr(c, k, _ptr(o.get(k)))
+            res[side] = o
+            structs.append(c)
+        self._pre()
+        self._call(self.lib.dsir_forward_pair(self.h, C.byref(b), int(num_sub), C.byref(structs[0]), C.byref(structs[1])))
+        if sync:
+            self.sync()
+        res["_keep"] = keep
+        return res
 
     # ------------------------------------------------------------------ in front of the path: pre-processing
     def voxel_downsample(self, clouds: Sequence[torch.Tensor], voxel_size: float, crop: Optional[Sequence[float]] = None,

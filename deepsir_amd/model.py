@@ -1,4 +1,4 @@
-"""Drop-in for the reference's ``network.model.Network`` (align pipeline).
+"""Drop-in for the reference's ``network.model.Network`` (align, feat and label pipelines, inference).
 
 Keeps the reference's host API verbatim (reference network/model.py:119-195,
 :297-298, :520-607; test.py:609-614):
@@ -47,10 +47,11 @@ class Network(nn.Module):
         super().__init__()
         self.cfg = NetConfig.from_args(args)
         self.pipeline = self.cfg.pipeline
-        if self.pipeline != "align":
-            raise NotImplementedError("only pipeline='align' (forward_align_4) is on the accelerated path")
-        if self.cfg.num_sub > 0:
-            raise NotImplementedError("num_sub > 0 (top-k sub-selection) is outside the accelerated path")
+        if self.pipeline not in ("align", "feat", "label"):
+            raise AssertionError("pipeline must be 'align', 'feat' or 'label' (reference model.py:131)")
+        if self.pipeline == "align" and self.cfg.num_sub > 0:
+            # the reference's inlier model runs on the FULL src pyramid (model.py:575): it cannot follow a top-k selection
+            raise NotImplementedError("num_sub > 0 with pipeline='align' is not runnable in the reference either")
         self.num_sub, self.num_knn, self.d_out = self.cfg.num_sub, self.cfg.num_knn, self.cfg.out_feat_dim
         self.clip_weight_thresh = getattr(args, "clip_weight_thresh", 0.0)
         for spec in network_specs(self.cfg):
@@ -87,16 +88,31 @@ class Network(nn.Module):
             self._dirty = False
         return self._engine
 
-    # ---- forward = forward_align_4
+    # ---- forward = forward_pair for 'feat' / 'label' (model.py:173-179, :609-666)
+    def _forward_pair(self, eng: Engine, src, ref, pyr):
+        out = eng.forward_pair(src.float(), ref.float(), self.cfg.num_sub, pyramids=pyr)
+        endpoints = {}
+        for side in ("src", "ref"):
+            o = out[side]
+            endpoints[f"pt_{side}"] = o["xyz"].permute(0, 2, 1).contiguous()          # [B, 3, M]
+            endpoints[f"feat_{side}"] = o["feat"].permute(0, 2, 1).contiguous()       # [B, C, M]
+            endpoints[f"logits_{side}"] = o["logits"].permute(0, 2, 1).contiguous()   # [B, num_class, N]
+            if self.pipeline != "label":
+                endpoints[f"score_{side}"] = o["score"]                               # [B, M]
+        return None, endpoints
+
+    # ---- forward = forward_align_4 for 'align'
     @torch.no_grad()
     def forward(self, data: Dict[str, torch.Tensor], opt=None):
-        num_reg_iter, _clip_weight = opt  # clip_weight is ignored by the reference too (model.py:581-582)
         src, ref = data["points_src"], data["points_ref"]
         B, J, _ = src.shape
         K = ref.shape[1]
         eng = self._ensure_engine(max(J, K), B)
         have = all(f"points_{s}_{k}" in data for s in ("src", "ref") for k in _PYR_KEYS)
         pyr = {f"points_{s}_{k}": data[f"points_{s}_{k}"] for s in ("src", "ref") for k in _PYR_KEYS} if have else None
+        if self.pipeline != "align":
+            return self._forward_pair(eng, src, ref, pyr)
+        num_reg_iter, _clip_weight = opt  # clip_weight is ignored by the reference too (model.py:581-582)
         out = eng.register(src.float(), ref.float(), int(num_reg_iter), pyramids=pyr)
         transforms: List[torch.Tensor] = [out["transforms"][:, i].contiguous() for i in range(num_reg_iter)]
         idx_cpu = out["idx"].cpu()

@@ -49,7 +49,13 @@ typedef struct dsir_cfg {
   int32_t num_classes;                    /* 19 (semantic head of feat_extractor) */
   int32_t max_points;                     /* workspace sizing: points per cloud */
   int32_t max_pairs;                      /* workspace sizing: pairs per call   */
+  int32_t pipeline;                       /* args.pipeline (network/model.py:122,131): DSIR_PIPELINE_*; selects
+                                           * which sub-networks exist, i.e. which state-dict keys are expected  */
 } dsir_cfg;
+
+#define DSIR_PIPELINE_ALIGN 0   /* feat_extractor + mlp_feat/att/proj + inlier_model (370 keys): the whole path  */
+#define DSIR_PIPELINE_FEAT  1   /* feat_extractor + mlp_feat/att/proj: key-point descriptors (dsir_forward_pair)  */
+#define DSIR_PIPELINE_LABEL 2   /* feat_extractor only: semantic head (dsir_forward_pair)                         */
 
 /* ---- lifecycle ------------------------------------------------------------ */
 
@@ -155,6 +161,27 @@ typedef struct dsir_pair_result {
  * supplied), 2x feature RandLA + score, then n_iter x {aggregation, NN match,
  * inlier RandLA, weighted Kabsch, SE(3) update}. */
 int dsir_register(dsir_ctx* ctx, const dsir_pair_batch* in, int n_iter, const dsir_pair_result* out);
+
+/* ---- the `feat` / `label` pipelines of the same Network ---- */
+
+typedef struct dsir_cloud_out {   /* one side (src or ref) of endpoints, point-major; M = num_sub > 0 ? num_sub : N */
+  float* xyz;       /* [P][M][3]   endpoints['pt_*']                                                   or NULL */
+  float* feat;      /* [P][M][64]  endpoints['feat_*'] (ALIGN ctx: raw feat0 of forward_pair's 8-tuple)  or NULL */
+  float* logits;    /* [P][N][num_classes] endpoints['logits_*'] (always all N points)                 or NULL */
+  float* score;     /* [P][M] endpoints['score_*'] (descending when num_sub > 0); not for LABEL        or NULL */
+  int32_t* label;   /* [P][M] arg-max class of the (selected) points; not for LABEL                    or NULL */
+  int32_t* index;   /* [P][M] selected point indices (only when num_sub > 0)                           or NULL */
+} dsir_cloud_out;
+
+/* Replaces Network.forward -> forward_pair (network/model.py:609-666) incl. feat_score's top-num_sub key-point
+ * selection (:682-697, torch.topk; equal scores are taken in ascending index here) for P pairs:
+ *   LABEL ctx: feat = normalize(feat_extractor features), logits.
+ *   FEAT  ctx: score -> optional top-num_sub -> aggregation (:209-235) -> normalize (:650-651), logits, score.
+ *   ALIGN ctx: forward_pair as forward_align_4 calls it (return_flag, :646-648): raw feat0, xyz, label, score;
+ *              num_sub must be <= 0 (the inlier model needs the full pyramid, :575).
+ * The KNN pyramids are built on device unless supplied in `in`. */
+int dsir_forward_pair(dsir_ctx* ctx, const dsir_pair_batch* in, int num_sub, const dsir_cloud_out* src,
+                      const dsir_cloud_out* ref);
 
 /* ---- in front of the path: pre-processing ----------- */
 

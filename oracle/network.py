@@ -160,6 +160,40 @@ class OracleNet:
             out += [feat, xyz, label, s]
         return tuple(out)
 
+    @torch.no_grad()
+    def forward_endpoints(self, data: Dict[str, torch.Tensor], pipeline: str, num_sub: int = -1) -> Dict[str, torch.Tensor]:
+        """Network.forward of the 'feat' / 'label' pipelines = forward_pair without return_flag
+        (model.py:173-179, :609-666) incl. feat_score's top-num_sub selection (:682-697).
+        torch.topk's order among equal scores is unspecified; the rule here (and in select.hip) is
+        descending score, equal scores in ascending index (stable sort)."""
+        ep: Dict[str, torch.Tensor] = {}
+        sides = {}
+        for s, k in (("src", "points_src"), ("ref", "points_ref")):
+            feat, xyz, logits = self.randla("feat_extractor", data[k], data[k + "_xyz"], data[k + "_neigh_idx"],
+                                            data[k + "_sub_idx"], data[k + "_interp_idx"])
+            ep[f"logits_{s}"] = logits
+            score = label = index = None
+            if pipeline != "label":
+                prob, label = torch.max(logits, dim=1, keepdim=True)
+                N = xyz.shape[2]
+                score = self.score(feat, xyz, prob, label, data[k + "_neigh_idx"][:, :N])
+                if num_sub > 0:
+                    index = torch.sort(score + 0.0, dim=-1, descending=True, stable=True)[1][:, :num_sub]
+                    score = torch.gather(score, 1, index)
+                    xyz, feat, label = _gather_pts(xyz, index), _gather_pts(feat, index), _gather_pts(label, index)
+            sides[s] = (feat, xyz, label, score, index)
+        for s in ("src", "ref"):
+            feat, xyz, label, score, index = sides[s]
+            if pipeline != "label":
+                feat = self.aggregate(xyz, feat, score)
+                ep[f"score_{s}"] = score
+                ep[f"label_{s}"] = label
+                if index is not None:
+                    ep[f"index_{s}"] = index
+            ep[f"pt_{s}"] = xyz
+            ep[f"feat_{s}"] = F.normalize(feat, p=2, dim=1)
+        return ep
+
     # ------------------------------------------------------------------ per-iteration stages
     def aggregate(self, xyz: torch.Tensor, feat0: torch.Tensor, score: torch.Tensor) -> torch.Tensor:
         """One cloud's half of ``aggregation`` (model.py:209-235):

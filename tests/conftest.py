@@ -41,8 +41,8 @@ def build_case(name):
     from oracle.knn import add_pyramids
 
     g, m = load_golden(name)
-    cfg = NetConfig(feat_len=m["feat_len"])
-    sd = generate_state_dict(cfg, m["wseed"], m["variant"])
+    cfg = NetConfig(feat_len=m["feat_len"], pipeline=m.get("pipeline", "align"), num_sub=m.get("num_sub", -1))
+    sd = generate_state_dict(cfg, m["wseed"], m.get("variant", "plain"))
     data = add_pyramids(make_pair(m["n"], m["seed"], m["feat_len"]), cfg.num_knn, cfg.sub_sampling_ratio)
     _CASE_CACHE[name] = (g, m, cfg, sd, data)
     return _CASE_CACHE[name]

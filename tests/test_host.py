@@ -30,7 +30,13 @@ def test_network_module_surface():
     with pytest.raises(RuntimeError):   # strict loading, like nn.Module
         net.load_state_dict({"nope": torch.zeros(1)})
     with pytest.raises(NotImplementedError):
-        Network(_args(pipeline="feat"))
+        Network(_args(num_sub=512))             # align + top-k: not runnable in the reference either (model.py:575)
+    with pytest.raises(AssertionError):
+        Network(_args(pipeline="nope"))         # model.py:131
+    # the other pipelines own fewer sub-networks, hence fewer keys (model.py:135,181)
+    assert len(Network(_args(pipeline="feat", num_sub=256)).state_dict()) == 209
+    assert len(Network(_args(pipeline="label")).state_dict()) == 161
+    assert not any(k.startswith(("mlp_", "inlier_model")) for k in Network(_args(pipeline="label")).state_dict())
 
 
 def test_network_on_cpu_fails_loudly():
