@@ -37,6 +37,28 @@ __device__ __forceinline__ float exp_neg(float x) {
   return fmaf(r * e, 0.693147180559945309f, r);
 }
 
+// Butterfly steps across the four 16-lane rows of a wave with the gfx950 VALU lane swaps instead of ds_bpermute
+// (no LDS round trip, no lgkmcnt wait).  v_permlane16_swap exchanges the odd rows of its first operand with the
+// even rows of the second, v_permlane32_swap the upper half of the first with the lower half of the second; fed
+// the same value twice they return (x of the lower partner, x of the upper partner) in every lane, so
+// op(r0, r1) == op(x, shfl_xor(x, 16 | 32)) bit for bit (op commutative).
+__device__ __forceinline__ float xor16_add(float x) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xor32_add(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xor16_max(float x) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xor32_max(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
 // Attentive pooling of one 16x16 MFMA tile (reference RandLANet.py:152-155): column-wise softmax over
 // the tile's 16 rows (= the 16 neighbours of a point; C layout: col = lane & 15, row = 4*(lane>>4)+reg),
 // then sum_k f[k][c] * a[k][c].  `acc` = scores, `f` = the (normalised) features at the same positions.
@@ -44,8 +66,7 @@ __device__ __forceinline__ float exp_neg(float x) {
 // sum_k f_k e_k / sum_k e_k : one division per column instead of one per element.
 __device__ __forceinline__ float att_pool_tile(const f32x4& acc, const float (&f)[4]) {
   float mx = fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3]));
-  mx = fmaxf(mx, __shfl_xor(mx, 16));
-  mx = fmaxf(mx, __shfl_xor(mx, 32));
+  mx = xor32_max(xor16_max(mx));
   float se = 0.f, o = 0.f;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -53,8 +74,8 @@ __device__ __forceinline__ float att_pool_tile(const f32x4& acc, const float (&f
     se += e;
     o = fmaf(f[r], e, o);
   }
-  se += __shfl_xor(se, 16); se += __shfl_xor(se, 32);
-  o += __shfl_xor(o, 16); o += __shfl_xor(o, 32);
+  se = xor32_add(xor16_add(se));
+  o = xor32_add(xor16_add(o));
   return o / se;
 }
 
