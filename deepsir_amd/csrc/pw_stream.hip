@@ -116,6 +116,13 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const GemmArgs p) {
     __syncthreads();
   }
 
+  // first column of the block's t-th 16-column tile.  EPI_ATT2 (Cout = 2 Cin = 8 KQ, NT = 4): a block owns 32 columns
+  // of the gathered-feature half and the matching 32 of the enc half, so "tile t pools a gathered feature" is the
+  // compile-time condition t < NT/2 for every block
+  auto col0_of = [&](int t) -> int {
+    if (EPI == EPI_ATT2) return t < NT / 2 ? (n0 >> 1) + 16 * t : p.fseg.C + (n0 >> 1) + 16 * (t - NT / 2);
+    return n0 + 16 * t;
+  };
   // lane-constant pieces
   const int c_lo = fq * KQ;                       // first channel of this lane's chunk
   float sc[KQ], sh[KQ];
@@ -125,7 +132,7 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const GemmArgs p) {
   float bv[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    const int col = n0 + 16 * t + fr;
+    const int col = col0_of(t) + fr;
     if ((KQ % 4) == 0 && p.Cin == 4 * KQ) {          // rows of W are 16-byte aligned: vector loads
       if (col < p.Cout) vec_load<KQ>(p.W + (int64_t)col * ldw + c_lo, wf[t]);
       else {
@@ -216,51 +223,51 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const GemmArgs p) {
   // lane), then the D MFMA + epilogue passes.  D shrinks as the per-tile register footprint grows.
   constexpr bool kAtt = (EPI == EPI_ATT || EPI == EPI_ATT2);
   constexpr int D = kAtt ? (NT == 1 ? 4 : 1) : (KQ * NT <= 4 ? 8 : (KQ * NT <= 16 ? 4 : (KQ * NT <= 32 ? 2 : 1)));
-  constexpr int GA = EPI == EPI_ATT2 ? D : 1, GN_ = EPI == EPI_ATT2 ? NT : 1;
+  constexpr int GA = EPI == EPI_ATT2 ? D : 1, GN_ = EPI == EPI_ATT2 ? NT : 1, GF_ = EPI == EPI_ATT2 ? NT / 2 : 1;
   // Two groups are alive at a time (ping-pong): the loads of group g+1 are issued before group g is computed,
   // so index -> row -> use latencies overlap with MFMA / epilogue work even at one wave per SIMD.
   struct Group {
     int srow[D];
     Chunk<KQ> buf[D];
-    float gpre_all[GA][GN_][4], fpre_all[GA][GN_][4];
+    float gpre_all[GA][GN_][4], fpre_all[GA][GF_][4];
     int gi_all[GA][4];
   };
+  // Vector mode issues every load unconditionally on CLAMPED tile / row indices (a group past the end re-reads the
+  // last tile; its results are never used): straight-line code, no exec-mask or scalar branches between the loads,
+  // so the compiler can keep them all in flight and count them precisely.
   auto issue_group = [&](Group& G, int tile0) {
     int (&srow)[D] = G.srow;
     Chunk<KQ> (&buf)[D] = G.buf;
     float (&gpre_all)[GA][GN_][4] = G.gpre_all;
-    float (&fpre_all)[GA][GN_][4] = G.fpre_all;
+    float (&fpre_all)[GA][GF_][4] = G.fpre_all;
     int (&gi_all)[GA][4] = G.gi_all;
 #pragma unroll
     for (int d = 0; d < D; ++d) {
       const int tl = tile0 + d * nwaves;
-      srow[d] = tl < ntiles ? tile_srow(tl) : 0;
+      const int tlc = min(tl, ntiles - 1);
+      srow[d] = (MODE == S_VEC) ? tile_srow(tlc) : (tl < ntiles ? tile_srow(tl) : 0);
       if (EPI == EPI_ATT2) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          gi_all[d][r] = tl < ntiles ? p.fseg.idx[cloud * p.fseg.idx_cloud_stride + tl * 16 + 4 * fq + r] : 0;
+          gi_all[d][r] = p.fseg.idx[cloud * p.fseg.idx_cloud_stride + min(tlc * 16 + 4 * fq + r, p.M - 1)];
       }
     }
 #pragma unroll
     for (int d = 0; d < D; ++d) {
       const int tl = tile0 + d * nwaves;
-      if (tl < ntiles) load_tile(tl, srow[d], buf[d]);
+      if (MODE == S_VEC) load_tile(min(tl, ntiles - 1), srow[d], buf[d]);
+      else if (tl < ntiles) load_tile(tl, srow[d], buf[d]);
       if (EPI == EPI_ATT2) {
-        // the gathered rows of G = W1 f (added to the scores) and of f (pooled operand) for this lane's
-        // 4 rows x NT columns
-        const int ch = p.fseg.C;   // = Cout / 2
+        // the gathered rows of G = W1 f (added to the scores; all NT tiles) and of f (pooled operand; the first
+        // NT/2 tiles) for this lane's 4 rows
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          const int col = n0 + 16 * t + fr;
+        for (int r = 0; r < 4; ++r) {
+          const float* gp = p.g + cloud * p.g_cloud_stride + (int64_t)gi_all[d][r] * p.Cout + fr;
+          const float* fp = p.fseg.x + cloud * p.fseg.cloud_stride + (int64_t)gi_all[d][r] * p.fseg.ld + fr;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int64_t go = cloud * p.g_cloud_stride + (int64_t)gi_all[d][r] * p.Cout;
-            const int64_t fo = cloud * p.fseg.cloud_stride + (int64_t)gi_all[d][r] * p.fseg.ld;
-            // EPI_ATT2 launches have Cout == 2 Cin == 8 KQ, a multiple of the 16-column tiles: every column is
-            // valid, and "column in the gathered half" is uniform per (block, t) — scalar conditions only
-            gpre_all[d][t][r] = (tl < ntiles) ? p.g[go + col] : 0.f;
-            fpre_all[d][t][r] = (tl < ntiles && n0 + 16 * t < ch) ? p.fseg.x[fo + col] : 0.f;
-          }
+          for (int t = 0; t < NT; ++t) gpre_all[d][t][r] = gp[col0_of(t)];
+#pragma unroll
+          for (int t = 0; t < NT / 2; ++t) fpre_all[d][t][r] = fp[col0_of(t)];
         }
       }
     }
@@ -273,7 +280,7 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const GemmArgs p) {
     Chunk<KQ>& cur = G.buf[d];
     finish_tile(tile, cur);
     float (&gpre)[GN_][4] = G.gpre_all[EPI == EPI_ATT2 ? d : 0];
-    float (&fpre)[GN_][4] = G.fpre_all[EPI == EPI_ATT2 ? d : 0];
+    float (&fpre)[GF_][4] = G.fpre_all[EPI == EPI_ATT2 ? d : 0];
     const int rbase = tile * 16 + 4 * fq;   // C layout: col = lane & 15, row = 4 * (lane >> 4) + reg
 
     f32x4 acc[NT];
@@ -365,7 +372,7 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const GemmArgs p) {
       __builtin_amdgcn_wave_barrier();
     } else if (EPI == EPI_ATT2) {
       // split attentive pooling: scores = acc (enc half of the contraction) + gathered G rows;
-      // pooled operand = [gathered f (first Cout/2 columns) ; enc (last Cout/2, from the A fragments via LDS)]
+      // pooled operand = [gathered f (tiles t < NT/2) ; enc (tiles t >= NT/2, from the A fragments via LDS)]
       float* Y = p.Y + cloud * p.y_cloud_stride;
       float* T = &s_att[w * 16 * (CP + 4)];
       const int ch = p.fseg.C;
@@ -373,24 +380,28 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const GemmArgs p) {
 #pragma unroll
       for (int j = 0; j < KQ; ++j) T[fr * (CP + 4) + c_lo + j] = cur.v[j];
       __builtin_amdgcn_wave_barrier();
+      float o[NT];
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        const int col = n0 + 16 * t + fr;
+        const int col = col0_of(t) + fr;
         float f[4];
         f32x4 sc4 = acc[t];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           sc4[r] += gpre[t][r];
-          if (n0 + 16 * t < ch) {   // uniform per (block, t): ch is a multiple of 16 here
-            const float v = fmaf(fpre[t][r], s_fsc[col], s_fsh[col]);
+          if (t < NT / 2) {
+            const float v = fmaf(fpre[t < NT / 2 ? t : 0][r], s_fsc[col], s_fsh[col]);
             f[r] = (fact && v < 0.f) ? 0.2f * v : v;
           } else {
             f[r] = T[(4 * fq + r) * (CP + 4) + (col - ch)];
           }
         }
-        const float o = att_pool_tile(sc4, f);
-        if (lane < 16 && col < p.Cout) Y[(int64_t)tile * p.ldy + col] = o;
+        o[t] = att_pool_tile(sc4, f);
       }
+      // every lane holds its column's result for all NT tiles: lane group fq stores tile fq -> one full-wave store
+      static_assert(EPI != EPI_ATT2 || NT == 4, "EPI_ATT2 stores one tile per 16-lane group");
+      const float ov = fq == 0 ? o[0] : (fq == 1 ? o[1 % NT] : (fq == 2 ? o[2 % NT] : o[3 % NT]));
+      Y[(int64_t)tile * p.ldy + col0_of(fq) + fr] = ov;
       __builtin_amdgcn_wave_barrier();
     }
     }  // tile < ntiles
