@@ -163,6 +163,32 @@ __global__ __launch_bounds__(256) void pw_tile_kernel(const GemmArgs p) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[rt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // EPI_ATT2: the epilogue's gathered operands (rows of G = W1 f and of f, or the enc rows themselves) are
+  // independent of the contraction: their index loads and the dependent row gathers are issued BEFORE the K loop
+  // and land while it runs, instead of forming an exposed index -> row -> use chain after it.
+  constexpr int PR = EPI == EPI_ATT2 ? RT : 1, PT = EPI == EPI_ATT2 ? NT : 1;
+  float gpre[PR][PT][4], fpre[PR][PT][4];
+  const bool gath = EPI == EPI_ATT2 && n0 < p.fseg.C;    // block-uniform: this block pools gathered f (else enc)
+  if (EPI == EPI_ATT2) {
+    const int ch = p.fseg.C;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = min(m0 + 16 * RT * w + 16 * rt + 4 * fq + r, p.M - 1);
+        const int gi = p.fseg.idx[cloud * p.fseg.idx_cloud_stride + row];
+        const float* gp = p.g + cloud * p.g_cloud_stride + (int64_t)gi * p.Cout + n0 + fr;
+        const float* fp = gath ? p.fseg.x + cloud * p.fseg.cloud_stride + (int64_t)gi * p.fseg.ld + n0 + fr
+                               : p.seg[0].x + row_off(p, cloud, row).o0 + (n0 - ch) + fr;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          gpre[rt][t][r] = gp[16 * t];
+          fpre[rt][t][r] = fp[16 * t];
+        }
+      }
+    }
+  }
+
   const int nchunks = p.Cin / BK;
   gload(0);
   lstore(0, 0);
@@ -292,44 +318,32 @@ __global__ __launch_bounds__(256) void pw_tile_kernel(const GemmArgs p) {
     }
   } else if (EPI == EPI_ATT2) {
     // split attentive pooling (kernels.h): scores = acc (enc half) + gathered G rows; pooled operand =
-    // [gathered f (columns < Cout/2) ; enc (columns >= Cout/2)], both re-read from L2 with their GroupNorm applied
+    // [gathered f (column blocks < Cout/2) ; enc (column blocks >= Cout/2)], prefetched above, GroupNorm applied here
     float* Y = p.Y + cloud * p.y_cloud_stride;
     const int ch = p.fseg.C;
-    const int fact = p.fseg.act;
+    const int pact = gath ? p.fseg.act : act0;
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
       const int trow = r0 + 16 * rt;
       if (trow >= p.M) continue;
-      int64_t go[4], fo[4], eo[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = trow + 4 * fq + r;
-        const int gi = p.fseg.idx[cloud * p.fseg.idx_cloud_stride + row];
-        go[r] = cloud * p.g_cloud_stride + (int64_t)gi * p.Cout;
-        fo[r] = cloud * p.fseg.cloud_stride + (int64_t)gi * p.fseg.ld;
-        eo[r] = row_off(p, cloud, row).o0;
-      }
+      float o[NT];
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const int col = n0 + 16 * t + fr;
+        const float scv = gath ? s_fsc[col] : s_sc[col - ch], shv = gath ? s_fsh[col] : s_sh[col - ch];
         f32x4 sc4 = acc[rt][t];
         float f[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          // EPI_ATT2: Cout == 2 Cin is a multiple of 64, so every column is valid and "gathered half or enc
-          // half" is uniform per (block, t): scalar branches only
-          sc4[r] += p.g[go[r] + col];
-          if (n0 + 16 * t < ch) {
-            const float v = fmaf(p.fseg.x[fo[r] + col], s_fsc[col], s_fsh[col]);
-            f[r] = (fact && v < 0.f) ? 0.2f * v : v;
-          } else {
-            const float v = fmaf(p.seg[0].x[eo[r] + (col - ch)], s_sc[col - ch], s_sh[col - ch]);
-            f[r] = (act0 && v < 0.f) ? 0.2f * v : v;
-          }
+          sc4[r] += gpre[rt][t][r];
+          const float v = fmaf(fpre[rt][t][r], scv, shv);
+          f[r] = (pact && v < 0.f) ? 0.2f * v : v;
         }
-        const float o = att_pool_tile(sc4, f);
-        if (lane < 16 && col < p.Cout) Y[(int64_t)(trow >> 4) * p.ldy + col] = o;
+        o[t] = att_pool_tile(sc4, f);
       }
+      // every lane holds its column's pooled value for all four tiles: lane group fq stores tile fq (one store)
+      const float ov = fq == 0 ? o[0] : (fq == 1 ? o[1] : (fq == 2 ? o[2] : o[3]));
+      Y[(int64_t)(trow >> 4) * p.ldy + n0 + lane] = ov;
     }
   }
 }
