@@ -513,6 +513,17 @@ void run_att_proj(dsir_ctx* c, const float* xyz, int64_t xyz_cs, const float* sc
                   float* desc) {
   Sched s{c, c->stream, clouds};
   const NetW& w = c->net;
+  static const bool no_agg = getenv("DSIR_NO_AGG") != nullptr;   // A/B switch
+  const LinW* m = w.mlp_att;
+  if (!no_agg && m[0].cin == 4 && m[0].cout == 32 && m[1].cout == 64 && m[2].cout == 128 && m[3].cout == 256 &&
+      m[4].cout == 64 && w.mlp_proj.cin == 64 && w.mlp_proj.cout == 64) {
+    AggArgs a;
+    a.xyz = xyz; a.xyz_cs = xyz_cs; a.score = score; a.F = F;
+    a.W1 = m[0].W; a.b1 = m[0].b; a.W2 = m[1].W; a.b2 = m[1].b; a.W3 = m[2].W; a.b3 = m[2].b;
+    a.W4 = m[3].W; a.b4 = m[3].b; a.W5 = m[4].W; a.b5 = m[4].b; a.W6 = w.mlp_proj.W; a.b6 = w.mlp_proj.b;
+    a.desc = desc; a.n = n; a.clouds = clouds;
+    if (launch_agg_chain(a, c->stream)) return;
+  }
   const Seg sx = plain_seg(xyz, xyz_cs, 3, 3);
   const Seg ss = plain_seg(score, n, 1, 1);
   Act h = s.linear(w.mlp_att[0], sx, &ss, n, EPI_ACT);

@@ -89,6 +89,22 @@ struct HeadArgs {
 };
 bool launch_head_mlp(const HeadArgs& a, hipStream_t st);   // false => shape outside the fused envelope
 
+// agg_chain.hip — mlp_att chain + residual + mlp_proj + L2 normalise in one launch (model.py:223-233)
+struct AggArgs {
+  const float* xyz = nullptr; int64_t xyz_cs = 0;   // [clouds][n][3], cloud stride in floats
+  const float* score = nullptr;                     // [clouds][n]
+  const float* F = nullptr;                         // [clouds][n][64] = mlp_feat(feat0)
+  const float *W1 = nullptr, *b1 = nullptr;         // mlp_att, BN folded: [32][4]
+  const float *W2 = nullptr, *b2 = nullptr;         // [64][32]
+  const float *W3 = nullptr, *b3 = nullptr;         // [128][64]
+  const float *W4 = nullptr, *b4 = nullptr;         // [256][128]
+  const float *W5 = nullptr, *b5 = nullptr;         // [64][256]
+  const float *W6 = nullptr, *b6 = nullptr;         // mlp_proj [64][64]
+  float* desc = nullptr;                            // [clouds][n][64]
+  int n = 0, clouds = 0;
+};
+bool launch_agg_chain(const AggArgs& a, hipStream_t st);
+
 // select.hip — feat / label pipelines (model.py:650-651, :682-697)
 size_t topk_scratch_bytes(int clouds, int n);
 // idx_out [clouds][k] = the k highest scores of every cloud, descending, ties in ascending index; score_out optional
