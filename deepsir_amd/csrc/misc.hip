@@ -18,7 +18,10 @@ __device__ __forceinline__ void gn_scale_shift(const GnRef& g, int cloud, int c,
   shift = (float)((double)g.beta[c] - mean * sc);
 }
 
-// y = LeakyReLU(GN(a) + GN(b)) ; one thread per element, channels fastest (coalesced).
+__device__ __forceinline__ float lrelu(float v) { return v < 0.f ? 0.2f * v : v; }
+
+// y = LeakyReLU(GN(a) + GN(b)) ; one thread per 4 channels (16-byte accesses), channels fastest (coalesced).
+// C is a multiple of 4 (32..512) and every tensor base is 16-byte aligned (arena allocations).
 __global__ __launch_bounds__(256) void residual_combine_kernel(const float* __restrict__ a, GnRef ga,
                                                                const float* __restrict__ b, GnRef gb, int C, int rows,
                                                                float* __restrict__ y) {
@@ -29,12 +32,20 @@ __global__ __launch_bounds__(256) void residual_combine_kernel(const float* __re
     gn_scale_shift(gb, cloud, c, C, sb[c], hb[c]);
   }
   __syncthreads();
-  const int64_t total = (int64_t)rows * C;
-  const int64_t base = (int64_t)cloud * total;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-    const int c = (int)(e % C);
-    const float v = fmaf(a[base + e], sa[c], ha[c]) + fmaf(b[base + e], sb[c], hb[c]);
-    y[base + e] = v < 0.f ? 0.2f * v : v;
+  const int C4 = C >> 2;
+  const int64_t total4 = (int64_t)rows * C4;
+  const float4* a4 = reinterpret_cast<const float4*>(a + (int64_t)cloud * rows * C);
+  const float4* b4 = reinterpret_cast<const float4*>(b + (int64_t)cloud * rows * C);
+  float4* y4 = reinterpret_cast<float4*>(y + (int64_t)cloud * rows * C);
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total4; e += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(e % C4) * 4;
+    const float4 x = a4[e], z = b4[e];
+    float4 r;
+    r.x = lrelu(fmaf(x.x, sa[c], ha[c]) + fmaf(z.x, sb[c], hb[c]));
+    r.y = lrelu(fmaf(x.y, sa[c + 1], ha[c + 1]) + fmaf(z.y, sb[c + 1], hb[c + 1]));
+    r.z = lrelu(fmaf(x.z, sa[c + 2], ha[c + 2]) + fmaf(z.z, sb[c + 2], hb[c + 2]));
+    r.w = lrelu(fmaf(x.w, sa[c + 3], ha[c + 3]) + fmaf(z.w, sb[c + 3], hb[c + 3]));
+    y4[e] = r;
   }
 }
 
@@ -43,14 +54,20 @@ __global__ __launch_bounds__(256) void gather_max_kernel(const float* __restrict
                                                          const int32_t* __restrict__ idx, int64_t idx_cs, int C,
                                                          int rows_out, float* __restrict__ out) {
   const int cloud = blockIdx.y;
-  const int64_t total = (int64_t)rows_out * C;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-    const int i = (int)(e / C), c = (int)(e % C);
+  const int C4 = C >> 2;
+  const int64_t total4 = (int64_t)rows_out * C4;
+  const float* src = in + cloud * in_cs;
+  float4* o4 = reinterpret_cast<float4*>(out + (int64_t)cloud * rows_out * C);
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total4; e += (int64_t)gridDim.x * blockDim.x) {
+    const int i = (int)(e / C4), c = (int)(e % C4) * 4;
     const int32_t* nb = idx + cloud * idx_cs + (int64_t)i * kKnn;
-    float m = -INFINITY;
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
 #pragma unroll
-    for (int k = 0; k < kKnn; ++k) m = fmaxf(m, in[cloud * in_cs + (int64_t)nb[k] * C + c]);
-    out[(int64_t)cloud * total + e] = m;
+    for (int k = 0; k < kKnn; ++k) {
+      const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)nb[k] * C + c);
+      m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+    }
+    o4[e] = m;
   }
 }
 
@@ -67,20 +84,27 @@ __global__ __launch_bounds__(256) void gather_max_combine_kernel(const float* __
     gn_scale_shift(gb, cloud, c, C, sb[c], hb[c]);
   }
   __syncthreads();
-  const int64_t in_base = (int64_t)cloud * rows_in * C;
-  const int64_t total = (int64_t)rows_out * C;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-    const int i = (int)(e / C), c = (int)(e % C);
+  const int C4 = C >> 2;
+  const int64_t total4 = (int64_t)rows_out * C4;
+  const float* pa = a + (int64_t)cloud * rows_in * C;
+  const float* pb = b + (int64_t)cloud * rows_in * C;
+  float4* o4 = reinterpret_cast<float4*>(out + (int64_t)cloud * rows_out * C);
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total4; e += (int64_t)gridDim.x * blockDim.x) {
+    const int i = (int)(e / C4), c = (int)(e % C4) * 4;
     const int32_t* nb = idx + cloud * idx_cs + (int64_t)i * kKnn;
-    const float s1 = sa[c], h1 = ha[c], s2 = sb[c], h2 = hb[c];
-    float m = -INFINITY;
+    const float4 s1 = *reinterpret_cast<const float4*>(&sa[c]), h1 = *reinterpret_cast<const float4*>(&ha[c]);
+    const float4 s2 = *reinterpret_cast<const float4*>(&sb[c]), h2 = *reinterpret_cast<const float4*>(&hb[c]);
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
 #pragma unroll
     for (int k = 0; k < kKnn; ++k) {
-      const int64_t o = in_base + (int64_t)nb[k] * C + c;
-      const float v = fmaf(a[o], s1, h1) + fmaf(b[o], s2, h2);
-      m = fmaxf(m, v < 0.f ? 0.2f * v : v);
+      const int64_t o = (int64_t)nb[k] * C + c;
+      const float4 x = *reinterpret_cast<const float4*>(pa + o), z = *reinterpret_cast<const float4*>(pb + o);
+      m.x = fmaxf(m.x, lrelu(fmaf(x.x, s1.x, h1.x) + fmaf(z.x, s2.x, h2.x)));
+      m.y = fmaxf(m.y, lrelu(fmaf(x.y, s1.y, h1.y) + fmaf(z.y, s2.y, h2.y)));
+      m.z = fmaxf(m.z, lrelu(fmaf(x.z, s1.z, h1.z) + fmaf(z.z, s2.z, h2.z)));
+      m.w = fmaxf(m.w, lrelu(fmaf(x.w, s1.w, h1.w) + fmaf(z.w, s2.w, h2.w)));
     }
-    out[(int64_t)cloud * total + e] = m;
+    o4[e] = m;
   }
 }
 
@@ -112,21 +136,21 @@ inline int grid_for(int64_t total, int block = 256, int cap = 2048) {
 
 void launch_residual_combine(const float* a, GnRef ga, const float* b, GnRef gb, int C, int rows, int clouds, float* y,
                              hipStream_t st) {
-  dim3 grid(grid_for((int64_t)rows * C), clouds);
+  dim3 grid(grid_for((int64_t)rows * C / 4), clouds);
   hipLaunchKernelGGL(residual_combine_kernel, grid, dim3(256), 0, st, a, ga, b, gb, C, rows, y);
 }
 
 void launch_gather_max(const float* in, int64_t in_cs, const int32_t* idx, int64_t idx_cs, int C, int rows_out,
                        int clouds, float* out, hipStream_t st) {
   if (rows_out <= 0) return;
-  dim3 grid(grid_for((int64_t)rows_out * C), clouds);
+  dim3 grid(grid_for((int64_t)rows_out * C / 4), clouds);
   hipLaunchKernelGGL(gather_max_kernel, grid, dim3(256), 0, st, in, in_cs, idx, idx_cs, C, rows_out, out);
 }
 
 void launch_gather_max_combine(const float* a, GnRef ga, const float* b, GnRef gb, int rows_in, const int32_t* idx,
                                int64_t idx_cs, int C, int rows_out, int clouds, float* out, hipStream_t st) {
   if (rows_out <= 0) return;
-  dim3 grid(grid_for((int64_t)rows_out * C), clouds);
+  dim3 grid(grid_for((int64_t)rows_out * C / 4), clouds);
   hipLaunchKernelGGL(gather_max_combine_kernel, grid, dim3(256), 0, st, a, ga, b, gb, rows_in, idx, idx_cs, C, rows_out, out);
 }
 
