@@ -7,6 +7,19 @@ namespace dsir {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Wave-uniform base + 32-bit per-lane BYTE offset: compiles to the SGPR-base addressing mode
+// (global_load_dword v, v_off, s[base:base+1]) — one 32-bit multiply-add per address instead of a 64-bit
+// multiply-add chain.  Every per-cloud tensor of the engine is far below 4 GiB.
+__device__ __forceinline__ float ld_f32(const float* base, uint32_t byte_off) {
+  return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ __forceinline__ int ld_i32(const int32_t* base, uint32_t byte_off) {
+  return *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ __forceinline__ void st_f32(float* base, uint32_t byte_off, float v) {
+  *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byte_off) = v;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

@@ -154,6 +154,10 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const GemmArgs p) {
   const Seg& myseg = in_seg1 ? p.seg[1] : p.seg[0];
   const int seg_c = in_seg1 ? c_lo - C0 : c_lo;
   const int my_act = myseg.act;
+  const float* mybase = myseg.x + cloud * myseg.cloud_stride + seg_c;                     // per lane (segment of its chunk)
+  const int32_t* myidx = myseg.idx ? myseg.idx + cloud * myseg.idx_cloud_stride : nullptr;
+  const uint32_t my_ld = (uint32_t)myseg.ld;
+  const int my_div = myseg.row_div;
 
   const int ntiles = (p.M + 15) >> 4;
   const int wave0 = blockIdx.x * 4 + w, nwaves = gridDim.x * 4;
@@ -163,7 +167,8 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const GemmArgs p) {
   // never stored nor counted, and unconditional loads keep the exec mask (and the branch count) out of the loop.
   auto tile_srow = [&](int tile) -> int {
     if (MODE != S_VEC) return 0;
-    return src_row(myseg, cloud, min(tile * 16 + fr, p.M - 1));
+    const int row = min(tile * 16 + fr, p.M - 1);
+    return myidx ? myidx[row] : row / my_div;
   };
   auto finish_tile = [&](int tile, Chunk<KQ>& ch) {
     if (MODE != S_VEC) return;
@@ -177,7 +182,7 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const GemmArgs p) {
     const int row = tile * 16 + fr;
     const bool ok = row < p.M;
     if (MODE == S_VEC) {
-      const float* src = myseg.x + cloud * myseg.cloud_stride + (int64_t)srow * myseg.ld + seg_c;
+      const float* src = mybase + (uint32_t)srow * my_ld;      // 32-bit row offset: per-cloud tensors are < 4 GiB
       vec_load<KQ>(src, ch.v);          // raw values; normalised by finish_tile() after the MFMA burst
     } else if (MODE == S_ELEM) {
 #pragma unroll
@@ -249,7 +254,7 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const GemmArgs p) {
       if (EPI == EPI_ATT2) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          gi_all[d][r] = p.fseg.idx[cloud * p.fseg.idx_cloud_stride + min(tlc * 16 + 4 * fq + r, p.M - 1)];
+          gi_all[d][r] = ld_i32(p.fseg.idx + cloud * p.fseg.idx_cloud_stride, 4u * (uint32_t)min(tlc * 16 + 4 * fq + r, p.M - 1));
       }
     }
 #pragma unroll
@@ -262,12 +267,14 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const GemmArgs p) {
         // NT/2 tiles) for this lane's 4 rows
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float* gp = p.g + cloud * p.g_cloud_stride + (int64_t)gi_all[d][r] * p.Cout + fr;
-          const float* fp = p.fseg.x + cloud * p.fseg.cloud_stride + (int64_t)gi_all[d][r] * p.fseg.ld + fr;
+          const float* gp = p.g + cloud * p.g_cloud_stride;                 // wave-uniform bases
+          const float* fp = p.fseg.x + cloud * p.fseg.cloud_stride;
+          const uint32_t go = 4u * ((uint32_t)gi_all[d][r] * (uint32_t)p.Cout + (uint32_t)fr);
+          const uint32_t fo = 4u * ((uint32_t)gi_all[d][r] * (uint32_t)p.fseg.ld + (uint32_t)fr);
 #pragma unroll
-          for (int t = 0; t < NT; ++t) gpre_all[d][t][r] = gp[col0_of(t)];
+          for (int t = 0; t < NT; ++t) gpre_all[d][t][r] = ld_f32(gp + col0_of(t), go);
 #pragma unroll
-          for (int t = 0; t < NT / 2; ++t) fpre_all[d][t][r] = fp[col0_of(t)];
+          for (int t = 0; t < NT / 2; ++t) fpre_all[d][t][r] = ld_f32(fp + col0_of(t), fo);
         }
       }
     }
@@ -301,7 +308,7 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const GemmArgs p) {
           const int row = rbase + r;
           if (row < p.M && col < p.Cout) {
             const float v = acc[t][r] + bv[t];
-            Y[(int64_t)row * p.ldy + col] = v;
+            st_f32(Y, 4u * ((uint32_t)row * (uint32_t)p.ldy + (uint32_t)col), v);
             g1[t] += v;
             g2[t] += v * v;
           }
@@ -317,9 +324,9 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const GemmArgs p) {
           const int row = rbase + r;
           if (row < p.M && col < p.Cout) {
             float v = acc[t][r] + bv[t];
-            if (EPI == EPI_LINEAR && p.residual) v += p.residual[cloud * p.res_cloud_stride + (int64_t)row * p.ldres + col];
+            if (EPI == EPI_LINEAR && p.residual) v += ld_f32(p.residual + cloud * p.res_cloud_stride, 4u * ((uint32_t)row * (uint32_t)p.ldres + (uint32_t)col));
             if (EPI == EPI_ACT && v < 0.f) v *= 0.2f;
-            Y[(int64_t)row * p.ldy + col] = v;
+            st_f32(Y, 4u * ((uint32_t)row * (uint32_t)p.ldy + (uint32_t)col), v);
           }
         }
       }
@@ -346,7 +353,7 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const GemmArgs p) {
 #pragma unroll
           for (int t = 0; t < NT; ++t) {
             const int col = n0 + 16 * t + fr;
-            if (col < p.Cout) Y[(int64_t)row * p.ldy + col] = v[t][r] / den;
+            if (col < p.Cout) st_f32(Y, 4u * ((uint32_t)row * (uint32_t)p.ldy + (uint32_t)col), v[t][r] / den);
           }
         }
       }
@@ -367,7 +374,7 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const GemmArgs p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) f[r] = T[(4 * fq + r) * (CP + 4) + col];
         const float o = att_pool_tile(acc[t], f);
-        if (lane < 16 && col < p.Cout) Y[(int64_t)tile * p.ldy + col] = o;
+        if (lane < 16 && col < p.Cout) st_f32(Y, 4u * ((uint32_t)tile * (uint32_t)p.ldy + (uint32_t)col), o);
       }
       __builtin_amdgcn_wave_barrier();
     } else if (EPI == EPI_ATT2) {
@@ -401,7 +408,7 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const GemmArgs p) {
       // every lane holds its column's result for all NT tiles: lane group fq stores tile fq -> one full-wave store
       static_assert(EPI != EPI_ATT2 || NT == 4, "EPI_ATT2 stores one tile per 16-lane group");
       const float ov = fq == 0 ? o[0] : (fq == 1 ? o[1 % NT] : (fq == 2 ? o[2 % NT] : o[3 % NT]));
-      Y[(int64_t)tile * p.ldy + col0_of(fq) + fr] = ov;
+      st_f32(Y, 4u * ((uint32_t)tile * (uint32_t)p.ldy + (uint32_t)(col0_of(fq) + fr)), ov);
       __builtin_amdgcn_wave_barrier();
     }
     }  // tile < ntiles
