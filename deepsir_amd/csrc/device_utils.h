@@ -36,18 +36,12 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-// exp(x) for x <= 0 (softmax numerators, x = score - max) in ~6 instructions at ~2 ulp:
-// exp(x) = 2^(x*log2e); the product is split into its rounded value t and its exact
-// rounding error e (two fmas, log2e in hi+lo parts), then 2^(t+e) = exp2(t) * (1 + e ln2)
-// with the hardware v_exp_f32 (1 ulp).  Results below 2^-126 flush towards 0: such terms
-// are < 1e-38 of a softmax denominator that is >= 1.
+// exp(x) for x <= 0 (softmax numerators, x = score - max): 2^(x*log2e) with the hardware v_exp_f32 (1 ulp).
+// The rounding of the product x*log2e adds a relative error of at most |x| * 6e-8 — below the noise the scores
+// themselves carry (an fp32 GEMM over 32..256 channels), and only on terms that are already e^x of the
+// denominator.  Two instructions per element instead of six.
 __device__ __forceinline__ float exp_neg(float x) {
-  const float kL2eHi = 1.44269502162933349609375f, kL2eLo = 1.925963033500011e-8f;
-  const float t = x * kL2eHi;
-  float e = fmaf(x, kL2eHi, -t);
-  e = fmaf(x, kL2eLo, e);
-  const float r = __builtin_amdgcn_exp2f(t);
-  return fmaf(r * e, 0.693147180559945309f, r);
+  return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f);
 }
 
 // Butterfly steps across the four 16-lane rows of a wave with the gfx950 VALU lane swaps instead of ds_bpermute
@@ -89,7 +83,7 @@ __device__ __forceinline__ float att_pool_tile(const f32x4& acc, const float (&f
   }
   se = xor32_add(xor16_add(se));
   o = xor32_add(xor16_add(o));
-  return o / se;
+  return o * __builtin_amdgcn_rcpf(se);   // se >= 1 (the max term contributes e^0): v_rcp_f32 is 1 ulp there
 }
 
 // Order-preserving float max through integer atomics (target initialised to -inf).

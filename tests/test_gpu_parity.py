@@ -55,10 +55,13 @@ def rot_angle(Ra, Rb):
 
 def assert_pose_close(T, Tref, tol_rad=1e-4, tol_m=1e-4, msg=""):
     T, Tref = np.asarray(T), np.asarray(Tref)
+    worst_a = worst_d = 0.0
     for t, r in zip(T.reshape(-1, 3, 4), Tref.reshape(-1, 3, 4)):
         a = rot_angle(t[:, :3], r[:, :3])
         d = float(np.linalg.norm(t[:, 3].astype(np.float64) - r[:, 3].astype(np.float64)))
+        worst_a, worst_d = max(worst_a, a), max(worst_d, d)
         assert a < tol_rad and d < tol_m, f"{msg} rot diff {a:.3e} rad, trans diff {d:.3e} m"
+    print(f"[pose] {msg}: worst rot diff {worst_a:.2e} rad, worst trans diff {worst_d:.2e} m (tol {tol_rad:g}/{tol_m:g})")
 
 
 # --------------------------------------------------------------------------- KNN pyramid (bit-exact)
