@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const GemmArgs p) {
   const bool in_seg1 = (MODE == S_VEC) && (p.nseg > 1) && (c_lo >= C0);
   const Seg& myseg = in_seg1 ? p.seg[1] : p.seg[0];
   const int seg_c = in_seg1 ? c_lo - C0 : c_lo;
-  const int my_act = myseg.act;
+  const float my_slope = myseg.act ? 0.2f : 1.f;   // LeakyReLU(v) = max(v, slope * v); slope 1 = identity
   const float* mybase = myseg.x + cloud * myseg.cloud_stride + seg_c;                     // per lane (segment of its chunk)
   const int32_t* myidx = myseg.idx ? myseg.idx + cloud * myseg.idx_cloud_stride : nullptr;
   const uint32_t my_ld = (uint32_t)myseg.ld;
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const GemmArgs p) {
 #pragma unroll
     for (int j = 0; j < KQ; ++j) {
       const float v = fmaf(ch.v[j], sc[j], sh[j]);
-      ch.v[j] = (my_act && v < 0.f) ? 0.2f * v : v;
+      ch.v[j] = fmaxf(v, my_slope * v);
     }
   };
   auto load_tile = [&](int tile, int srow, Chunk<KQ>& ch) {
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const GemmArgs p) {
       float* Y = p.Y + cloud * p.y_cloud_stride;
       float* T = &s_att[w * 16 * (CP + 4)];
       const int ch = p.fseg.C;
-      const int fact = p.fseg.act;
+      const float fslope = p.fseg.act ? 0.2f : 1.f;
 #pragma unroll
       for (int j = 0; j < KQ; ++j) T[fr * (CP + 4) + c_lo + j] = cur.v[j];
       __builtin_amdgcn_wave_barrier();
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const GemmArgs p) {
           sc4[r] += gpre[t][r];
           if (t < NT / 2) {
             const float v = fmaf(fpre[t < NT / 2 ? t : 0][r], s_fsc[col], s_fsh[col]);
-            f[r] = (fact && v < 0.f) ? 0.2f * v : v;
+            f[r] = fmaxf(v, fslope * v);
           } else {
             f[r] = T[(4 * fq + r) * (CP + 4) + (col - ch)];
           }

@@ -134,17 +134,15 @@ __global__ __launch_bounds__(256) void pw_tile_kernel(const GemmArgs p) {
   };
   auto lstore = [&](int k0, int buf) {
     const int c = k0 + c4;
-    const int act = (c >= C0) ? act1 : act0;
+    const float slope = ((c >= C0) ? act1 : act0) ? 0.2f : 1.f;   // LeakyReLU(v) = max(v, slope * v); slope 1 = identity
     const float4 sc = *reinterpret_cast<const float4*>(&s_sc[c]);
     const float4 sh = *reinterpret_cast<const float4*>(&s_sh[c]);
 #pragma unroll
     for (int i = 0; i < AV; ++i) {
       float4 v = ra[i];
       v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y); v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
-      if (act) {
-        v.x = v.x < 0.f ? 0.2f * v.x : v.x; v.y = v.y < 0.f ? 0.2f * v.y : v.y;
-        v.z = v.z < 0.f ? 0.2f * v.z : v.z; v.w = v.w < 0.f ? 0.2f * v.w : v.w;
-      }
+      v.x = fmaxf(v.x, slope * v.x); v.y = fmaxf(v.y, slope * v.y);
+      v.z = fmaxf(v.z, slope * v.z); v.w = fmaxf(v.w, slope * v.w);
       float2* d = reinterpret_cast<float2*>(&As[buf][(sr0 + 32 * i) * LDS_LD + c4]);
       d[0] = make_float2(v.x, v.y);
       d[1] = make_float2(v.z, v.w);
@@ -321,7 +319,7 @@ __global__ __launch_bounds__(256) void pw_tile_kernel(const GemmArgs p) {
     // [gathered f (column blocks < Cout/2) ; enc (column blocks >= Cout/2)], prefetched above, GroupNorm applied here
     float* Y = p.Y + cloud * p.y_cloud_stride;
     const int ch = p.fseg.C;
-    const int pact = gath ? p.fseg.act : act0;
+    const float pslope = (gath ? p.fseg.act : act0) ? 0.2f : 1.f;
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
       const int trow = r0 + 16 * rt;
@@ -337,7 +335,7 @@ __global__ __launch_bounds__(256) void pw_tile_kernel(const GemmArgs p) {
         for (int r = 0; r < 4; ++r) {
           sc4[r] += gpre[rt][t][r];
           const float v = fmaf(fpre[rt][t][r], scv, shv);
-          f[r] = (pact && v < 0.f) ? 0.2f * v : v;
+          f[r] = fmaxf(v, pslope * v);
         }
         o[t] = att_pool_tile(sc4, f);
       }
