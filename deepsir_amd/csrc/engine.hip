@@ -307,10 +307,10 @@ struct Sched {
     c->stats_top += (size_t)clouds * groups * 2;
     return p;
   }
-  static Seg seg_of(const Act& a, const int32_t* idx = nullptr, int64_t idx_cs = 0, int row_div = 1) {
+  static Seg seg_of(const Act& a, const int32_t* idx = nullptr, int64_t idx_cs = 0) {
     Seg s{};
     s.x = a.p; s.cloud_stride = (int64_t)a.rows * a.C; s.C = a.C; s.ld = a.C;
-    s.idx = idx; s.idx_cloud_stride = idx_cs; s.row_div = row_div; s.gn = a.gn; s.act = a.act;
+    s.idx = idx; s.idx_cloud_stride = idx_cs; s.gn = a.gn; s.act = a.act;
     return s;
   }
   // MLP2D: conv1x1 + GroupNorm (lazy) [+ LeakyReLU (lazy)]
@@ -392,7 +392,7 @@ struct Sched {
 
 Seg plain_seg(const float* x, int64_t cloud_stride, int C, int ld, const int32_t* idx = nullptr, int64_t idx_cs = 0) {
   Seg s{};
-  s.x = x; s.cloud_stride = cloud_stride; s.C = C; s.ld = ld; s.idx = idx; s.idx_cloud_stride = idx_cs; s.row_div = 1;
+  s.x = x; s.cloud_stride = cloud_stride; s.C = C; s.ld = ld; s.idx = idx; s.idx_cloud_stride = idx_cs;
   s.gn = GnRef{nullptr, nullptr, nullptr, 0, 0.0}; s.act = 0;
   return s;
 }

@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void head_mlp_kernel(const HeadArgs p) {
 
 bool launch_head_mlp(const HeadArgs& a, hipStream_t st) {
   if (a.M <= 0 || a.clouds <= 0) return true;
-  if (a.in.C != 32 || (a.in.ld % 4) != 0 || (a.in.cloud_stride % 4) != 0 || a.in.idx || a.in.row_div != 1) return false;
+  if (a.in.C != 32 || (a.in.ld % 4) != 0 || (a.in.cloud_stride % 4) != 0 || a.in.idx) return false;
   if (a.ncls < 1 || a.ncls > 32 || !a.logits_out) return false;
   if ((reinterpret_cast<uintptr_t>(a.in.x) | reinterpret_cast<uintptr_t>(a.W1) | reinterpret_cast<uintptr_t>(a.W2) |
        reinterpret_cast<uintptr_t>(a.W3) | reinterpret_cast<uintptr_t>(a.W4)) % 16) return false;

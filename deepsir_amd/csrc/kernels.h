@@ -25,7 +25,7 @@ struct Seg {
   int ld;                // row stride in floats
   const int32_t* idx;    // optional row gather index [clouds][M]
   int64_t idx_cloud_stride;
-  int row_div;           // source row = idx ? idx[r] : r / row_div
+                         // source row = idx ? idx[r] : r
   GnRef gn;
   int act;               // 1 => LeakyReLU(0.2) after the normalisation
 };

@@ -42,12 +42,12 @@ __device__ __forceinline__ RowSrc row_source(const GemmArgs& p, int cloud, int r
   if (row >= p.M) { r.o0 = r.o1 = -1; return r; }
   {
     const Seg& s = p.seg[0];
-    int sr = s.idx ? s.idx[cloud * s.idx_cloud_stride + row] : row / s.row_div;
+    int sr = s.idx ? s.idx[cloud * s.idx_cloud_stride + row] : row;
     r.o0 = cloud * s.cloud_stride + (int64_t)sr * s.ld;
   }
   if (p.nseg > 1) {
     const Seg& s = p.seg[1];
-    int sr = s.idx ? s.idx[cloud * s.idx_cloud_stride + row] : row / s.row_div;
+    int sr = s.idx ? s.idx[cloud * s.idx_cloud_stride + row] : row;
     r.o1 = cloud * s.cloud_stride + (int64_t)sr * s.ld;
   } else {
     r.o1 = -1;

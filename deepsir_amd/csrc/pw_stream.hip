@@ -49,7 +49,7 @@ __device__ __forceinline__ void vec_load(const float* __restrict__ p, float (&v)
 }
 
 __device__ __forceinline__ int src_row(const Seg& s, int cloud, int row) {
-  return s.idx ? s.idx[cloud * s.idx_cloud_stride + row] : row / s.row_div;
+  return s.idx ? s.idx[cloud * s.idx_cloud_stride + row] : row;
 }
 
 template <int KQ, int NT, int EPI, int MODE>
@@ -157,7 +157,6 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const GemmArgs p) {
   const float* mybase = myseg.x + cloud * myseg.cloud_stride + seg_c;                     // per lane (segment of its chunk)
   const int32_t* myidx = myseg.idx ? myseg.idx + cloud * myseg.idx_cloud_stride : nullptr;
   const uint32_t my_ld = (uint32_t)myseg.ld;
-  const int my_div = myseg.row_div;
 
   const int ntiles = (p.M + 15) >> 4;
   const int wave0 = blockIdx.x * 4 + w, nwaves = gridDim.x * 4;
@@ -168,7 +167,7 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const GemmArgs p) {
   auto tile_srow = [&](int tile) -> int {
     if (MODE != S_VEC) return 0;
     const int row = min(tile * 16 + fr, p.M - 1);
-    return myidx ? myidx[row] : row / my_div;
+    return myidx ? myidx[row] : row;
   };
   auto finish_tile = [&](int tile, Chunk<KQ>& ch) {
     if (MODE != S_VEC) return;

@@ -33,12 +33,12 @@ __device__ __forceinline__ RowOff row_off(const GemmArgs& p, int cloud, int row)
   if (row >= p.M) return r;
   {
     const Seg& s = p.seg[0];
-    const int sr = s.idx ? s.idx[cloud * s.idx_cloud_stride + row] : row / s.row_div;
+    const int sr = s.idx ? s.idx[cloud * s.idx_cloud_stride + row] : row;
     r.o0 = cloud * s.cloud_stride + (int64_t)sr * s.ld;
   }
   if (p.nseg > 1) {
     const Seg& s = p.seg[1];
-    const int sr = s.idx ? s.idx[cloud * s.idx_cloud_stride + row] : row / s.row_div;
+    const int sr = s.idx ? s.idx[cloud * s.idx_cloud_stride + row] : row;
     r.o1 = cloud * s.cloud_stride + (int64_t)sr * s.ld;
   }
   return r;
