@@ -69,6 +69,19 @@ def cpu_baseline(cfg, sd, n_points, n_iter, budget_s=25.0):
                       f"restatement, bit-identical to the imported reference on the golden fixtures"}
 
 
+def path_flops(n, n_iter):
+    """Algorithmic FLOPs of one pair through the whole path: F = 2 R(N) + n_iter [2 A(N) + 131 N^2 + R(N)
+    + 40 N] + KNN(N), R(N) = 327.4 kFLOP/pt (RandLA pass), A(N) = 2 N (20480 + 59520 + 4096) (aggregation of one cloud),
+    KNN(N) = 20 sum_l n_l^2 (SURVEY counts 0.53 G at N = 5000).  Hoisted loop invariants are NOT subtracted."""
+    R = 327.4e3 * n
+    A = 2.0 * n * (20480 + 59520 + 4096)
+    lv, knn = n, 0.0
+    for _ in range(4):
+        knn += 20.0 * lv * lv
+        lv //= 4
+    return 2 * R + n_iter * (2 * A + 131.0 * n * n + R + 40.0 * n) + knn
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -242,7 +255,14 @@ def main():
                          "launches": int(match_n), "avg_launch_ms": round(avg_match_s * 1e3, 5),
                          "flops_per_launch": match_flops(P_launch, N, N), "pairs_per_launch": P_launch, "concurrent_streams": S,
                          "achieved_isolated": None if isolated is None else round(isolated, 3),
-                         "frac_isolated": None if isolated is None else round(isolated / PEAK_F32_MFMA_TFLOPS, 4)},
+                         "frac_isolated": None if isolated is None else round(isolated / PEAK_F32_MFMA_TFLOPS, 4),
+                         "note": ("achieved = HIP-event bracket around the launch inside the timed region; with concurrent_streams > 1 "
+                                  "the kernel shares the CUs with the other engines' kernels during that bracket.  achieved_isolated = the "
+                                  "same launches back to back on one stream.  whole_path = algorithmic FLOPs of the entire job "
+                                  "(SURVEY 8d formula) / wall time"),
+                         "whole_path": {"flops_per_pair": path_flops(N, n_iter),
+                                        "achieved": round(path_flops(N, n_iter) * total_pairs / dt / 1e12, 3),
+                                        "frac": round(path_flops(N, n_iter) * total_pairs / dt / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}},
         }
         if model_only is not None:
             line["model_only"] = model_only
