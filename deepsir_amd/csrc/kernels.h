@@ -71,9 +71,7 @@ struct GemmArgs {
 void launch_pw_gemm(const GemmArgs& a, hipStream_t st);
 // narrow-layer fast path (pw_stream.hip); false => not applicable
 bool launch_pw_stream(const GemmArgs& a, hipStream_t st);
-// wide-layer path (pw_deep.hip): Cin a multiple of 32 in [64,768], Cout >= 64; false => not applicable
-bool launch_pw_deep(const GemmArgs& a, hipStream_t st);
-// wide-layer path, LDS-tiled 128/64 x 64 x 32 (pw_tile.hip); same envelope as pw_deep
+// wide-layer path, LDS-tiled 128/64 x 64 x 32 (pw_tile.hip): Cin a multiple of 32 in [64,768], Cout >= 64
 bool launch_pw_tile(const GemmArgs& a, hipStream_t st);
 
 // mlp_out + fc_label fused (head_mlp.hip): x[32] -> feat[64] -> 64 -> 32 -> ncls   (RandLANet.py:363-367)

@@ -20,6 +20,8 @@
 // LDS as [row][16+2] (the +2 pad makes the fragment reads bank-conflict free:
 // 18*r mod 32 is a permutation of the even banks for r = 0..15); the next
 // chunk's global loads are issued before the MFMAs of the current one.
+#include <cstdio>
+#include <cstdlib>
 #include "kernels.h"
 #include "device_utils.h"
 #include <cstdlib>
@@ -307,9 +309,6 @@ void launch_pw_gemm(const GemmArgs& a, hipStream_t st) {
   if (!no_stream && launch_pw_stream(a, st)) return;
   static const bool no_tile = getenv("DSIR_NO_TILE") != nullptr;
   if (!no_tile && launch_pw_tile(a, st)) return;
-  // pw_deep.hip is not yet faster than the LDS-tiled kernel below on MI355X (profiles/README.md): opt-in
-  static const bool use_deep = getenv("DSIR_DEEP") != nullptr;
-  if (use_deep && launch_pw_deep(a, st)) return;
   if (a.amode == A_LSE) {
     launch_bn<EPI_GN, A_LSE>(a, st);
     return;
@@ -320,6 +319,9 @@ void launch_pw_gemm(const GemmArgs& a, hipStream_t st) {
     case EPI_LINEAR: launch_bn<EPI_LINEAR, A_SEGS>(a, st); break;
     case EPI_L2NORM: launch_t<64, EPI_L2NORM, A_SEGS>(a, st); break;
     case EPI_ATT: launch_bn<EPI_ATT, A_SEGS>(a, st); break;
+    default:   // EPI_ATT2 exists only in pw_stream / pw_tile; the engine falls back to EPI_ATT itself (Sched::att)
+      fprintf(stderr, "dsir: launch_pw_gemm: epilogue %d has no generic kernel\n", a.epi);
+      abort();
   }
 }
 
