@@ -117,3 +117,113 @@ def summarize_metrics(metrics: Dict[str, np.ndarray]) -> Dict[str, float]:
         else:
             out[k] = float(np.mean(v))
     return out
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# 'feat' / 'label' pipelines (reference test.py:460-567): the caller side of Network.forward = forward_pair
+class SemanticMetric:
+    """Running semantic-segmentation statistics of the reference's ``SemanticLoss`` (network/loss.py:854-992):
+    label 0 ('unlabeled') is ignored, label l > 0 is class l-1; per-class IoU = TP / (GT + P - TP) (0 for an absent
+    class), mean IoU over all ``num_classes``, overall accuracy, and the inverse-frequency weighted cross entropy
+    (class weights 1 / (freq + 0.02) from the SemanticKITTI point counts, loss.py:905-911)."""
+
+    NUM_PER_CLASS = np.array([55437630, 320797, 541736, 2578735, 3274484, 552662, 184064, 78858, 240942562, 17294618,
+                              170599734, 6369672, 230413074, 101130274, 476491114, 9833174, 129609852, 4506626, 1168181],
+                             dtype=np.float64)
+
+    def __init__(self, num_classes: int = 19):
+        self.num_classes = num_classes
+        w = self.NUM_PER_CLASS / self.NUM_PER_CLASS.sum()
+        self.class_weights = (1.0 / (w + 0.02)).astype(np.float32)
+        self.reset()
+
+    def reset(self):
+        self.gt = np.zeros(self.num_classes, np.int64)
+        self.pos = np.zeros(self.num_classes, np.int64)
+        self.tp = np.zeros(self.num_classes, np.int64)
+        self.correct = 0
+        self.seen = 0
+
+    def add(self, logits: torch.Tensor, labels: torch.Tensor):
+        """logits [B, num_classes, N], labels [B, N] (0 = ignored).  Returns (weighted CE loss, accuracy) of this
+        batch (loss.py:929-958) and accumulates the confusion counts (:960-971)."""
+        lg = logits.transpose(1, 2).reshape(-1, self.num_classes).float()
+        lb = labels.reshape(-1).long()
+        valid = lb != 0
+        lg, lb = lg[valid], lb[valid] - 1
+        if lb.numel() == 0:
+            return float("nan"), float("nan")
+        w = torch.from_numpy(self.class_weights).to(lg.device)
+        loss = torch.nn.functional.cross_entropy(lg, lb, weight=w, reduction="mean")
+        pred = lg.max(dim=1)[1]
+        acc = (pred == lb).sum().float() / float(lb.shape[0])
+        conf = torch.bincount(lb * self.num_classes + pred, minlength=self.num_classes ** 2)
+        conf = conf.reshape(self.num_classes, self.num_classes).cpu().numpy()
+        self.gt += conf.sum(1)
+        self.pos += conf.sum(0)
+        self.tp += np.diagonal(conf)
+        self.correct += int((pred == lb).sum())
+        self.seen += int(lb.numel())
+        return float(loss), float(acc)
+
+    def result(self):
+        """(mean IoU, per-class IoU list, mean accuracy); resets like the reference (loss.py:973-987)."""
+        denom = (self.gt + self.pos - self.tp).astype(np.float64)
+        iou = np.where(denom != 0, self.tp / np.where(denom != 0, denom, 1.0), 0.0)
+        out = float(iou.sum() / self.num_classes), [float(x) for x in iou], self.correct / float(max(self.seen, 1))
+        self.reset()
+        return out
+
+
+def _pair_batches(pairs, batch, device):
+    for b0 in range(0, len(pairs), batch):
+        ids = list(range(b0, min(b0 + batch, len(pairs))))
+        keys = [k for k in pairs[ids[0]] if k != "others" and isinstance(pairs[ids[0]][k], np.ndarray)]
+        yield ids, {k: torch.from_numpy(np.concatenate([pairs[i][k] for i in ids], 0)).to(device) for k in keys}
+
+
+@torch.no_grad()
+def inference_feat(pairs: Sequence[Dict[str, np.ndarray]], model, batch: int = 1, device: Optional[torch.device] = None):
+    """test.py::inference_feat (:460-505): key points + saliency per cloud.  Returns a list (one entry per pair) of
+    {'pt_src' [M,3], 'score_src' [M], 'feat_src' [M,64], ... same for ref} as numpy, and the total model time."""
+    device = device or torch.device("cuda", torch.cuda.current_device())
+    out, total = [], 0.0
+    for ids, data in _pair_batches(pairs, batch, device):
+        torch.cuda.synchronize(device)
+        t0 = time.time()
+        _, ep = model(data)
+        torch.cuda.synchronize(device)
+        total += time.time() - t0
+        for j in range(len(ids)):
+            rec = {}
+            for s in ("src", "ref"):
+                rec[f"pt_{s}"] = ep[f"pt_{s}"][j].t().cpu().numpy()
+                rec[f"feat_{s}"] = ep[f"feat_{s}"][j].t().cpu().numpy()
+                rec[f"score_{s}"] = ep[f"score_{s}"][j].cpu().numpy()
+            out.append(rec)
+    return out, total
+
+
+@torch.no_grad()
+def inference_label(pairs: Sequence[Dict[str, np.ndarray]], model, batch: int = 1, device: Optional[torch.device] = None):
+    """test.py::inference_label (:508-567): semantic head over every pair; ``labels_src`` / ``labels_ref`` [1,N]
+    (0 = unlabeled) give accuracy / IoU.  Returns (per-pair predicted labels (1-based like the reference's export),
+    {'mean_iou', 'iou', 'mean_acc', 'loss'}, total model time)."""
+    device = device or torch.device("cuda", torch.cuda.current_device())
+    metric = SemanticMetric(model.cfg.num_classes)
+    preds, losses, total = [], [], 0.0
+    for ids, data in _pair_batches(pairs, batch, device):
+        torch.cuda.synchronize(device)
+        t0 = time.time()
+        _, ep = model(data)
+        torch.cuda.synchronize(device)
+        total += time.time() - t0
+        if "labels_src" in data:
+            l_s, _ = metric.add(ep["logits_src"], data["labels_src"])
+            l_r, _ = metric.add(ep["logits_ref"], data["labels_ref"])
+            losses.append(l_s + l_r)
+        for j in range(len(ids)):
+            preds.append({s: (torch.argmax(ep[f"logits_{s}"][j], dim=0) + 1).cpu().numpy() for s in ("src", "ref")})
+    mean_iou, iou, mean_acc = metric.result()
+    return preds, {"mean_iou": mean_iou, "iou": iou, "mean_acc": mean_acc,
+                   "loss": float(np.nanmean(losses)) if losses else float("nan")}, total

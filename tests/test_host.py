@@ -94,3 +94,26 @@ def test_summarize_metrics_naming():
     s = summarize_metrics(m)
     assert s["r_rmse"] == pytest.approx(np.sqrt(5.0)) and s["t_mae"] == 1.0
     assert s["err_t_mean"] == 3.5 and s["err_t_rmse"] == pytest.approx(np.sqrt(12.5)) and s["succ"] == 0.5
+
+
+def test_semantic_metric_matches_hand_computation():
+    """SemanticLoss bookkeeping (reference network/loss.py:929-987): label 0 ignored, label l -> class l-1."""
+    from deepsir_amd.harness import SemanticMetric
+    m = SemanticMetric(19)
+    logits = torch.full((1, 19, 6), -5.0)
+    pred = [0, 0, 3, 3, 7, 2]                       # arg-max classes
+    for i, c in enumerate(pred):
+        logits[0, c, i] = 5.0
+    labels = torch.tensor([[1, 4, 4, 0, 8, 1]])     # classes 0, 3, 3, ignored, 7, 0
+    loss, acc = m.add(logits, labels)
+    assert acc == pytest.approx(3 / 5)              # points 0, 2, 4 are right; point 3 is ignored
+    w = m.class_weights
+    nll = np.array([0.0, 10.0, 0.0, 0.0, 10.0]) + np.log1p(18 * np.exp(-10.0))
+    wt = w[[0, 3, 3, 7, 0]]
+    assert loss == pytest.approx(float((nll * wt).sum() / wt.sum()), rel=1e-5)
+    mean_iou, iou, mean_acc = m.result()
+    assert iou[0] == pytest.approx(1 / 3)           # class 0: GT 2 (points 0, 5), predicted 2 (points 0, 1), TP 1
+    assert iou[3] == pytest.approx(1 / 2)           # class 3: GT 2 (points 1, 2), predicted 1 (point 2; point 3 ignored), TP 1
+    assert iou[7] == pytest.approx(1.0) and iou[2] == 0.0 and iou[5] == 0.0
+    assert mean_iou == pytest.approx((1 / 3 + 1 / 2 + 1.0) / 19) and mean_acc == pytest.approx(3 / 5)
+    assert m.seen == 0                              # result() resets, like semantic_metric()

@@ -124,3 +124,36 @@ def test_gpu_pipeline_guards():
     full = generate_state_dict(NetConfig(), 0)
     with pytest.raises(Exception, match="unexpected key"):
         eng.load_state_dict(full)
+
+
+@pytest.mark.gpu
+def test_gpu_harness_feat_and_label():
+    """inference_feat / inference_label (reference test.py:460-567) around the drop-in Network."""
+    from types import SimpleNamespace
+    from deepsir_amd.harness import inference_feat, inference_label
+    from deepsir_amd.model import Network
+    from deepsir_amd.weights import to_torch_state_dict
+
+    def build(name):
+        g, m, cfg, sd, data = build_case(name)
+        args = SimpleNamespace(pipeline=m["pipeline"], num_sub=m["num_sub"], feat_len=m["feat_len"], num_knn=16,
+                               out_feat_dim=64, d_out=[16, 64, 128, 256], sub_sampling_ratio=[4, 4, 4, 4],
+                               clip_weight_thresh=0.0, use_ppf=False)
+        net = Network(args)
+        net.load_state_dict(to_torch_state_dict(sd), strict=True)
+        return g, m, data, net.cuda().eval()
+
+    g, m, data, net = build("feat_n2048_s13_sub512")
+    pair = {k: v for k, v in data.items() if k.startswith("points_") and k.count("_") == 1}   # clouds only: KNN on device
+    recs, t = inference_feat([pair, pair], net, batch=2)
+    assert len(recs) == 2 and recs[0]["pt_src"].shape == (512, 3) and recs[0]["feat_ref"].shape == (512, 64) and t > 0
+    np.testing.assert_allclose(recs[0]["score_src"], g["score_src"][0], rtol=1e-5, atol=1e-7)
+    np.testing.assert_array_equal(recs[0]["score_src"], recs[1]["score_src"])
+
+    g, m, data, net = build("label_n1024_s11")
+    pair = {k: v for k, v in data.items() if k.startswith("points_") and k.count("_") == 1}
+    want = {s: g[f"logits_{s}"][0].argmax(0) + 1 for s in ("src", "ref")}
+    pair["labels_src"], pair["labels_ref"] = want["src"][None].astype(np.int64), want["ref"][None].astype(np.int64)
+    preds, met, t = inference_label([pair], net)
+    agree = np.mean(preds[0]["src"] == want["src"])
+    assert agree > 0.995 and met["mean_acc"] > 0.995 and 0.0 < met["mean_iou"] <= 1.0 and np.isfinite(met["loss"])
