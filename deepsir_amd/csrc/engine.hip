@@ -546,7 +546,8 @@ int build_pyramid(dsir_ctx* c, const float* points, int stride, int clouds, int 
     // every level's points are a prefix of the level above, hence of the input cloud (data_base.py:166-172)
     launch_copy_xyz(points, (int64_t)n * stride, stride, p.nl[l], clouds, xyz + (int64_t)p.off[l] * 3, xyz_cs, st);
     static const bool no_grid = getenv("DSIR_NO_GRID") != nullptr;   // A/B switch
-    if (p.nl[l] >= 2048 && !no_grid) {
+    static const int grid_min = getenv("DSIR_GRID_MIN") ? atoi(getenv("DSIR_GRID_MIN")) : 1024;   // tuning hook
+    if (p.nl[l] >= grid_min && !no_grid) {
       // large levels: exact grid-pruned search (knn_grid.hip); same bits as the brute force
       const size_t mark = c->ws.mark();
       void* scratch = c->ws.raw(knn_grid_scratch_bytes(clouds, p.nl[l]));

@@ -1,4 +1,4 @@
-// Exact 16-NN through a uniform grid, for the large pyramid levels (n >= 2048).
+// Exact 16-NN through a uniform grid, for the large pyramid levels (n >= 1024; DSIR_GRID_MIN).
 // Same result, bit for bit, as the brute force of knn.hip / oracle/knn.py: fp32
 // d = (dx*dx + dy*dy) + dz*dz without FMA contraction, neighbours ordered by
 // (d, then lower index).  The grid only prunes: a query visits the cells of growing
