@@ -154,77 +154,112 @@ __global__ __launch_bounds__(256) void grid_scatter_kernel(const float* __restri
   }
 }
 
+// Sorted top-16 under the lexicographic order (distance, index).  A squared distance is a non-negative float, whose
+// bit pattern is monotone as an unsigned integer, so (bits(d) << 32 | index) orders exactly like (d, index): one
+// 64-bit compare and four selects per compare-exchange step, no branches.
 struct TopLex {
-  float d[kKnn];
-  int i[kKnn];
+  unsigned long long k[kKnn];
   __device__ __forceinline__ void init() {
 #pragma unroll
-    for (int t = 0; t < kKnn; ++t) { d[t] = INFINITY; i[t] = 0x7fffffff; }
+    for (int t = 0; t < kKnn; ++t) k[t] = 0x7f8000007fffffffull;   // (+inf, INT_MAX)
   }
+  __device__ __forceinline__ float worst() const { return __uint_as_float((unsigned)(k[kKnn - 1] >> 32)); }
+  __device__ __forceinline__ int index(int t) const { return (int)(unsigned)(k[t] & 0xffffffffull); }
   __device__ __forceinline__ void insert(float dist, int idx) {
-    if (dist < d[kKnn - 1] || (dist == d[kKnn - 1] && idx < i[kKnn - 1])) {
-      d[kKnn - 1] = dist; i[kKnn - 1] = idx;
+    const unsigned long long x = ((unsigned long long)__float_as_uint(dist) << 32) | (unsigned)idx;
+    if (x < k[kKnn - 1]) {
+      k[kKnn - 1] = x;
 #pragma unroll
       for (int t = kKnn - 1; t > 0; --t) {
-        const bool sw = d[t] < d[t - 1] || (d[t] == d[t - 1] && i[t] < i[t - 1]);
-        const float dl = sw ? d[t] : d[t - 1], dh = sw ? d[t - 1] : d[t];
-        const int il = sw ? i[t] : i[t - 1], ih = sw ? i[t - 1] : i[t];
-        d[t - 1] = dl; d[t] = dh; i[t - 1] = il; i[t] = ih;
+        const bool sw = k[t] < k[t - 1];
+        const unsigned long long lo = sw ? k[t] : k[t - 1], hi = sw ? k[t - 1] : k[t];
+        k[t - 1] = lo; k[t] = hi;
       }
     }
   }
 };
 
+constexpr int QCAP = 16;   // per-lane candidate queue depth
+
+// One lane per query (queries taken in cell order, so a wave's lanes walk neighbouring cells).  The sorted
+// insertion (15 lexicographic compare-exchange steps, ~130 VALU instructions) is far more expensive than a
+// candidate's distance, and with 64 independent lanes SOME lane wants to insert at almost every candidate, so an
+// immediate insert() would run its body ~once per candidate for the whole wave.  Candidates that pass the lane's
+// threshold (its 16th best distance at the last flush) are therefore parked in a per-lane LDS queue and inserted in
+// bursts — all lanes together — when some lane's queue is full and at the end of every shell.  insert() re-checks
+// exactly, and TopLex is order independent, so the result is unchanged.
 __global__ __launch_bounds__(256) void grid_knn_kernel(const float4* __restrict__ sorted, const int* __restrict__ starts,
                                                        const GridParams* __restrict__ gp, int max_cells, int n,
                                                        int32_t* __restrict__ out, int64_t ocs) {
+  __shared__ float qd[QCAP][256];
+  __shared__ int qi[QCAP][256];
   const int cloud = blockIdx.y;
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n) return;
+  const int tid = threadIdx.x;
+  const int t = blockIdx.x * blockDim.x + tid;
+  const bool live = t < n;
   const GridParams g = gp[cloud];
   const float4* S = sorted + (int64_t)cloud * n;
   const int* ST = starts + (int64_t)cloud * (max_cells + 1);
-  const float4 q = S[t];
-  const int qi = __float_as_int(q.w);
+  const float4 q = S[live ? t : n - 1];
+  const int qidx = __float_as_int(q.w);
   const int cx = cell_coord(q.x, g.ox, g.inv_h, g.gx);
   const int cy = cell_coord(q.y, g.oy, g.inv_h, g.gy);
   const int cz = cell_coord(q.z, g.oz, g.inv_h, g.gz);
   TopLex top;
   top.init();
-  const int rmax = max(max(max(cx, g.gx - 1 - cx), max(cy, g.gy - 1 - cy)), max(cz, g.gz - 1 - cz));
+  float thr = INFINITY;
+  int nq = 0;
+  auto flush = [&]() {
+#pragma unroll 1
+    for (int c = 0; c < QCAP; ++c)
+      if (c < nq) top.insert(qd[c][tid], qi[c][tid]);
+    nq = 0;
+    thr = top.worst();
+  };
+  // Four candidates per step: their (clamped) loads are independent, so their latencies overlap instead of adding up.
+  auto scan = [&](int b, int e) {
+    for (int k = b; k < e; k += 4) {
+      float4 sv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) sv[u] = S[min(k + u, e - 1)];
+      if (__any(nq > QCAP - 4)) flush();
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float d = sqdist3(q.x, q.y, q.z, sv[u].x, sv[u].y, sv[u].z);
+        if (k + u < e && d <= thr) { qd[nq][tid] = d; qi[nq][tid] = __float_as_int(sv[u].w); ++nq; }
+      }
+    }
+  };
+  const int rmax = live ? max(max(max(cx, g.gx - 1 - cx), max(cy, g.gy - 1 - cy)), max(cz, g.gz - 1 - cz)) : -1;
   for (int r = 0; r <= rmax; ++r) {
     const int z0 = max(cz - r, 0), z1 = min(cz + r, g.gz - 1);
     const int y0 = max(cy - r, 0), y1 = min(cy + r, g.gy - 1);
     const int x0 = max(cx - r, 0), x1 = min(cx + r, g.gx - 1);
-    for (int z = z0; z <= z1; ++z) {
-      const bool zshell = (z == cz - r) || (z == cz + r);
-      for (int y = y0; y <= y1; ++y) {
-        const bool yshell = zshell || (y == cy - r) || (y == cy + r);
-        const int rowbase = (z * g.gy + y) * g.gx;
-        if (yshell) {                               // whole x-run of this row lies on the shell: cells are contiguous
-          const int b = ST[rowbase + x0], e = ST[rowbase + x1 + 1];
-          for (int k = b; k < e; ++k) {
-            const float4 s = S[k];
-            top.insert(sqdist3(q.x, q.y, q.z, s.x, s.y, s.z), __float_as_int(s.w));
-          }
-        } else {                                    // interior row: only the two end cells are on the shell
-          if (cx - r >= 0) {
-            const int b = ST[rowbase + cx - r], e = ST[rowbase + cx - r + 1];
-            for (int k = b; k < e; ++k) {
-              const float4 s = S[k];
-              top.insert(sqdist3(q.x, q.y, q.z, s.x, s.y, s.z), __float_as_int(s.w));
-            }
-          }
-          if (cx + r <= g.gx - 1) {
-            const int b = ST[rowbase + cx + r], e = ST[rowbase + cx + r + 1];
-            for (int k = b; k < e; ++k) {
-              const float4 s = S[k];
-              top.insert(sqdist3(q.x, q.y, q.z, s.x, s.y, s.z), __float_as_int(s.w));
-            }
-          }
-        }
+    const int ny = y1 - y0 + 1, nrows = (z1 - z0 + 1) * ny;
+    // the shell's rows (z, y) one after the other; the cell-range loads of row j+1 are issued before row j is scanned
+    // row -> up to two candidate ranges [b0,e0), [b1,e1): the whole x-run when the row lies on a face of the shell,
+    // else its two end cells
+    auto bounds = [&](int j, int& b0, int& e0, int& b1, int& e1) {
+      const int z = z0 + j / ny, y = y0 + j % ny;
+      const bool face = (z == cz - r) || (z == cz + r) || (y == cy - r) || (y == cy + r);
+      const int rowbase = (z * g.gy + y) * g.gx;
+      b0 = e0 = b1 = e1 = 0;
+      if (face) { b0 = ST[rowbase + x0]; e0 = ST[rowbase + x1 + 1]; }
+      else {
+        if (cx - r >= 0) { b0 = ST[rowbase + cx - r]; e0 = ST[rowbase + cx - r + 1]; }
+        if (cx + r <= g.gx - 1) { b1 = ST[rowbase + cx + r]; e1 = ST[rowbase + cx + r + 1]; }
       }
+    };
+    int b0, e0, b1, e1;
+    if (nrows > 0) bounds(0, b0, e0, b1, e1);
+    for (int j = 0; j < nrows; ++j) {
+      int nb0 = 0, ne0 = 0, nb1 = 0, ne1 = 0;
+      if (j + 1 < nrows) bounds(j + 1, nb0, ne0, nb1, ne1);
+      scan(b0, e0);
+      scan(b1, e1);
+      b0 = nb0; e0 = ne0; b1 = nb1; e1 = ne1;
     }
+    flush();
     // distance from the query to the nearest face of the visited cube that still has cells behind it
     float bound = INFINITY;
     if (cx - r > 0) bound = fminf(bound, q.x - (g.ox + (float)(cx - r) * g.h));
@@ -236,11 +271,13 @@ __global__ __launch_bounds__(256) void grid_knn_kernel(const float4* __restrict_
     if (bound == INFINITY) break;                   // the cube covers the whole grid
     // Points binned by clamped/rounded coordinates can sit a few ulps outside their cell: keep a margin.
     bound -= 1e-4f * g.h;
-    if (bound > 0.f && top.d[kKnn - 1] < bound * bound * 0.9999f) break;
+    if (bound > 0.f && top.worst() < bound * bound * 0.9999f) break;
   }
-  int32_t* o = out + cloud * ocs + (int64_t)qi * kKnn;
+  if (live) {
+    int32_t* o = out + cloud * ocs + (int64_t)qidx * kKnn;
 #pragma unroll
-  for (int k = 0; k < kKnn; k += 4) *reinterpret_cast<int4*>(o + k) = make_int4(top.i[k], top.i[k + 1], top.i[k + 2], top.i[k + 3]);
+    for (int k = 0; k < kKnn; k += 4) *reinterpret_cast<int4*>(o + k) = make_int4(top.index(k), top.index(k + 1), top.index(k + 2), top.index(k + 3));
+  }
 }
 
 }  // namespace
