@@ -180,6 +180,7 @@ struct TopLex {
 };
 
 constexpr int QCAP = 16;   // per-lane candidate queue depth
+constexpr int KB = 64;     // threads per query block (queue = QCAP * KB * 8 bytes of LDS)
 
 // One lane per query (queries taken in cell order, so a wave's lanes walk neighbouring cells).  The sorted
 // insertion (15 lexicographic compare-exchange steps, ~130 VALU instructions) is far more expensive than a
@@ -188,11 +189,11 @@ constexpr int QCAP = 16;   // per-lane candidate queue depth
 // threshold (its 16th best distance at the last flush) are therefore parked in a per-lane LDS queue and inserted in
 // bursts — all lanes together — when some lane's queue is full and at the end of every shell.  insert() re-checks
 // exactly, and TopLex is order independent, so the result is unchanged.
-__global__ __launch_bounds__(256) void grid_knn_kernel(const float4* __restrict__ sorted, const int* __restrict__ starts,
+__global__ __launch_bounds__(KB) void grid_knn_kernel(const float4* __restrict__ sorted, const int* __restrict__ starts,
                                                        const GridParams* __restrict__ gp, int max_cells, int n,
                                                        int32_t* __restrict__ out, int64_t ocs) {
-  __shared__ float qd[QCAP][256];
-  __shared__ int qi[QCAP][256];
+  __shared__ float qd[QCAP][KB];
+  __shared__ int qi[QCAP][KB];
   const int cloud = blockIdx.y;
   const int tid = threadIdx.x;
   const int t = blockIdx.x * blockDim.x + tid;
@@ -311,7 +312,7 @@ void launch_knn16_grid(const float* pts, int64_t cs, int stride, int n, int clou
   hipLaunchKernelGGL(grid_count_kernel, dim3(gx, clouds), dim3(256), 0, st, pts, cs, stride, n, gp, max_cells, cell_of, counts);
   hipLaunchKernelGGL(grid_scan_kernel, dim3(clouds), dim3(1024), 0, st, counts, max_cells, gp, starts, cursor);
   hipLaunchKernelGGL(grid_scatter_kernel, dim3(gx, clouds), dim3(256), 0, st, pts, cs, stride, n, cell_of, max_cells, cursor, sorted);
-  hipLaunchKernelGGL(grid_knn_kernel, dim3(gx, clouds), dim3(256), 0, st, sorted, starts, gp, max_cells, n, out, ocs);
+  hipLaunchKernelGGL(grid_knn_kernel, dim3((n + KB - 1) / KB, clouds), dim3(KB), 0, st, sorted, starts, gp, max_cells, n, out, ocs);
 }
 
 }  // namespace dsir
