@@ -66,6 +66,7 @@ struct GemmArgs {
   const float* residual = nullptr;  // EPI_LINEAR: added before the store
   int64_t res_cloud_stride = 0;
   int ldres = 0;
+  int grid_x = 0, grid_y = 0;   // filled by the launchers that flatten their grid (XCD-aware work mapping)
 };
 
 void launch_pw_gemm(const GemmArgs& a, hipStream_t st);

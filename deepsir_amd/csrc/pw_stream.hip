@@ -68,8 +68,17 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const GemmArgs p) {
   // exec-mask save/restore sequences
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fq = lane >> 4;
-  const int cloud = blockIdx.z;
-  const int n0 = blockIdx.y * BN;
+  // XCD-aware work mapping (speed only; per-cloud work and results are unchanged): workgroups are dealt round-robin
+  // over the 8 XCDs, each with its own L2.  The bijective remap hands every XCD a CONTIGUOUS range of work items ordered
+  // (cloud, column block, row block), i.e. whole clouds, so the rows a cloud's blocks gather (neighbour features, G = W1 f)
+  // live in ONE L2 instead of being replicated through eight.
+  const int nwg = gridDim.x, id = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = id & 7;
+  const int wi = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3);
+  const int bx = wi % p.grid_x;
+  const int by = (wi / p.grid_x) % p.grid_y;
+  const int cloud = wi / (p.grid_x * p.grid_y);
+  const int n0 = by * BN;
   const int ldw = p.ldw ? p.ldw : p.Cin;
 
   if (EPI == EPI_ATT2) {
@@ -159,7 +168,7 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const GemmArgs p) {
   const uint32_t my_ld = (uint32_t)myseg.ld;
 
   const int ntiles = (p.M + 15) >> 4;
-  const int wave0 = blockIdx.x * 4 + w, nwaves = gridDim.x * 4;
+  const int wave0 = bx * 4 + w, nwaves = p.grid_x * 4;
 
   // source row of this lane's A row in tile `tile` (gathered segments: one index load, issued a tile ahead)
   // Rows past M (last, partial tile) are CLAMPED to row M-1 rather than predicated: their MFMA results are
@@ -478,8 +487,10 @@ void launch_s(const GemmArgs& a, hipStream_t st) {
     blocks = want < most ? want : most;
   }
   if (blocks < 1) blocks = 1;
-  dim3 grid(blocks, gy, a.clouds);
-  hipLaunchKernelGGL((pw_stream_kernel<KQ, NT, EPI, MODE>), grid, dim3(256), 0, st, a);
+  GemmArgs b = a;
+  b.grid_x = blocks; b.grid_y = gy;
+  dim3 grid((unsigned)((int64_t)blocks * gy * a.clouds));
+  hipLaunchKernelGGL((pw_stream_kernel<KQ, NT, EPI, MODE>), grid, dim3(256), 0, st, b);
 }
 
 template <int KQ, int NT, int MODE>
