@@ -401,6 +401,41 @@ def test_network_dropin_api():
         net.load_state_dict({"bogus": torch.zeros(1)})
 
 
+@pytest.mark.parametrize("n_src,n_ref,seed", [(1357, 1357, 21), (1100, 1999, 22), (3001, 2048, 23)])
+def test_ragged_sizes_vs_oracle(n_src, n_ref, seed):
+    """Sizes that are multiples of nothing (row tiles of 16, GEMM blocks of 64/128, 4-wide vectors) and unequal src / ref
+    clouds (separate pyramids, no joint batch): the engine's correspondences forced into the oracle, poses within 1e-4;
+    arg-min checked against the oracle's own descriptors where the fp64 gap is clear."""
+    from deepsir_amd.arch import NetConfig
+    from deepsir_amd.engine import Engine
+    from deepsir_amd.synth import make_pair
+    from deepsir_amd.weights import generate_state_dict
+    from oracle.knn import add_pyramids
+    from oracle.network import OracleNet, to_torch
+    cfg = NetConfig(feat_len=3)
+    sd = generate_state_dict(cfg, 2, "separated")
+    a, b = make_pair(n_src, seed, 3), make_pair(n_ref, seed + 100, 3)
+    raw = {"points_src": a["points_src"], "points_ref": b["points_ref"]}
+    eng = Engine(cfg, 0, max_points=max(n_src, n_ref), max_pairs=1)
+    eng.load_state_dict(sd)
+    out = eng.register(cu(raw["points_src"]), cu(raw["points_ref"]), 3)
+    assert not bool(out["invalid"].any())
+    data = to_torch(add_pyramids(raw, cfg.num_knn, cfg.sub_sampling_ratio))
+    idx = out["idx"].cpu()
+    assert int(idx.min()) >= 0 and int(idx.max()) < n_ref and tuple(idx.shape) == (3, 1, n_src)
+    taps = {}
+    T_forced, ep = OracleNet(cfg, sd).register(data, 3, forced_idx=[idx[i].long() for i in range(3)], taps=taps)
+    assert_pose_close(out["transforms"].cpu().numpy()[0], np.stack([t.numpy()[0] for t in T_forced]), 1e-4, 1e-4,
+                      f"ragged {n_src}x{n_ref}")
+    np.testing.assert_allclose(out["logits"].cpu().numpy()[:, 0], np.stack([l.numpy()[0] for l in ep["perm_matrices"]]),
+                               rtol=2e-3, atol=2e-3)
+    best, second, arg = OracleNet.nn_gap(taps["desc_src"][0], taps["desc_ref"][0])
+    clear = ((second - best) > 1e-4 * (1.0 + best.abs()))[0].numpy()
+    assert clear.mean() > 0.5
+    assert np.array_equal(idx[0, 0].numpy()[clear], arg[0].numpy()[clear])
+    eng.close()
+
+
 def test_kitti_shaped_16k_feat4_vs_oracle():
     """BASELINE config 3 shape: 16384-point clouds with reflectance (feat_len 4), KITTI-like extent.
     The engine's own correspondences are forced into the CPU oracle: (R,t) of every iteration within 1e-4."""
