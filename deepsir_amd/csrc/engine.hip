@@ -969,7 +969,7 @@ static int register_enqueue(dsir_ctx* c, const dsir_pair_batch* in, int n_iter, 
         e0 = c->match_events[c->match_events_used].first; e1 = c->match_events[c->match_events_used].second;
         ++c->match_events_used;
       }
-      launch_nn_match_ws(desc_s, desc_r, P, J, K, idx_out, match_scratch, st, e0, e1);
+      launch_nn_match_ws(desc_s, desc_r, P, J, K, idx_out, match_scratch, st, e0, e1, /*ref_norms_cached=*/it > 0);
     }
     // inlier RandLA on [xyz_src(t); xyz_ref[idx]] with the SRC pyramid (model.py:574-577)
     const Seg s0 = plain_seg(xyz_cur, (int64_t)J * 3, 3, 3);

@@ -30,7 +30,9 @@ __device__ __forceinline__ unsigned int order_bits(float f) {
 }
 
 // |x|^2 of every descriptor row: one wave per 4 rows... (16 lanes per row, float4 each)
-__global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ x, int64_t rows, float* __restrict__ out) {
+// `init` (optional): the row's packed (distance, index) result slot, set to all ones here instead of by a separate memset
+__global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ x, int64_t rows, float* __restrict__ out,
+                                                     unsigned long long* __restrict__ init) {
   const int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
   const int l = threadIdx.x & 15;
   float s = 0.f;
@@ -39,7 +41,10 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ x
     s = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
   }
   s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
-  if (row < rows && l == 0) out[row] = s;
+  if (row < rows && l == 0) {
+    out[row] = s;
+    if (init) init[row] = ~0ull;
+  }
 }
 
 template <int RT>
@@ -184,15 +189,15 @@ size_t nn_match_scratch_bytes(int pairs, int J, int K) {
 }
 
 void launch_nn_match_ws(const float* a, const float* b, int pairs, int J, int K, int32_t* idx, void* scratch,
-                        hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
+                        hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, bool ref_norms_cached) {
   float* sa = reinterpret_cast<float*>(scratch);
   float* sb = sa + (size_t)pairs * J;
   size_t f = ((size_t)pairs * J + (size_t)pairs * K + 3) & ~(size_t)3;
   unsigned long long* packed = reinterpret_cast<unsigned long long*>(sa + f);
   const int64_t ra = (int64_t)pairs * J, rb = (int64_t)pairs * K;
-  hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)((ra + 15) / 16)), dim3(256), 0, st, a, ra, sa);
-  hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)((rb + 15) / 16)), dim3(256), 0, st, b, rb, sb);
-  hipMemsetAsync(packed, 0xff, (size_t)pairs * J * 8, st);
+  hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)((ra + 15) / 16)), dim3(256), 0, st, a, ra, sa, packed);
+  // the ref descriptors are loop invariant in dsir_register: their norms stay in the (persistent) scratch
+  if (!ref_norms_cached) hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)((rb + 15) / 16)), dim3(256), 0, st, b, rb, sb, nullptr);
   // geometry: 2 row tiles per wave (128-row blocks) once there is enough work, else 64-row blocks; the ref
   // range is split so that the grid is a whole number of residency rounds (256 CUs x 4 blocks: 34 KB LDS each)
   static const int force_rt = getenv("DSIR_MATCH_RT") ? atoi(getenv("DSIR_MATCH_RT")) : 0;   // tuning hook
