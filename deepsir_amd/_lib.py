@@ -84,6 +84,7 @@ SYMBOLS = {
     "dsir_forward_pair": (C.c_int, [C.c_void_p, C.POINTER(dsir_pair_batch), C.c_int, C.POINTER(dsir_cloud_out),
                                     C.POINTER(dsir_cloud_out)]),
     "dsir_match_timer": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), c_i64_p]),
+    "dsir_match_timer_device": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), c_i64_p]),
     "dsir_enable_match_timer": (C.c_int, [C.c_void_p, C.c_int]),
     "dsir_enable_graph": (C.c_int, [C.c_void_p, C.c_int]),
     "dsir_voxel_downsample": (C.c_int, [C.c_void_p, C.c_void_p, c_i64_p, C.c_int, C.c_int, C.c_float, c_float_p, C.c_int,

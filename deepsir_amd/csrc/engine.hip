@@ -99,7 +99,13 @@ struct dsir_ctx {
   size_t match_events_used = 0;
   double match_ms = 0.0;
   int64_t match_launches = 0;
+  // device-clock brackets {first wave start, last wave end} of the timed nn_match launches
+  unsigned long long* match_ts = nullptr;    // [kMatchSlots][2]
+  size_t match_ts_used = 0;
+  double match_dev_ms = 0.0;
+  int64_t match_dev_launches = 0;
 };
+constexpr size_t kMatchSlots = 4096;
 
 namespace {
 
@@ -641,6 +647,7 @@ void dsir_destroy(dsir_ctx* c) {
   for (auto& e : c->match_events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
   if (c->graph_exec) hipGraphExecDestroy(c->graph_exec);
   if (c->dweights) hipFree(c->dweights);
+  if (c->match_ts) hipFree(c->match_ts);
   if (c->stats) hipFree(c->stats);
   if (c->ws.base) hipFree(c->ws.base);
   hipStreamDestroy(c->stream);
@@ -895,6 +902,11 @@ static int forward_pair_stage(dsir_ctx* c, const dsir_pair_batch* in, bool want_
   return 0;
 }
 
+static unsigned long long* match_ts_slot(dsir_ctx* c) {
+  if (!c->time_match || !c->match_ts || c->match_ts_used >= kMatchSlots) return nullptr;
+  return c->match_ts + 2 * c->match_ts_used++;
+}
+
 static int register_enqueue(dsir_ctx* c, const dsir_pair_batch* in, int n_iter, const dsir_pair_result* out) {
   const dsir_cfg& g = c->cfg;
   const int P = in->pairs, J = in->n_src, K = in->n_ref;
@@ -969,7 +981,7 @@ static int register_enqueue(dsir_ctx* c, const dsir_pair_batch* in, int n_iter, 
         e0 = c->match_events[c->match_events_used].first; e1 = c->match_events[c->match_events_used].second;
         ++c->match_events_used;
       }
-      launch_nn_match_ws(desc_s, desc_r, P, J, K, idx_out, match_scratch, st, e0, e1, /*ref_norms_cached=*/it > 0);
+      launch_nn_match_ws(desc_s, desc_r, P, J, K, idx_out, match_scratch, st, e0, e1, /*ref_norms_cached=*/it > 0, match_ts_slot(c));
     }
     // inlier RandLA on [xyz_src(t); xyz_ref[idx]] with the SRC pyramid (model.py:574-577)
     const Seg s0 = plain_seg(xyz_cur, (int64_t)J * 3, 3, 3);
@@ -1148,9 +1160,43 @@ int dsir_eval_metrics(dsir_ctx* c, const float* pred_T, int64_t pred_stride, con
   return post(c);
 }
 
+static int match_ts_reset(dsir_ctx* c) {
+  std::vector<unsigned long long> init(2 * kMatchSlots);
+  for (size_t i = 0; i < kMatchSlots; ++i) { init[2 * i] = ~0ull; init[2 * i + 1] = 0ull; }
+  HIP_OK(c, hipMemcpy(c->match_ts, init.data(), init.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+  c->match_ts_used = 0;
+  return 0;
+}
 int dsir_enable_match_timer(dsir_ctx* c, int enable) {
   if (!c) return 1;
+  HIP_OK(c, hipSetDevice(c->device));
+  HIP_OK(c, hipStreamSynchronize(c->stream));
   c->time_match = enable != 0;
+  if (c->time_match) {
+    if (!c->match_ts) HIP_OK(c, hipMalloc((void**)&c->match_ts, 2 * kMatchSlots * sizeof(unsigned long long)));
+    if (int r = match_ts_reset(c)) return r;
+  }
+  return 0;
+}
+int dsir_match_timer_device(dsir_ctx* c, int reset, double* total_ms, int64_t* launches) {
+  if (!c) return 1;
+  HIP_OK(c, hipSetDevice(c->device));
+  HIP_OK(c, hipStreamSynchronize(c->stream));
+  if (c->match_ts && c->match_ts_used) {
+    std::vector<unsigned long long> h(2 * c->match_ts_used);
+    HIP_OK(c, hipMemcpy(h.data(), c->match_ts, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device) != hipSuccess || khz <= 0) khz = 100000;
+    for (size_t i = 0; i < c->match_ts_used; ++i)
+      if (h[2 * i] != ~0ull && h[2 * i + 1] > h[2 * i]) {
+        c->match_dev_ms += (double)(h[2 * i + 1] - h[2 * i]) / (double)khz;
+        ++c->match_dev_launches;
+      }
+    if (int r = match_ts_reset(c)) return r;
+  }
+  if (total_ms) *total_ms = c->match_dev_ms;
+  if (launches) *launches = c->match_dev_launches;
+  if (reset) { c->match_dev_ms = 0.0; c->match_dev_launches = 0; }
   return 0;
 }
 

@@ -154,7 +154,8 @@ void launch_score(const float* feat, const float* logits, int ncls, const float*
 // fused distance GEMM + row arg-min (matchnet.py:96-113 + model.py:566); ev0/ev1 (optional) bracket the main kernel
 size_t nn_match_scratch_bytes(int pairs, int J, int K);
 void launch_nn_match_ws(const float* a, const float* b, int pairs, int J, int K, int32_t* idx, void* scratch,
-                        hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, bool ref_norms_cached = false);
+                        hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, bool ref_norms_cached = false,
+                        unsigned long long* tstamp = nullptr);   // tstamp: {min start, max end} device-clock slot or nullptr
 
 // weighted Kabsch + SE(3) bookkeeping (model.py:22-66, :586-595; se3_torch.py:28-77)
 struct KabschArgs {

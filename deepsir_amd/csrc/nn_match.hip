@@ -51,7 +51,10 @@ template <int RT>
 __global__ __launch_bounds__(256) void nn_match_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                        const float* __restrict__ sa, const float* __restrict__ sb,
                                                        int J, int K, int cols_per_split, int rb_count, int splits,
-                                                       unsigned long long* __restrict__ packed) {
+                                                       unsigned long long* __restrict__ packed,
+                                                       unsigned long long* __restrict__ tstamp) {
+  // measurement hook: first-wave start / last-wave end on the device's constant-rate clock (what a kernel trace reports)
+  if (tstamp && threadIdx.x == 0) atomicMin(tstamp, (unsigned long long)wall_clock64());
   __shared__ float Bs[2][BC * LDB];   // double-buffered ref tile
   __shared__ float sbs[2][BC];
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform
@@ -173,6 +176,7 @@ __global__ __launch_bounds__(256) void nn_match_kernel(const float* __restrict__
         atomicMin(packed + (int64_t)pair * J + row, key);
       }
     }
+  if (tstamp && threadIdx.x == 0) atomicMax(tstamp + 1, (unsigned long long)wall_clock64());
 }
 
 __global__ void unpack_idx_kernel(const unsigned long long* __restrict__ packed, int64_t n, int32_t* __restrict__ idx) {
@@ -189,7 +193,7 @@ size_t nn_match_scratch_bytes(int pairs, int J, int K) {
 }
 
 void launch_nn_match_ws(const float* a, const float* b, int pairs, int J, int K, int32_t* idx, void* scratch,
-                        hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, bool ref_norms_cached) {
+                        hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, bool ref_norms_cached, unsigned long long* tstamp) {
   float* sa = reinterpret_cast<float*>(scratch);
   float* sb = sa + (size_t)pairs * J;
   size_t f = ((size_t)pairs * J + (size_t)pairs * K + 3) & ~(size_t)3;
@@ -226,9 +230,9 @@ void launch_nn_match_ws(const float* a, const float* b, int pairs, int J, int K,
   splits = (K + cols - 1) / cols;
   dim3 grid((unsigned)((int64_t)rb_count * splits * pairs));
   if (ev0) hipEventRecord(ev0, st);
-  if (rt == 4)      hipLaunchKernelGGL((nn_match_kernel<4>), grid, dim3(256), 0, st, a, b, sa, sb, J, K, cols, rb_count, splits, packed);
-  else if (rt == 2) hipLaunchKernelGGL((nn_match_kernel<2>), grid, dim3(256), 0, st, a, b, sa, sb, J, K, cols, rb_count, splits, packed);
-  else              hipLaunchKernelGGL((nn_match_kernel<1>), grid, dim3(256), 0, st, a, b, sa, sb, J, K, cols, rb_count, splits, packed);
+  if (rt == 4)      hipLaunchKernelGGL((nn_match_kernel<4>), grid, dim3(256), 0, st, a, b, sa, sb, J, K, cols, rb_count, splits, packed, tstamp);
+  else if (rt == 2) hipLaunchKernelGGL((nn_match_kernel<2>), grid, dim3(256), 0, st, a, b, sa, sb, J, K, cols, rb_count, splits, packed, tstamp);
+  else              hipLaunchKernelGGL((nn_match_kernel<1>), grid, dim3(256), 0, st, a, b, sa, sb, J, K, cols, rb_count, splits, packed, tstamp);
   if (ev1) hipEventRecord(ev1, st);
   hipLaunchKernelGGL(unpack_idx_kernel, dim3(256), dim3(256), 0, st, packed, ra, idx);
 }

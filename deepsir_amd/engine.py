@@ -355,6 +355,12 @@ class Engine:
         self._call(self.lib.dsir_match_timer(self.h, 1 if reset else 0, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def match_timer_device(self, reset=True):
+        """(total ms, launches) of the timed nn_match launches on the device clock (first wave start .. last wave end)."""
+        ms, n = C.c_double(), C.c_int64()
+        self._call(self.lib.dsir_match_timer_device(self.h, 1 if reset else 0, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
 
 class EnginePool:
     """S engines (each with its own HIP stream and workspace) registering disjoint slices of a batch
@@ -416,6 +422,13 @@ class EnginePool:
         ms = n = 0
         for e in self.engines:
             m, k = e.match_timer(reset)
+            ms, n = ms + m, n + k
+        return ms, n
+
+    def match_timer_device(self, reset=True):
+        ms = n = 0
+        for e in self.engines:
+            m, k = e.match_timer_device(reset)
             ms, n = ms + m, n + k
         return ms, n
 

@@ -222,6 +222,10 @@ int dsir_enable_graph(dsir_ctx* ctx, int enable);
  * with HIP events on the engine stream since the last reset: total ms and
  * launch count. */
 int dsir_match_timer(dsir_ctx* ctx, int reset, double* total_ms, int64_t* launches);
+/* Same launches, bracketed on the DEVICE's constant-rate clock inside the kernel (first wave start .. last wave end,
+ * the quantity a kernel trace reports): unlike the HIP-event bracket it does not include time the launch spends
+ * queued behind other streams' kernels when several engines share the GPU. */
+int dsir_match_timer_device(dsir_ctx* ctx, int reset, double* total_ms, int64_t* launches);
 int dsir_enable_match_timer(dsir_ctx* ctx, int enable);
 
 #ifdef __cplusplus
