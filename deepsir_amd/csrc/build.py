@@ -50,6 +50,12 @@ def build(force: bool = False, verbose: bool = False) -> str:
     objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES]
     if force or jobs or not os.path.exists(OUT):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs)
+    # the plain C++ host over the C ABI (examples/cabi_register.cpp): links against libdsir.so only
+    ex_src = os.path.join(ROOT, "examples", "cabi_register.cpp")
+    ex_bin = os.path.join(ROOT, "examples", "cabi_register")
+    if os.path.exists(ex_src) and (force or not _newer(ex_bin, [ex_src, OUT, os.path.join(ROOT, "include", "dsir.h")])):
+        run([hipcc, "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), ex_src, "-o", ex_bin,
+             "-L" + PKG, "-ldsir", "-Wl,-rpath," + PKG, "-Wl,-rpath,$ORIGIN/../deepsir_amd"])
     return OUT
 
 
