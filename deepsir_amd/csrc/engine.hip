@@ -1107,6 +1107,22 @@ int dsir_forward_pair(dsir_ctx* c, const dsir_pair_batch* in, int num_sub, const
   return post(c);
 }
 
+int dsir_icp_refine(dsir_ctx* c, const float* points_src, const float* points_ref, int pairs, int J, int K, int stride,
+                    float max_corr_dist, int max_iter, float rel_fitness, float rel_rmse, const float* T_init,
+                    float* T_out, double* stats) {
+  if (!c) return 1;
+  if (!points_src || !points_ref || !T_init || !T_out || pairs < 1 || J < 1 || K < 1 || stride < 3 || max_iter < 0 ||
+      !(max_corr_dist > 0.f))
+    return fail(c, "dsir_icp_refine: bad arguments");
+  HIP_OK(c, hipSetDevice(c->device));
+  c->ws.top = 0; c->ws.overflow = false;
+  void* scratch = c->ws.raw(icp_scratch_bytes(pairs, J));
+  if (c->ws.overflow) return fail(c, "workspace too small for dsir_icp_refine (raise max_points / max_pairs)");
+  launch_icp_refine(points_src, points_ref, pairs, J, K, stride, max_corr_dist, max_iter, rel_fitness, rel_rmse, T_init,
+                    T_out, stats, scratch, c->stream);
+  return post(c);
+}
+
 int dsir_enable_graph(dsir_ctx* c, int enable) {
   if (!c) return 1;
   c->use_graph = enable != 0;

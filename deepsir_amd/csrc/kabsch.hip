@@ -122,6 +122,19 @@ __global__ __launch_bounds__(NTHR) void kabsch_kernel(const KabschArgs a) {
   __shared__ int s_bad;
   const int pair = blockIdx.x;
   const int m = a.m;
+  if (a.skip && a.skip[pair]) {   // block-uniform: frozen pair (ICP converged): identity step, cumulative transform carried over
+    if (threadIdx.x == 0) {
+      const float I[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+      for (int k = 0; k < 12; ++k) a.T[(int64_t)pair * 12 + k] = I[k];
+      if (a.T_cum) {
+        float* out = a.T_cum + pair * a.T_stride;
+        const float* P = a.T_prev ? a.T_prev + pair * a.T_stride : I;
+        for (int k = 0; k < 12; ++k) out[k] = P[k];
+      }
+    }
+    return;
+  }
+  const int ld = a.ref_ld ? a.ref_ld : 3;
   const float* src = a.src + pair * a.src_stride;
   const float* ref = a.ref + pair * a.ref_stride;
   const int32_t* idx = a.idx ? a.idx + (int64_t)pair * m : nullptr;
@@ -132,7 +145,7 @@ __global__ __launch_bounds__(NTHR) void kabsch_kernel(const KabschArgs a) {
   };
   auto target = [&](int i, float& x, float& y, float& z) {
     const int64_t j = idx ? idx[i] : i;
-    x = ref[j * 3]; y = ref[j * 3 + 1]; z = ref[j * 3 + 2];
+    x = ref[j * ld]; y = ref[j * ld + 1]; z = ref[j * ld + 2];
   };
 
   // pass 1: S = sum |w|

@@ -175,8 +175,16 @@ struct KabschArgs {
   float* T_cum;          // cumulative out
   int64_t T_stride;      // floats between pairs in T_prev / T_cum
   float* matched_out;    // [pairs][m][3] gathered ref points (or nullptr)
+  int ref_ld;            // floats between ref points (0 => 3)
+  const int32_t* skip;   // [pairs] or nullptr: non-zero => this pair's update is the identity, src_out untouched (ICP)
 };
 void launch_kabsch(const KabschArgs& a, hipStream_t st);
+
+// icp.hip — point-to-point ICP refinement (test.py:241-258 / open3d registration_icp), all pairs at once
+size_t icp_scratch_bytes(int pairs, int J);
+void launch_icp_refine(const float* src, const float* ref, int pairs, int J, int K, int stride, float max_corr_dist,
+                       int max_iter, float rel_fitness, float rel_rmse, const float* T_init, float* T_out,
+                       double* stats_out, void* scratch, hipStream_t st);
 
 // pre-processing on ragged batches (preprocess.hip); return 0 on success
 size_t voxel_downsample_scratch_bytes(int64_t total, int clouds);

@@ -343,6 +343,23 @@ class Engine:
         return {k: out[:, i] for i, k in enumerate(self.METRIC_NAMES)}
 
     # ------------------------------------------------------------------ measurement hooks
+    def icp_refine(self, points_src, points_ref, T_init, max_corr_dist: float, max_iter: int = 30,
+                   rel_fitness: float = 1e-6, rel_rmse: float = 1e-6):
+        """open3d registration_icp (point-to-point) counterpart for P pairs (reference test.py:241-258, disabled there).
+        points_* [P,N,>=3] CUDA fp32, T_init [P,3,4] -> (T [P,3,4], stats [P,4] f64: fitness, inlier_rmse, converged, iters)."""
+        points_src, points_ref = _chk(points_src, torch.float32, "points_src"), _chk(points_ref, torch.float32, "points_ref")
+        T_init = _chk(T_init, torch.float32, "T_init")
+        P, J, stride = points_src.shape
+        K = points_ref.shape[1]
+        assert points_ref.shape[0] == P and points_ref.shape[2] == stride and tuple(T_init.shape) == (P, 3, 4)
+        T = self._empty((P, 3, 4))
+        stats = self._empty((P, 4), torch.float64)
+        self._pre()
+        self._call(self.lib.dsir_icp_refine(self.h, _ptr(points_src), _ptr(points_ref), P, J, K, stride, float(max_corr_dist),
+                                            int(max_iter), float(rel_fitness), float(rel_rmse), _ptr(T_init), _ptr(T), _ptr(stats)))
+        self.sync()
+        return T, stats
+
     def enable_graph(self, on=True):
         """Replay dsir_register through a captured hipGraph (same buffers on every call)."""
         self._call(self.lib.dsir_enable_graph(self.h, 1 if on else 0))

@@ -24,7 +24,8 @@ from .metrics import THRESHOLDS, rte_rre
 
 @torch.no_grad()
 def inference_align(pairs: Sequence[Dict[str, np.ndarray]], model, num_reg_iter: int = 5, dataset_type: str = "3DMatch",
-                    batch: int = 1, device: Optional[torch.device] = None, dist=None):
+                    batch: int = 1, device: Optional[torch.device] = None, dist=None, pose_opt: Optional[str] = None,
+                    voxel_size: float = 0.3):
     """pairs: sequence of dicts with ``points_src/points_ref [1,N,C]``, ``transform_gt [1,3,4]`` and optionally the
     pyramid tensors and ``others`` (as the reference's collate, data_base.py:196-219).
     Returns (pred_transforms_all [n_pairs, n_iter+1, 3, 4], stats [n_pairs, 5]) gathered over ranks."""
@@ -45,7 +46,16 @@ def inference_align(pairs: Sequence[Dict[str, np.ndarray]], model, num_reg_iter:
         transforms, endpoints = model(data, opt)
         torch.cuda.synchronize(device)
         dt = (time.time() - t0) / len(ids)
-        transforms.append(transforms[-1].detach())            # pose_optimization == identity (test.py:406-408)
+        if pose_opt == "icp":
+            # pose_optimization with use_icp (test.py:241-258; off in the reference): point-to-point ICP on the raw clouds,
+            # correspondence radius 2 x voxel size (test.py:219), open3d's default criteria
+            T_opt, _ = model._engine.icp_refine(data["points_src"].float(), data["points_ref"].float(),
+                                                transforms[-1].contiguous(), 2.0 * voxel_size)
+            transforms.append(T_opt)
+        elif pose_opt is None:
+            transforms.append(transforms[-1].detach())        # pose_optimization == identity (test.py:215-216, :406-408)
+        else:
+            raise ValueError("pose_opt must be None or 'icp' (the Adam fine-tune branch, test.py:159-207, is not built)")
         T = torch.stack(transforms, dim=1).cpu().numpy()      # [B, n_iter+1, 3, 4]
         preds.append(T)
         gt = data["transform_gt"].cpu().numpy()

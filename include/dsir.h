@@ -213,6 +213,19 @@ int dsir_eval_metrics(dsir_ctx* ctx, const float* pred_T, int64_t pred_stride, c
                       const float* points_src, const float* points_ref, int pairs, int n, int stride,
                       float rte_thresh, float rre_thresh, double* out);
 
+/* ---- after the path: pose refinement --------------- */
+
+/* Replaces the `use_icp` branch of pose_optimization (test.py:241-258): open3d
+ *   registration_icp(src, tgt, max_correspondence_distance, T_init, TransformationEstimationPointToPoint(),
+ *                    ICPConvergenceCriteria(relative_fitness, relative_rmse, max_iteration))
+ * for P pairs at once, entirely on device.  points_src [P][J][stride], points_ref [P][K][stride] (xyz first);
+ * T_init / T_out [P][3][4]; stats [P][4] float64 {fitness, inlier_rmse, converged (0/1), iterations} or NULL.
+ * The branch is disabled in the reference and open3d is not pinned: the rule (open3d's RegistrationICP loop, exact
+ * brute-force nearest neighbours in fp32 with ties to the lower index) is restated in oracle/icp.py. */
+int dsir_icp_refine(dsir_ctx* ctx, const float* points_src, const float* points_ref, int pairs, int J, int K, int stride,
+                    float max_corr_dist, int max_iter, float rel_fitness, float rel_rmse, const float* T_init,
+                    float* T_out, double* stats);
+
 /* Launch-bound small batches: capture the whole dsir_register launch sequence into a hipGraph once per
  * call signature (sizes and buffer addresses) and replay it.  Off by default. */
 int dsir_enable_graph(dsir_ctx* ctx, int enable);
