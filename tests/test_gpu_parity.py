@@ -485,3 +485,43 @@ def test_64k_partial_overlap_properties():
     assert idx.min() >= 0 and idx.max() < 65536 and np.isfinite(a["logits"].cpu().numpy()).all()
     assert int(a["invalid"][0]) == 0
     eng.close()
+
+
+def test_error_paths_fail_loudly():
+    """Unsupported / inconsistent arguments are rejected with a message (never a silent fallback, never a fault)."""
+    from deepsir_amd.arch import NetConfig
+    from deepsir_amd.engine import Engine, EngineError
+    from deepsir_amd.weights import generate_state_dict
+    cfg = NetConfig(feat_len=3)
+    sd = generate_state_dict(cfg, 0)
+    eng = Engine(cfg, 0, max_points=2048, max_pairs=2)
+    x = torch.rand(1, 2048, 3, device=_dev())
+    with pytest.raises(EngineError, match="not finalized"):
+        eng.register(x, x, 2)                                          # weights missing
+    bad = dict(sd); bad["mlp_proj.0.weight"] = np.zeros((64, 32), np.float32)
+    with pytest.raises(EngineError, match="size mismatch"):
+        eng.load_state_dict(bad)
+    short = dict(sd); short.pop("mlp_att.12.bias")
+    with pytest.raises(EngineError, match="missing keys"):
+        eng.load_state_dict(short)
+    eng.load_state_dict(sd)
+    with pytest.raises(EngineError, match="max_points"):
+        eng.register(torch.rand(1, 4096, 3, device=_dev()), torch.rand(1, 4096, 3, device=_dev()), 2)
+    with pytest.raises(EngineError, match="pairs="):
+        eng.register(torch.rand(3, 2048, 3, device=_dev()), torch.rand(3, 2048, 3, device=_dev()), 2)
+    with pytest.raises(EngineError, match="n_iter|null argument"):
+        eng.register(x, x, 0)
+    with pytest.raises(EngineError, match="channels"):
+        eng.register(torch.rand(1, 2048, 4, device=_dev()), torch.rand(1, 2048, 4, device=_dev()), 2)
+    with pytest.raises(EngineError, match="CUDA tensor"):
+        eng.register(x.cpu(), x.cpu(), 2)
+    with pytest.raises(EngineError, match="too small|at least"):
+        eng.register(torch.rand(1, 512, 3, device=_dev()), torch.rand(1, 512, 3, device=_dev()), 2)
+    with pytest.raises(EngineError, match="feat pipeline"):
+        eng.forward_pair(x, x, 128)                                    # top-k selection on an align context
+    with pytest.raises(EngineError, match="bad arguments"):
+        eng.icp_refine(x, x, torch.eye(3, 4, device=_dev())[None], -1.0)
+    # after all the rejected calls the context is still healthy
+    out = eng.register(x, x, 2)
+    assert torch.isfinite(out["transforms"]).all()
+    eng.close()
