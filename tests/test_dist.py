@@ -2,6 +2,8 @@
 import os
 import socket
 
+import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -54,3 +56,26 @@ def test_two_rank_shard_and_gather():
         assert p.exitcode == 0
     assert ids == [float(i) for i in range(n_pairs)]
     assert eq == [0.0] * 3 + [1.0] * 3
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_gpu_match_single_process(tmp_path):
+    """examples/eval_multi_gpu.py with 2 ranks (gloo: both on the one GPU of the test box) and alone: the gathered
+    per-pair transforms are identical — sharding changes which process registers a pair, never its result."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(root, "examples", "eval_multi_gpu.py")
+    one, two = str(tmp_path / "one.npz"), str(tmp_path / "two.npz")
+    common = ["--pairs", "6", "--points", "2048", "--batch", "2", "--iters", "3"]
+    r1 = subprocess.run([sys.executable, script] + common + ["--out", one], capture_output=True, text=True, timeout=600)
+    assert r1.returncode == 0, r1.stdout + r1.stderr
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                         "127.0.0.1", "--master-port", "29541", script] + common + ["--backend", "gloo", "--out", two],
+                        capture_output=True, text=True, timeout=600)
+    assert r2.returncode == 0, r2.stdout + r2.stderr
+    a, b = np.load(one), np.load(two)
+    assert a["pred"].shape == b["pred"].shape == (6, 4, 3, 4)
+    assert np.array_equal(a["pred"], b["pred"])
+    assert np.array_equal(a["stats"][:, :3], b["stats"][:, :3])
