@@ -35,7 +35,7 @@ def match_flops(P, J, K):
     return float(P) * (128.0 * J * K + 3.0 * J * K)
 
 
-def cpu_baseline(cfg, sd, n_points, n_iter, budget_s=25.0):
+def cpu_baseline(cfg, sd, n_points, n_iter, budget_s=15.0):
     """The oracle (CPU port of the reference path) timed on this box's host cores.
     Model-only window, as the reference times it (test.py:399-402): the KNN pyramid is built beforehand."""
     from deepsir_amd.synth import make_pair
@@ -56,7 +56,8 @@ def cpu_baseline(cfg, sd, n_points, n_iter, budget_s=25.0):
     warm = time.time() - t0
     times = []
     t_end = time.time() + budget_s
-    while (len(times) < 3 and warm < budget_s / 3) or (time.time() < t_end and len(times) < 12):
+    # ~15 s of CPU work (bounded sample): at least 3 runs, at most 60
+    while (len(times) < 3 and warm < budget_s / 3) or (time.time() < t_end and len(times) < 60):
         t0 = time.time()
         net.register(data, n_iter)
         times.append(time.time() - t0)
