@@ -928,6 +928,17 @@ static int register_enqueue(dsir_ctx* c, const dsir_pair_batch* in, int n_iter, 
   int32_t* idx_it = ws.get<int32_t>((size_t)P * J);
   float* T_it = ws.get<float>((size_t)P * 12);
   void* match_scratch = ws.raw(nn_match_scratch_bytes(P, J, K));
+  // fp16-screened arg-min (nn_screen.hip): split descriptors, norms, candidate scratch.  The ref side is loop invariant.
+  static const bool no_screen = getenv("DSIR_NO_SCREEN") != nullptr;   // A/B switch: exhaustive fp32 kernel
+  const bool screen = !no_screen && !in->forced_idx;
+  void *sc_ah = nullptr, *sc_al = nullptr, *sc_bh = nullptr, *sc_bl = nullptr, *sc_scratch = nullptr;
+  float *sc_sa = nullptr, *sc_sb = nullptr;
+  if (screen) {
+    sc_ah = ws.raw((size_t)P * J * 64 * 2); sc_al = ws.raw((size_t)P * J * 64 * 2);
+    sc_bh = ws.raw((size_t)P * K * 64 * 2); sc_bl = ws.raw((size_t)P * K * 64 * 2);
+    sc_sa = ws.get<float>((size_t)P * J); sc_sb = ws.get<float>((size_t)P * K);
+    sc_scratch = ws.raw(nn_screen_scratch_bytes(P, J));
+  }
   // persistent storage of the inlier model's position-encoding branch (EncCache), alive across the iterations
   EncCache enc_cache;
   static const bool no_hoist = getenv("DSIR_NO_HOIST") != nullptr;   // A/B switch
@@ -953,6 +964,10 @@ static int register_enqueue(dsir_ctx* c, const dsir_pair_batch* in, int n_iter, 
     float* F_r = run_mlp_feat(c, feat_r, P, K);
     run_att_proj(c, rxyz, (int64_t)pr.S * 3, score_r, F_r, P, K, desc_r);
     ws.release(mark1);
+    if (screen) {
+      launch_split16(desc_r, (int64_t)P * K, sc_bh, sc_bl, st);
+      launch_sqnorm(desc_r, (int64_t)P * K, sc_sb, st);
+    }
     float* F_tmp = run_mlp_feat(c, feat_s, P, J);
     HIP_OK(c, hipMemcpyAsync(F_s, F_tmp, sizeof(float) * P * J * 64, hipMemcpyDeviceToDevice, st));
     ws.release(mark1);
@@ -981,7 +996,13 @@ static int register_enqueue(dsir_ctx* c, const dsir_pair_batch* in, int n_iter, 
         e0 = c->match_events[c->match_events_used].first; e1 = c->match_events[c->match_events_used].second;
         ++c->match_events_used;
       }
-      launch_nn_match_ws(desc_s, desc_r, P, J, K, idx_out, match_scratch, st, e0, e1, /*ref_norms_cached=*/it > 0, match_ts_slot(c));
+      if (screen) {
+        launch_split16(desc_s, (int64_t)P * J, sc_ah, sc_al, st);
+        launch_sqnorm(desc_s, (int64_t)P * J, sc_sa, st);
+        launch_nn_screen(desc_s, desc_r, sc_ah, sc_al, sc_bh, sc_bl, sc_sa, sc_sb, P, J, K, idx_out, sc_scratch, st, e0, e1);
+      } else {
+        launch_nn_match_ws(desc_s, desc_r, P, J, K, idx_out, match_scratch, st, e0, e1, /*ref_norms_cached=*/it > 0, match_ts_slot(c));
+      }
     }
     // inlier RandLA on [xyz_src(t); xyz_ref[idx]] with the SRC pyramid (model.py:574-577)
     const Seg s0 = plain_seg(xyz_cur, (int64_t)J * 3, 3, 3);

@@ -157,6 +157,15 @@ void launch_nn_match_ws(const float* a, const float* b, int pairs, int J, int K,
                         hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, bool ref_norms_cached = false,
                         unsigned long long* tstamp = nullptr);   // tstamp: {min start, max end} device-clock slot or nullptr
 
+void launch_sqnorm(const float* x, int64_t rows, float* out, hipStream_t st);   // |x|^2 of [rows][64], nn_match's order
+
+// nn_screen.hip — the same arg-min, screened with fp16 MFMAs under a rigorous bound and decided in exact fp32
+size_t nn_screen_scratch_bytes(int pairs, int J);
+void launch_split16(const float* x, int64_t rows, void* hi, void* lo, hipStream_t st);   // fp32 [rows][64] -> fp16 hi / lo
+void launch_nn_screen(const float* a, const float* b, const void* ah, const void* al, const void* bh, const void* bl,
+                      const float* sa, const float* sb, int pairs, int J, int K, int32_t* idx, void* scratch, hipStream_t st,
+                      hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+
 // weighted Kabsch + SE(3) bookkeeping (model.py:22-66, :586-595; se3_torch.py:28-77)
 struct KabschArgs {
   const float* src;      // [pairs][m][3]  current (transformed) src points

@@ -186,6 +186,11 @@ __global__ void unpack_idx_kernel(const unsigned long long* __restrict__ packed,
 
 }  // namespace
 
+void launch_sqnorm(const float* x, int64_t rows, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, st, x, rows, out,
+                     (unsigned long long*)nullptr);
+}
+
 // scratch layout (floats): sa[pairs*J] | sb[pairs*K] | packed (u64)[pairs*J]
 size_t nn_match_scratch_bytes(int pairs, int J, int K) {
   size_t f = ((size_t)pairs * J + (size_t)pairs * K + 3) & ~(size_t)3;
