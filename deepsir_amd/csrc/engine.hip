@@ -793,6 +793,34 @@ int dsir_nn_match(dsir_ctx* c, const float* a, const float* b, int pairs, int J,
   return post(c);
 }
 
+int dsir_nn_match_screened(dsir_ctx* c, const float* a, const float* b, int pairs, int J, int K, int32_t* idx,
+                           int64_t* stats) {
+  if (!c) return 1;
+  if (!a || !b || !idx || pairs < 1 || J < 1 || K < 1) return fail(c, "dsir_nn_match_screened: bad arguments");
+  HIP_OK(c, hipSetDevice(c->device));
+  c->ws.top = 0; c->ws.overflow = false;
+  Arena& ws = c->ws;
+  void* ah = ws.raw((size_t)pairs * J * 128); void* al = ws.raw((size_t)pairs * J * 128);
+  void* bh = ws.raw((size_t)pairs * K * 128); void* bl = ws.raw((size_t)pairs * K * 128);
+  float* sa = ws.get<float>((size_t)pairs * J); float* sb = ws.get<float>((size_t)pairs * K);
+  void* scratch = ws.raw(nn_screen_scratch_bytes(pairs, J));
+  unsigned long long* dstats = ws.get<unsigned long long>(2);
+  if (ws.overflow) return fail(c, "workspace exhausted in nn_match_screened");
+  hipStream_t st = c->stream;
+  launch_split16(a, (int64_t)pairs * J, ah, al, st);
+  launch_split16(b, (int64_t)pairs * K, bh, bl, st);
+  launch_sqnorm(a, (int64_t)pairs * J, sa, st);
+  launch_sqnorm(b, (int64_t)pairs * K, sb, st);
+  launch_nn_screen(a, b, ah, al, bh, bl, sa, sb, pairs, J, K, idx, scratch, st, nullptr, nullptr, stats ? dstats : nullptr);
+  if (stats) {
+    HIP_OK(c, hipStreamSynchronize(st));
+    unsigned long long h[2];
+    HIP_OK(c, hipMemcpy(h, dstats, 16, hipMemcpyDeviceToHost));
+    stats[0] = (int64_t)h[0]; stats[1] = (int64_t)h[1];
+  }
+  return post(c);
+}
+
 int dsir_kabsch(dsir_ctx* c, const float* src, const float* tgt, const float* w, int pairs, int m, float* T,
                 int32_t* invalid) {
   if (!c) return 1;
@@ -930,7 +958,9 @@ static int register_enqueue(dsir_ctx* c, const dsir_pair_batch* in, int n_iter, 
   void* match_scratch = ws.raw(nn_match_scratch_bytes(P, J, K));
   // fp16-screened arg-min (nn_screen.hip): split descriptors, norms, candidate scratch.  The ref side is loop invariant.
   static const bool no_screen = getenv("DSIR_NO_SCREEN") != nullptr;   // A/B switch: exhaustive fp32 kernel
-  const bool screen = !no_screen && !in->forced_idx;
+  // both paths return the same bits, so the choice is free: small problems (latency-bound, e.g. one pair in flight) take
+  // the single exhaustive kernel, large ones the three-kernel screened path
+  const bool screen = !no_screen && !in->forced_idx && (int64_t)P * J * K >= 200000000ll;
   void *sc_ah = nullptr, *sc_al = nullptr, *sc_bh = nullptr, *sc_bl = nullptr, *sc_scratch = nullptr;
   float *sc_sa = nullptr, *sc_sb = nullptr;
   if (screen) {

@@ -164,7 +164,7 @@ size_t nn_screen_scratch_bytes(int pairs, int J);
 void launch_split16(const float* x, int64_t rows, void* hi, void* lo, hipStream_t st);   // fp32 [rows][64] -> fp16 hi / lo
 void launch_nn_screen(const float* a, const float* b, const void* ah, const void* al, const void* bh, const void* bl,
                       const float* sa, const float* sb, int pairs, int J, int K, int32_t* idx, void* scratch, hipStream_t st,
-                      hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+                      hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, unsigned long long* stats = nullptr);
 
 // weighted Kabsch + SE(3) bookkeeping (model.py:22-66, :586-595; se3_torch.py:28-77)
 struct KabschArgs {

@@ -32,7 +32,10 @@ namespace {
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 
-constexpr int SBC = 64;     // ref columns per LDS tile
+#ifndef DSIR_SCREEN_BC
+#define DSIR_SCREEN_BC 64
+#endif
+constexpr int SBC = DSIR_SCREEN_BC;   // ref columns per LDS tile
 constexpr int SRS = 72;     // halfs per LDS row: 64 + 8 pad (144 B: the 16 lanes of a ds_read_b128 group hit 16 distinct bank quads)
 constexpr int CAP = 16;     // candidates kept per row; more => exhaustive exact scan of that row
 constexpr float kC2 = 1.0f / 16384.0f;
@@ -111,8 +114,9 @@ __global__ __launch_bounds__(NWV * 64) void screen_kernel(const _Float16* __rest
   const int c_begin = split * cols_per_split;
   const int c_end = min(K, c_begin + cols_per_split);
   // staging: thread -> 16-byte piece (8 channels) f of the tile: column f >> 3, piece f & 7; 512 pieces per part
-  constexpr int NP = (NWV * 64 >= 512) ? 1 : 512 / (NWV * 64);
-  const bool stager = NWV * 64 <= 512 || tid < 512;
+  constexpr int PIECES = SBC * 8;   // 16-byte pieces per part of a tile
+  constexpr int NP = (NWV * 64 >= PIECES) ? 1 : PIECES / (NWV * 64);
+  const bool stager = NWV * 64 <= PIECES || tid < PIECES;
   h8 pre[NB][NP];
   float pre_sb = 0.f;
   auto gload = [&](int c0) {
@@ -266,6 +270,18 @@ __global__ __launch_bounds__(256) void exact_pick_kernel(const float* __restrict
   if (live && l == 0) idx[row] = (int32_t)(best & 0xffffffffull);
 }
 
+// diagnostics: out[0] = total candidates, out[1] = rows scanned exhaustively (candidate list overflowed)
+__global__ void screen_stats_kernel(const int32_t* __restrict__ cnt, int64_t rows, unsigned long long* __restrict__ out) {
+  unsigned long long c = 0, o = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += (int64_t)gridDim.x * blockDim.x) {
+    const int n = cnt[i];
+    c += (unsigned long long)(n > 0 ? n : 0);
+    o += (n > CAP || n <= 0) ? 1ull : 0ull;
+  }
+  if (c) atomicAdd(out, c);
+  if (o) atomicAdd(out + 1, o);
+}
+
 inline int grid_for(int64_t n) { const int64_t g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > 65535 ? 65535 : g)); }
 
 }  // namespace
@@ -285,7 +301,7 @@ void launch_split16(const float* x, int64_t rows, void* hi, void* lo, hipStream_
 // a, b: fp32 descriptors [pairs][J|K][64] with their fp16 splits (ah, al, bh, bl) and squared norms (sa, sb)
 void launch_nn_screen(const float* a, const float* b, const void* ah, const void* al, const void* bh, const void* bl,
                       const float* sa, const float* sb, int pairs, int J, int K, int32_t* idx, void* scratch, hipStream_t st,
-                      hipEvent_t ev0, hipEvent_t ev1) {
+                      hipEvent_t ev0, hipEvent_t ev1, unsigned long long* stats) {
   const size_t rows = (size_t)pairs * J;
   char* p = reinterpret_cast<char*>(scratch);
   auto take = [&](size_t bytes) { char* r = p; p += (bytes + 255) & ~(size_t)255; return r; };
@@ -326,6 +342,10 @@ void launch_nn_screen(const float* a, const float* b, const void* ah, const void
   hipLaunchKernelGGL(exact_pick_kernel, dim3((unsigned)((rows * 16 + 255) / 256)), dim3(256), 0, st, a, b, sa, sb, J, K,
                      (int64_t)rows, cnt, cand, idx);
   if (ev1) (void)hipEventRecord(ev1, st);
+  if (stats) {
+    (void)hipMemsetAsync(stats, 0, 16, st);
+    hipLaunchKernelGGL(screen_stats_kernel, dim3(256), dim3(256), 0, st, cnt, (int64_t)rows, stats);
+  }
 }
 
 }  // namespace dsir

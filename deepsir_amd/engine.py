@@ -193,6 +193,20 @@ class Engine:
             self.sync()
         return idx
 
+    def nn_match_screened(self, desc_src, desc_ref, want_stats=True):
+        """Same arg-min as nn_match, computed the way dsir_register does (fp16-split screening + exact fp32 decision).
+        Returns (idx [p,J] i32, (total candidates, exhaustively scanned rows))."""
+        desc_src, desc_ref = _chk(desc_src, torch.float32, "desc_src"), _chk(desc_ref, torch.float32, "desc_ref")
+        p, J, _ = desc_src.shape
+        K = desc_ref.shape[1]
+        idx = self._empty((p, J), torch.int32)
+        st = (C.c_int64 * 2)()
+        self._pre()
+        self._call(self.lib.dsir_nn_match_screened(self.h, _ptr(desc_src), _ptr(desc_ref), p, J, K, _ptr(idx),
+                                                   st if want_stats else None))
+        self.sync()
+        return idx, (int(st[0]), int(st[1]))
+
     def kabsch(self, src, tgt, w):
         """compute_rigid_transform_2 counterpart -> (T [p,3,4], invalid [p] i32)."""
         src, tgt = _chk(src, torch.float32, "src"), _chk(tgt, torch.float32, "tgt")

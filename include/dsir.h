@@ -125,6 +125,13 @@ int dsir_aggregate(dsir_ctx* ctx, const float* xyz, int64_t xyz_cloud_stride, co
  * desc_src [pairs][J][64], desc_ref [pairs][K][64] -> idx [pairs][J] i32. */
 int dsir_nn_match(dsir_ctx* ctx, const float* desc_src, const float* desc_ref, int pairs, int J, int K, int32_t* idx);
 
+/* The same arg-min as dsir_nn_match, bit for bit, the way dsir_register computes it: columns are first discarded by an
+ * fp16-split MFMA screening with a rigorous error bound, the exact fp32 formula then decides among the survivors
+ * (csrc/nn_screen.hip).  Assumes |descriptor| <= ~1 per component (fp16 range; descriptors are L2-normalised).
+ * stats (HOST, optional): [0] = total surviving candidates, [1] = rows that fell back to the exhaustive exact scan. */
+int dsir_nn_match_screened(dsir_ctx* ctx, const float* desc_src, const float* desc_ref, int pairs, int J, int K,
+                           int32_t* idx, int64_t* stats);
+
 /* Replaces compute_rigid_transform_2 (network/model.py:22-66): weighted
  * Kabsch with fp64 3x3 SVD on device.  src/tgt [pairs][m][3], w [pairs][m]
  * -> T [pairs][3][4] f32, invalid [pairs] i32 (1 = non-finite covariance,

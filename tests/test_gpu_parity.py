@@ -525,3 +525,43 @@ def test_error_paths_fail_loudly():
     out = eng.register(x, x, 2)
     assert torch.isfinite(out["transforms"]).all()
     eng.close()
+
+
+@pytest.mark.parametrize("kind", ["random", "near_matches", "duplicates", "near_ties", "clustered"])
+def test_screened_argmin_equals_exhaustive(kind):
+    """csrc/nn_screen.hip (fp16-split screening under a rigorous bound, exact fp32 decision) must return the arg-min of
+    the exhaustive exact-fp32 kernel on every row — including exact duplicates (tie -> lower index), distances closer than
+    fp32 resolution of the screening values, and candidate-list overflow (exhaustive fallback)."""
+    from deepsir_amd.arch import NetConfig
+    from deepsir_amd.engine import Engine
+    rng = np.random.Generator(np.random.Philox(key=hash(kind) % 1000))
+    P, J, K = 2, 3001, 2777
+    a = rng.standard_normal((P, J, 64)).astype(np.float32)
+    b = rng.standard_normal((P, K, 64)).astype(np.float32)
+    if kind == "near_matches":
+        b[:, :2000] = a[:, :2000] + rng.standard_normal((P, 2000, 64)).astype(np.float32) * 1e-3
+    elif kind == "duplicates":
+        b[:, 100:600] = b[:, 1100:1600]                     # exact ties between far-apart indices
+        b[:, 2000:2040] = b[:, 1999:2000]                   # 41 identical columns: more than the candidate cap
+        a[:, :40] = b[:, 1999:2000]
+    elif kind == "near_ties":
+        base = rng.standard_normal((P, 1, 64)).astype(np.float32)
+        b[:, :1500] = base + rng.standard_normal((P, 1500, 64)).astype(np.float32) * 3e-6   # 1500 columns within ~1e-5
+        a[:, :500] = base + rng.standard_normal((P, 500, 64)).astype(np.float32) * 3e-6
+    elif kind == "clustered":
+        centers = rng.standard_normal((P, 8, 64)).astype(np.float32)
+        b = centers[:, rng.integers(0, 8, K)][np.arange(P)[:, None], np.arange(K)[None, :]] if False else \
+            centers[:, rng.integers(0, 8, K)] + rng.standard_normal((P, K, 64)).astype(np.float32) * 1e-2
+        a = centers[:, rng.integers(0, 8, J)] + rng.standard_normal((P, J, 64)).astype(np.float32) * 1e-2
+    a /= np.linalg.norm(a, axis=2, keepdims=True)
+    b /= np.linalg.norm(b, axis=2, keepdims=True)
+    eng = Engine(NetConfig(), 0, max_points=4096, max_pairs=2)
+    ta, tb = cu(a.astype(np.float32)), cu(b.astype(np.float32))
+    exact = eng.nn_match(ta, tb).cpu().numpy()
+    scr, (ncand, nexh) = eng.nn_match_screened(ta, tb)
+    scr = scr.cpu().numpy()
+    print(f"[screen] {kind}: {ncand / (P * J):.2f} candidates per row, {nexh} of {P * J} rows scanned exhaustively")
+    assert np.array_equal(scr, exact)
+    if kind in ("duplicates", "near_ties"):
+        assert nexh > 0            # the overflow path is exercised
+    eng.close()

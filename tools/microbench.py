@@ -19,7 +19,7 @@ from deepsir_amd.engine import Engine
 from deepsir_amd.weights import generate_state_dict
 
 ap = argparse.ArgumentParser()
-ap.add_argument("what", choices=["aggregate", "randla", "inlier", "match", "knn", "score"])
+ap.add_argument("what", choices=["aggregate", "randla", "inlier", "match", "match_screened", "knn", "score"])
 ap.add_argument("--clouds", type=int, default=16)
 ap.add_argument("--n", type=int, default=5000)
 ap.add_argument("--reps", type=int, default=20)
@@ -46,6 +46,8 @@ def run():
         eng.randla_forward("inlier_model", torch.cat([pts, pts], 2), xyz, neigh, sub, interp)
     elif a.what == "match":
         eng.nn_match(desc, desc.flip(0))
+    elif a.what == "match_screened":
+        eng.nn_match_screened(desc, desc.flip(0), want_stats=False)
     elif a.what == "knn":
         eng.knn_pyramid(pts)
     elif a.what == "score":
