@@ -1029,7 +1029,8 @@ static int register_enqueue(dsir_ctx* c, const dsir_pair_batch* in, int n_iter, 
       if (screen) {
         launch_split16(desc_s, (int64_t)P * J, sc_ah, sc_al, st);
         launch_sqnorm(desc_s, (int64_t)P * J, sc_sa, st);
-        launch_nn_screen(desc_s, desc_r, sc_ah, sc_al, sc_bh, sc_bl, sc_sa, sc_sb, P, J, K, idx_out, sc_scratch, st, e0, e1);
+        launch_nn_screen(desc_s, desc_r, sc_ah, sc_al, sc_bh, sc_bl, sc_sa, sc_sb, P, J, K, idx_out, sc_scratch, st, e0, e1, nullptr,
+                         /*keep_gate=*/it > 0);
       } else {
         launch_nn_match_ws(desc_s, desc_r, P, J, K, idx_out, match_scratch, st, e0, e1, /*ref_norms_cached=*/it > 0, match_ts_slot(c));
       }

@@ -156,6 +156,11 @@ size_t nn_match_scratch_bytes(int pairs, int J, int K);
 void launch_nn_match_ws(const float* a, const float* b, int pairs, int J, int K, int32_t* idx, void* scratch,
                         hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, bool ref_norms_cached = false,
                         unsigned long long* tstamp = nullptr);   // tstamp: {min start, max end} device-clock slot or nullptr
+// exhaustive search of all rows of the pairs with gate[pair] >= gate_min and of the rows rowlist[pair][0 .. gate[pair]) of
+// the others; results left in `packed` (preset to all ones)
+void launch_nn_match_gated(const float* a, const float* b, const float* sa, const float* sb, int pairs, int J, int K,
+                           unsigned long long* packed, const int32_t* gate, int gate_min, const int32_t* rowlist,
+                           hipStream_t st);
 
 void launch_sqnorm(const float* x, int64_t rows, float* out, hipStream_t st);   // |x|^2 of [rows][64], nn_match's order
 
@@ -164,7 +169,8 @@ size_t nn_screen_scratch_bytes(int pairs, int J);
 void launch_split16(const float* x, int64_t rows, void* hi, void* lo, hipStream_t st);   // fp32 [rows][64] -> fp16 hi / lo
 void launch_nn_screen(const float* a, const float* b, const void* ah, const void* al, const void* bh, const void* bl,
                       const float* sa, const float* sb, int pairs, int J, int K, int32_t* idx, void* scratch, hipStream_t st,
-                      hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, unsigned long long* stats = nullptr);
+                      hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, unsigned long long* stats = nullptr,
+                      bool keep_gate = false);   // keep_gate: pairs found not selective by the previous call on this scratch stay exhaustive
 
 // weighted Kabsch + SE(3) bookkeeping (model.py:22-66, :586-595; se3_torch.py:28-77)
 struct KabschArgs {

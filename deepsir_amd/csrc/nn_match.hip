@@ -52,7 +52,9 @@ __global__ __launch_bounds__(256) void nn_match_kernel(const float* __restrict__
                                                        const float* __restrict__ sa, const float* __restrict__ sb,
                                                        int J, int K, int cols_per_split, int rb_count, int splits,
                                                        unsigned long long* __restrict__ packed,
-                                                       unsigned long long* __restrict__ tstamp) {
+                                                       unsigned long long* __restrict__ tstamp,
+                                                       const int32_t* __restrict__ gate, int gate_min,
+                                                       const int32_t* __restrict__ rowlist) {
   // measurement hook: first-wave start / last-wave end on the device's constant-rate clock (what a kernel trace reports)
   if (tstamp && threadIdx.x == 0) atomicMin(tstamp, (unsigned long long)wall_clock64());
   __shared__ float Bs[2][BC * LDB];   // double-buffered ref tile
@@ -69,6 +71,21 @@ __global__ __launch_bounds__(256) void nn_match_kernel(const float* __restrict__
   const int rb = wi % rb_count;
   const int split = (wi / rb_count) % splits;
   const int pair = wi / (rb_count * splits);
+  // fallback use (nn_screen.hip), block-uniform exits before any barrier.  gate[pair] = src rows of the pair whose
+  // screening failed.  Without a row list: all rows of the pairs with gate >= gate_min.  With one: only the listed rows
+  // (rowlist[pair][0 .. gate)) of the pairs with gate < gate_min.
+  int vJ = J;
+  if (gate) {
+    const int g = gate[pair];
+    if (rowlist) {
+      if (g >= gate_min || rb * (64 * RT) >= g) return;
+      vJ = g;
+    } else if (g < gate_min) {
+      return;
+    }
+  }
+  const int32_t* lst = rowlist ? rowlist + (int64_t)pair * J : nullptr;
+  auto rowof = [&](int v) { return v < vJ ? (lst ? lst[v] : v) : -1; };
   const float* Ap = A + (int64_t)pair * J * 64;
   const float* Bp = B + (int64_t)pair * K * 64;
   const int row0 = (rb * 4 + w) * (16 * RT);
@@ -78,13 +95,13 @@ __global__ __launch_bounds__(256) void nn_match_kernel(const float* __restrict__
   float san[RT][4];
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
-    const int row = row0 + rt * 16 + fr;
+    const int row = rowof(row0 + rt * 16 + fr);
 #pragma unroll
-    for (int s = 0; s < 16; ++s) af[rt][s] = row < J ? Ap[(int64_t)row * 64 + 4 * s + fq] : 0.f;
+    for (int s = 0; s < 16; ++s) af[rt][s] = row >= 0 ? Ap[(int64_t)row * 64 + 4 * s + fq] : 0.f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int rr = row0 + rt * 16 + 4 * fq + r;
-      san[rt][r] = rr < J ? sa[(int64_t)pair * J + rr] : 0.f;
+      const int rr = rowof(row0 + rt * 16 + 4 * fq + r);
+      san[rt][r] = rr >= 0 ? sa[(int64_t)pair * J + rr] : 0.f;
     }
   }
   float best[RT][4];
@@ -170,8 +187,8 @@ __global__ __launch_bounds__(256) void nn_match_kernel(const float* __restrict__
         const int i2 = __shfl_xor(ix, o);
         if (d2 < d || (d2 == d && i2 < ix)) { d = d2; ix = i2; }
       }
-      const int row = row0 + rt * 16 + 4 * fq + r;
-      if (fr == 0 && row < J && ix != 0x7fffffff) {
+      const int row = rowof(row0 + rt * 16 + 4 * fq + r);
+      if (fr == 0 && row >= 0 && ix != 0x7fffffff) {
         const unsigned long long key = ((unsigned long long)order_bits(d) << 32) | (unsigned int)ix;
         atomicMin(packed + (int64_t)pair * J + row, key);
       }
@@ -197,29 +214,26 @@ size_t nn_match_scratch_bytes(int pairs, int J, int K) {
   return f * 4 + (size_t)pairs * J * 8;
 }
 
-void launch_nn_match_ws(const float* a, const float* b, int pairs, int J, int K, int32_t* idx, void* scratch,
-                        hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, bool ref_norms_cached, unsigned long long* tstamp) {
-  float* sa = reinterpret_cast<float*>(scratch);
-  float* sb = sa + (size_t)pairs * J;
-  size_t f = ((size_t)pairs * J + (size_t)pairs * K + 3) & ~(size_t)3;
-  unsigned long long* packed = reinterpret_cast<unsigned long long*>(sa + f);
-  const int64_t ra = (int64_t)pairs * J, rb = (int64_t)pairs * K;
-  hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)((ra + 15) / 16)), dim3(256), 0, st, a, ra, sa, packed);
-  // the ref descriptors are loop invariant in dsir_register: their norms stay in the (persistent) scratch
-  if (!ref_norms_cached) hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)((rb + 15) / 16)), dim3(256), 0, st, b, rb, sb, nullptr);
+// the exhaustive kernel over [pairs] x J x K with norms and the packed result slots supplied (slots preset to all ones)
+static void launch_core(const float* a, const float* b, const float* sa, const float* sb, int pairs, int J, int K,
+                        unsigned long long* packed, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1,
+                        unsigned long long* tstamp, const int32_t* gate, int gate_min, const int32_t* rowlist = nullptr) {
   // geometry: 2 row tiles per wave (128-row blocks) once there is enough work, else 64-row blocks; the ref
   // range is split so that the grid is a whole number of residency rounds (256 CUs x 4 blocks: 34 KB LDS each)
   static const int force_rt = getenv("DSIR_MATCH_RT") ? atoi(getenv("DSIR_MATCH_RT")) : 0;   // tuning hook
   int rt = (int64_t)pairs * ((J + 127) / 128) >= 256 ? 2 : 1;
   if (force_rt == 1 || force_rt == 2 || force_rt == 4) rt = force_rt;
+  if (rowlist) rt = 1;                          // few rows per pair: small row blocks, the ref range split as far as it goes
   const int rows_per_block = 64 * rt;
   const int resident = rt == 4 ? 768 : 1024;   // blocks the chip holds at once (VGPR- resp. LDS-limited)
-  const int rb_count = (J + rows_per_block - 1) / rows_per_block;
+  // a row list holds fewer than gate_min rows
+  const int rb_count = ((rowlist ? (gate_min < J ? gate_min : J) : J) + rows_per_block - 1) / rows_per_block;
   const int64_t base = (int64_t)pairs * rb_count;
   const int tiles = (K + BC - 1) / BC;
   int splits = 1;
   double best_eff = -1.0;
-  for (int sp = 1; sp <= 16 && sp <= tiles; ++sp) {
+  if (rowlist) { splits = tiles / 8 < 1 ? 1 : (tiles / 8 > 16 ? 16 : tiles / 8); best_eff = 2.0; }
+  for (int sp = 1; sp <= 16 && sp <= tiles && !rowlist; ++sp) {
     const int tiles_per = (tiles + sp - 1) / sp;
     if (sp > 1 && tiles_per < 8) break;                    // keep the A-fragment preload amortised
     const int nsp = (tiles + tiles_per - 1) / tiles_per;
@@ -235,11 +249,34 @@ void launch_nn_match_ws(const float* a, const float* b, int pairs, int J, int K,
   splits = (K + cols - 1) / cols;
   dim3 grid((unsigned)((int64_t)rb_count * splits * pairs));
   if (ev0) hipEventRecord(ev0, st);
-  if (rt == 4)      hipLaunchKernelGGL((nn_match_kernel<4>), grid, dim3(256), 0, st, a, b, sa, sb, J, K, cols, rb_count, splits, packed, tstamp);
-  else if (rt == 2) hipLaunchKernelGGL((nn_match_kernel<2>), grid, dim3(256), 0, st, a, b, sa, sb, J, K, cols, rb_count, splits, packed, tstamp);
-  else              hipLaunchKernelGGL((nn_match_kernel<1>), grid, dim3(256), 0, st, a, b, sa, sb, J, K, cols, rb_count, splits, packed, tstamp);
+  if (rt == 4)      hipLaunchKernelGGL((nn_match_kernel<4>), grid, dim3(256), 0, st, a, b, sa, sb, J, K, cols, rb_count, splits, packed, tstamp, gate, gate_min, rowlist);
+  else if (rt == 2) hipLaunchKernelGGL((nn_match_kernel<2>), grid, dim3(256), 0, st, a, b, sa, sb, J, K, cols, rb_count, splits, packed, tstamp, gate, gate_min, rowlist);
+  else              hipLaunchKernelGGL((nn_match_kernel<1>), grid, dim3(256), 0, st, a, b, sa, sb, J, K, cols, rb_count, splits, packed, tstamp, gate, gate_min, rowlist);
   if (ev1) hipEventRecord(ev1, st);
+}
+
+void launch_nn_match_ws(const float* a, const float* b, int pairs, int J, int K, int32_t* idx, void* scratch,
+                        hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, bool ref_norms_cached, unsigned long long* tstamp) {
+  float* sa = reinterpret_cast<float*>(scratch);
+  float* sb = sa + (size_t)pairs * J;
+  size_t f = ((size_t)pairs * J + (size_t)pairs * K + 3) & ~(size_t)3;
+  unsigned long long* packed = reinterpret_cast<unsigned long long*>(sa + f);
+  const int64_t ra = (int64_t)pairs * J, rb = (int64_t)pairs * K;
+  hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)((ra + 15) / 16)), dim3(256), 0, st, a, ra, sa, packed);
+  // the ref descriptors are loop invariant in dsir_register: their norms stay in the (persistent) scratch
+  if (!ref_norms_cached) hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)((rb + 15) / 16)), dim3(256), 0, st, b, rb, sb, nullptr);
+  launch_core(a, b, sa, sb, pairs, J, K, packed, st, ev0, ev1, tstamp, nullptr, 0);
   hipLaunchKernelGGL(unpack_idx_kernel, dim3(256), dim3(256), 0, st, packed, ra, idx);
+}
+
+// Exhaustive search of what the screening (nn_screen.hip) could not decide: all rows of the pairs with
+// gate[pair] >= gate_min, and the rows rowlist[pair][0 .. gate[pair]) of the other pairs (workgroups without work exit at
+// once).  Results stay in `packed` (low word = index), whose slots the caller has preset to all ones.
+void launch_nn_match_gated(const float* a, const float* b, const float* sa, const float* sb, int pairs, int J, int K,
+                           unsigned long long* packed, const int32_t* gate, int gate_min, const int32_t* rowlist,
+                           hipStream_t st) {
+  launch_core(a, b, sa, sb, pairs, J, K, packed, st, nullptr, nullptr, nullptr, gate, gate_min, nullptr);
+  launch_core(a, b, sa, sb, pairs, J, K, packed, st, nullptr, nullptr, nullptr, gate, gate_min, rowlist);
 }
 
 }  // namespace dsir

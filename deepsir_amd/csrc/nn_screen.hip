@@ -21,6 +21,9 @@
 // against d = 1.2e-4 (measured: 7e-7).  Both passes are fp16 MFMAs (v_mfma_f32_16x16x32_f16, fp32 accumulate): 6/16 of the
 // fp32 MFMA time.
 #include <hip/hip_fp16.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
 
 #include "kernels.h"
 #include "device_utils.h"
@@ -39,6 +42,7 @@ constexpr int SBC = DSIR_SCREEN_BC;   // ref columns per LDS tile
 constexpr int SRS = 72;     // halfs per LDS row: 64 + 8 pad (144 B: the 16 lanes of a ds_read_b128 group hit 16 distinct bank quads)
 constexpr int CAP = 16;     // candidates kept per row; more => exhaustive exact scan of that row
 constexpr float kC2 = 1.0f / 16384.0f;
+constexpr float kW2 = 2.0f * kC2 * 1.015625f;   // upper - lower bound, per unit of |a|^2 + |b|^2 (with slack for its own rounding)
 
 __device__ __forceinline__ unsigned int order_bits(float f) {
   const unsigned int u = __float_as_uint(f);
@@ -76,7 +80,8 @@ __global__ __launch_bounds__(NWV * 64) void screen_kernel(const _Float16* __rest
                                                      const float* __restrict__ sa, const float* __restrict__ sb, int J, int K,
                                                      int cols_per_split, int rb_count, int splits,
                                                      unsigned int* __restrict__ umin, int32_t* __restrict__ cnt,
-                                                     int32_t* __restrict__ cand) {
+                                                     int2* __restrict__ cand, int32_t* __restrict__ ovf,
+                                                     int32_t* __restrict__ rowlist, int ovf_min) {
   constexpr int NB = 2;                             // B tiles per buffer: high and low parts
   __shared__ _Float16 Bs[2][NB][SBC * SRS];
   __shared__ float sbs[2][SBC];
@@ -90,10 +95,16 @@ __global__ __launch_bounds__(NWV * 64) void screen_kernel(const _Float16* __rest
   const int pair = wi / (rb_count * splits);
   const int row0 = (rb * NWV + w) * (16 * RT);
   const int64_t arow = (int64_t)pair * J, brow = (int64_t)pair * K;
+  // a pair with that many undecidable rows is searched exhaustively as a whole (block-uniform exit before any barrier;
+  // the counter only grows, so exiting on a value seen mid-launch is safe)
+  if (ovf[pair] >= ovf_min) return;
+  auto overflowed = [&](int row) { rowlist[arow + atomicAdd(ovf + pair, 1)] = row; };   // once per row: at most J entries
 
   // A fragments (lane: row fr, channels 32 c + 8 fq .. +7) and the per-row constants of this lane's C rows (4 fq + r)
   h8 ah[RT][2], al[RT][2];
-  float srow[RT][4], thr[RT][4];
+  float srow[RT][4], thr[RT][4];          // PASS 3: thr = smallest lower bound seen by this lane (l1)
+  float l2[RT][4];                        // PASS 3: second smallest
+  int k1[RT][4];                          // PASS 3: column of the smallest
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
     const int row = min(row0 + rt * 16 + fr, J - 1);
@@ -107,7 +118,9 @@ __global__ __launch_bounds__(NWV * 64) void screen_kernel(const _Float16* __rest
       const int rr = min(row0 + rt * 16 + 4 * fq + r, J - 1);
       const float s = sa[arow + rr];
       srow[rt][r] = PASS == 1 ? s + kC2 * s : s - kC2 * s;
-      thr[rt][r] = PASS == 1 ? INFINITY : unorder_bits(umin[arow + rr]);
+      thr[rt][r] = PASS == 2 ? unorder_bits(umin[arow + rr]) : INFINITY;
+      l2[rt][r] = INFINITY;
+      k1[rt][r] = -1;
     }
   }
 
@@ -181,13 +194,18 @@ __global__ __launch_bounds__(NWV * 64) void screen_kernel(const _Float16* __rest
           const float x = fmaf(hh[rt][r], -2.f, fmaf(mx[rt][r], -9.765625e-4f, srow[rt][r]));
           if (PASS == 1) {
             thr[rt][r] = fminf(thr[rt][r], x);                                 // x = upper bound of D(row, col)
+          } else if (PASS == 3) {                                              // x = lower bound: keep the lane's two smallest
+            l2[rt][r] = __builtin_amdgcn_fmed3f(thr[rt][r], l2[rt][r], x);     // thr <= l2: the median is the new runner-up
+            k1[rt][r] = x < thr[rt][r] ? col : k1[rt][r];
+            thr[rt][r] = fminf(thr[rt][r], x);
           } else {
             const float l = x;                                                 // x = lower bound of D(row, col)
             if (l <= thr[rt][r]) {
               const int row = row0 + rt * 16 + 4 * fq + r;
               if (row < J) {
                 const int slot = atomicAdd(cnt + arow + row, 1);
-                if (slot < CAP) cand[(arow + row) * CAP + slot] = col;
+                if (slot < CAP) cand[(arow + row) * CAP + slot] = make_int2(col, __float_as_int(l));
+                else if (slot == CAP) overflowed(row);                                 // this row just overflowed
               }
             }
           }
@@ -209,6 +227,37 @@ __global__ __launch_bounds__(NWV * 64) void screen_kernel(const _Float16* __rest
         if (fr == 0 && row < J) atomicMin(umin + arow + row, order_bits(u));
       }
   }
+  if (PASS == 3) {
+    // T = min over the lanes of (their smallest lower bound + its bound width) >= min_k D(row, k) over this block's
+    // columns, hence over all columns.  Every column of the block with lower bound <= T is either some lane's smallest
+    // (emitted) or makes that lane's runner-up <= T (row flagged for the exhaustive scan).
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = row0 + rt * 16 + 4 * fq + r;
+        const int rr = min(row, J - 1);
+        const float l1 = thr[rt][r];
+        const int k = k1[rt][r];
+        float u = INFINITY;
+        if (k >= 0) u = l1 + kW2 * (sa[arow + rr] + sb[brow + k]);
+        float T = u;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) T = fminf(T, __shfl_xor(T, o));
+        if (row < J) {
+          if (fr == 0) atomicMin(umin + arow + row, order_bits(T));
+          auto emit = [&](int code, float lower) {
+            const int slot = atomicAdd(cnt + arow + row, 1);
+            if (slot < CAP) cand[(arow + row) * CAP + slot] = make_int2(code, __float_as_int(lower));
+            else if (slot == CAP) overflowed(row);                                  // this row just overflowed
+          };
+          if (k >= 0 && l1 <= T) emit(k, l1);
+          // a second column of this lane's class (columns c_begin + fr + 16 m of this split) may qualify as well: which
+          // one is not tracked, so the class itself becomes a candidate (K / (16 splits) exact evaluations, not K)
+          if (l2[rt][r] <= T) emit(-(1 + split * 16 + fr), l2[rt][r]);
+        }
+      }
+  }
 }
 
 // exact D(row, k) exactly as nn_match.hip evaluates it: the k-ordered fmaf chain of v_mfma_f32_16x16x4_f32 from a zero
@@ -223,73 +272,108 @@ __device__ __forceinline__ float exact_dist(const float4 (&a)[16], const float* 
   return __fadd_rn(__fmaf_rn(acc, -2.f, san), sbn);
 }
 
-// 16 lanes per src row.  A single survivor IS the arg-min (nothing to evaluate); several survivors: one lane each
-// evaluates the exact distance; a row whose candidate list overflowed: its 16 lanes scan every ref column exactly.
+// One thread per src row.  Entries whose lower bound exceeds the row's final threshold (the min over all blocks) are
+// dropped; a single surviving column IS the arg-min (nothing to evaluate); several surviving columns: their exact
+// distances decide (ties to the lower index).  Left to the exhaustive fp32 MFMA kernel (nn_match.hip;
+// unpack_listed_kernel copies its results): rows whose entry list overflowed (listed by screen_kernel), rows with a
+// surviving class entry (code < 0: some column of that class, not tracked which) or without any entry (non-finite
+// input) - listed here -, and every row of a pair with ovf_min or more listed rows.
 __global__ __launch_bounds__(256) void exact_pick_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                          const float* __restrict__ sa, const float* __restrict__ sb, int J,
-                                                         int K, int64_t rows, const int32_t* __restrict__ cnt,
-                                                         const int32_t* __restrict__ cand, int32_t* __restrict__ idx) {
-  const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
-  const int l = threadIdx.x & 15;
-  const bool live = row < rows;
-  const int64_t rr = live ? row : rows - 1;
-  const int n = cnt[rr];
-  if (n == 1) {                                    // uniform over the row's 16 lanes
-    if (live && l == 0) idx[row] = cand[rr * CAP];
-    return;
-  }
-  const bool exhaustive = n > CAP || n <= 0;      // n <= 0 cannot happen for finite inputs (the minimiser always qualifies)
-  const int64_t pair = rr / J;
-  const float* Bp = B + pair * K * 64;
-  const float* sbp = sb + pair * K;
-  unsigned long long best = ~0ull;
-  if (exhaustive || l < n) {
-    float4 a[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) a[q] = reinterpret_cast<const float4*>(A + rr * 64)[q];
-    const float san = sa[rr];
-    if (!exhaustive) {
-      const int k = cand[rr * CAP + l];
-      best = ((unsigned long long)order_bits(exact_dist(a, Bp + (int64_t)k * 64, san, sbp[k])) << 32) | (unsigned int)k;
-    } else {
-      for (int k = l; k < K; k += 16) {
-        const unsigned long long key =
-            ((unsigned long long)order_bits(exact_dist(a, Bp + (int64_t)k * 64, san, sbp[k])) << 32) | (unsigned int)k;
-        best = key < best ? key : best;
-      }
+                                                         int K, const unsigned int* __restrict__ umin,
+                                                         const int32_t* __restrict__ cnt, const int2* __restrict__ cand,
+                                                         int32_t* __restrict__ ovf, int ovf_min,
+                                                         int32_t* __restrict__ rowlist, int32_t* __restrict__ idx) {
+  const int pair = blockIdx.y;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= J) return;
+  const int64_t row = (int64_t)pair * J + j;
+  const int n = cnt[row];
+  if (n > CAP || ovf[pair] >= ovf_min) return;
+  const float T = unorder_bits(umin[row]);
+  const int2* ce = cand + row * CAP;
+  int kept = 0, first = 0;
+  bool cls = n <= 0;
+  for (int e = 0; e < n; ++e) {
+    const int2 c = ce[e];
+    if (__int_as_float(c.y) <= T) {
+      if (c.x < 0) cls = true;
+      else if (kept++ == 0) first = c.x;
     }
   }
-  // the rows of a wave that reach this point may differ: shuffles only among the 16 lanes of one row (all of them are here)
-#pragma unroll
-  for (int o = 1; o < 16; o <<= 1) {
-    const unsigned int lo = __shfl_xor((unsigned int)(best & 0xffffffffull), o);
-    const unsigned int hi = __shfl_xor((unsigned int)(best >> 32), o);
-    const unsigned long long other = ((unsigned long long)hi << 32) | lo;
-    best = other < best ? other : best;
+  if (cls) {
+    rowlist[(int64_t)pair * J + atomicAdd(ovf + pair, 1)] = j;
+    return;
   }
-  if (live && l == 0) idx[row] = (int32_t)(best & 0xffffffffull);
+  if (kept == 1) {
+    idx[row] = first;
+    return;
+  }
+  float4 a[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) a[q] = reinterpret_cast<const float4*>(A + row * 64)[q];
+  const float san = sa[row];
+  const float* Bp = B + (int64_t)pair * K * 64;
+  const float* sbp = sb + (int64_t)pair * K;
+  unsigned long long best = ~0ull;
+  for (int e = 0; e < n; ++e) {
+    const int2 c = ce[e];
+    if (__int_as_float(c.y) <= T) {
+      const unsigned long long key =
+          ((unsigned long long)order_bits(exact_dist(a, Bp + (int64_t)c.x * 64, san, sbp[c.x])) << 32) | (unsigned int)c.x;
+      best = key < best ? key : best;
+    }
+  }
+  idx[row] = (int32_t)(best & 0xffffffffull);
 }
 
-// diagnostics: out[0] = total candidates, out[1] = rows scanned exhaustively (candidate list overflowed)
-__global__ void screen_stats_kernel(const int32_t* __restrict__ cnt, int64_t rows, unsigned long long* __restrict__ out) {
+// results of the exhaustive kernel -> idx: every row of a pair with ovf_min or more listed rows, else the listed rows
+__global__ __launch_bounds__(256) void unpack_listed_kernel(const unsigned long long* __restrict__ packed,
+                                                            const int32_t* __restrict__ ovf, int ovf_min,
+                                                            const int32_t* __restrict__ rowlist, int J,
+                                                            int32_t* __restrict__ idx) {
+  const int pair = blockIdx.y;
+  const int g = ovf[pair];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int64_t base = (int64_t)pair * J;
+  if (g >= ovf_min) {
+    if (i < J) idx[base + i] = (int32_t)(packed[base + i] & 0xffffffffull);
+  } else if (i < g) {
+    const int r = rowlist[base + i];
+    idx[base + r] = (int32_t)(packed[base + r] & 0xffffffffull);
+  }
+}
+
+// diagnostics: out[0] = total entries, out[1] = rows left to the exhaustive kernel
+__global__ void screen_stats_kernel(const int32_t* __restrict__ cnt, int64_t rows, int J, const int32_t* __restrict__ ovf,
+                                    int ovf_min, unsigned long long* __restrict__ out) {
   unsigned long long c = 0, o = 0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += (int64_t)gridDim.x * blockDim.x) {
     const int n = cnt[i];
     c += (unsigned long long)(n > 0 ? n : 0);
-    o += (n > CAP || n <= 0) ? 1ull : 0ull;
+    if (i % J == 0) { const int g = ovf[i / J]; o += (unsigned long long)(g >= ovf_min ? J : g); }
   }
   if (c) atomicAdd(out, c);
   if (o) atomicAdd(out + 1, o);
+}
+
+// between the searches of one registration: a pair found not selective stays so (its descriptors barely change from one
+// iteration to the next), every other counter restarts
+__global__ void screen_reset_kernel(int32_t* __restrict__ ovf, int pairs, int ovf_min, int keep) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < pairs) ovf[p] = (keep && ovf[p] >= ovf_min) ? ovf[p] : 0;
 }
 
 inline int grid_for(int64_t n) { const int64_t g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > 65535 ? 65535 : g)); }
 
 }  // namespace
 
-// scratch: Umin u32 [rows] | cnt i32 [rows] | cand i32 [rows][CAP]
+// scratch: Umin u32 [rows] | cnt i32 [rows] | cand {col, lower bound} [rows][CAP] | undecidable rows per pair i32 [pairs] |
+//          packed results of the exhaustive fallback u64 [rows] | list of the undecidable rows i32 [rows]
 size_t nn_screen_scratch_bytes(int pairs, int J) {
   const size_t rows = (size_t)pairs * J;
-  return ((rows * 4 + 255) & ~(size_t)255) * 2 + ((rows * CAP * 4 + 255) & ~(size_t)255);
+  auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  return al(rows * 4) * 3 + al(rows * CAP * 8) + al((size_t)pairs * 4) + al(rows * 8);
 }
 
 void launch_split16(const float* x, int64_t rows, void* hi, void* lo, hipStream_t st) {
@@ -301,16 +385,26 @@ void launch_split16(const float* x, int64_t rows, void* hi, void* lo, hipStream_
 // a, b: fp32 descriptors [pairs][J|K][64] with their fp16 splits (ah, al, bh, bl) and squared norms (sa, sb)
 void launch_nn_screen(const float* a, const float* b, const void* ah, const void* al, const void* bh, const void* bl,
                       const float* sa, const float* sb, int pairs, int J, int K, int32_t* idx, void* scratch, hipStream_t st,
-                      hipEvent_t ev0, hipEvent_t ev1, unsigned long long* stats) {
+                      hipEvent_t ev0, hipEvent_t ev1, unsigned long long* stats, bool keep_gate) {
   const size_t rows = (size_t)pairs * J;
   char* p = reinterpret_cast<char*>(scratch);
   auto take = [&](size_t bytes) { char* r = p; p += (bytes + 255) & ~(size_t)255; return r; };
   unsigned int* umin = reinterpret_cast<unsigned int*>(take(rows * 4));
   int32_t* cnt = reinterpret_cast<int32_t*>(take(rows * 4));
-  int32_t* cand = reinterpret_cast<int32_t*>(take(rows * CAP * 4));
+  int2* cand = reinterpret_cast<int2*>(take(rows * CAP * 8));
+  int32_t* ovf = reinterpret_cast<int32_t*>(take((size_t)pairs * 4));
+  unsigned long long* packed = reinterpret_cast<unsigned long long*>(take(rows * 8));
+  int32_t* rowlist = reinterpret_cast<int32_t*>(take(rows * 4));
+  // Screening that is not selective (descriptors closer to each other than the bound width) leaves rows undecided: they
+  // are searched by the exhaustive fp32 MFMA kernel - row by row through a list, or the whole pair once a quarter of its
+  // rows is affected (then the pair also skips the screening in the remaining iterations of the registration).
+  static const int force_min = getenv("DSIR_SCREEN_OVF_MIN") ? atoi(getenv("DSIR_SCREEN_OVF_MIN")) : 0;   // tuning/test hook
+  const int ovf_min = force_min > 0 ? force_min : J / 4 + 1;
   if (ev0) (void)hipEventRecord(ev0, st);
   (void)hipMemsetAsync(umin, 0xff, rows * 4, st);
   (void)hipMemsetAsync(cnt, 0, rows * 4, st);
+  hipLaunchKernelGGL(screen_reset_kernel, dim3((pairs + 255) / 256), dim3(256), 0, st, ovf, pairs, ovf_min, keep_gate ? 1 : 0);
+  (void)hipMemsetAsync(packed, 0xff, rows * 8, st);
   constexpr int RT = 2;
   constexpr int NWV = 8;   // waves per block: 8 x 32 rows share one staged ref tile (the L2 -> LDS fill is the scarce resource)
   const int rows_per_block = NWV * 16 * RT;
@@ -335,16 +429,34 @@ void launch_nn_screen(const float* a, const float* b, const void* ah, const void
   const dim3 grid((unsigned)((int64_t)rb_count * splits * pairs));
   const _Float16 *Ah = reinterpret_cast<const _Float16*>(ah), *Al = reinterpret_cast<const _Float16*>(al);
   const _Float16 *Bh = reinterpret_cast<const _Float16*>(bh), *Bl = reinterpret_cast<const _Float16*>(bl);
-  hipLaunchKernelGGL((screen_kernel<RT, 1, NWV>), grid, dim3(NWV * 64), 0, st, Ah, Al, Bh, Bl, sa, sb, J, K, cols, rb_count, splits, umin,
-                     cnt, cand);
-  hipLaunchKernelGGL((screen_kernel<RT, 2, NWV>), grid, dim3(NWV * 64), 0, st, Ah, Al, Bh, Bl, sa, sb, J, K, cols, rb_count, splits, umin,
-                     cnt, cand);
-  hipLaunchKernelGGL(exact_pick_kernel, dim3((unsigned)((rows * 16 + 255) / 256)), dim3(256), 0, st, a, b, sa, sb, J, K,
-                     (int64_t)rows, cnt, cand, idx);
+  static const bool two_pass = getenv("DSIR_SCREEN_2PASS") != nullptr;
+  if (two_pass) {
+    hipLaunchKernelGGL((screen_kernel<RT, 1, NWV>), grid, dim3(NWV * 64), 0, st, Ah, Al, Bh, Bl, sa, sb, J, K, cols, rb_count, splits,
+                       umin, cnt, cand, ovf, rowlist, ovf_min);
+    hipLaunchKernelGGL((screen_kernel<RT, 2, NWV>), grid, dim3(NWV * 64), 0, st, Ah, Al, Bh, Bl, sa, sb, J, K, cols, rb_count, splits,
+                       umin, cnt, cand, ovf, rowlist, ovf_min);
+  } else {
+    hipLaunchKernelGGL((screen_kernel<RT, 3, NWV>), grid, dim3(NWV * 64), 0, st, Ah, Al, Bh, Bl, sa, sb, J, K, cols, rb_count, splits,
+                       umin, cnt, cand, ovf, rowlist, ovf_min);
+  }
+  hipLaunchKernelGGL(exact_pick_kernel, dim3((J + 255) / 256, pairs), dim3(256), 0, st, a, b, sa, sb, J, K, umin, cnt, cand, ovf,
+                     ovf_min, rowlist, idx);
+  launch_nn_match_gated(a, b, sa, sb, pairs, J, K, packed, ovf, ovf_min, rowlist, st);
+  hipLaunchKernelGGL(unpack_listed_kernel, dim3((J + 255) / 256, pairs), dim3(256), 0, st, packed, ovf, ovf_min, rowlist, J, idx);
   if (ev1) (void)hipEventRecord(ev1, st);
+  static const bool debug = getenv("DSIR_SCREEN_DEBUG") != nullptr;   // diagnostic: rows left to the exhaustive kernel (synchronises)
+  if (debug) {
+    std::vector<int32_t> h(pairs);
+    (void)hipMemcpyAsync(h.data(), ovf, (size_t)pairs * 4, hipMemcpyDeviceToHost, st);
+    (void)hipStreamSynchronize(st);
+    long sum = 0; int mx = 0, full = 0;
+    for (int v : h) { sum += v; mx = v > mx ? v : mx; full += v >= ovf_min; }
+    fprintf(stderr, "[nn_screen] pairs %d J %d K %d splits %d: listed rows %ld (max %d per pair), %d pairs exhaustive\n", pairs, J, K,
+            splits, sum, mx, full);
+  }
   if (stats) {
     (void)hipMemsetAsync(stats, 0, 16, st);
-    hipLaunchKernelGGL(screen_stats_kernel, dim3(256), dim3(256), 0, st, cnt, (int64_t)rows, stats);
+    hipLaunchKernelGGL(screen_stats_kernel, dim3(256), dim3(256), 0, st, cnt, (int64_t)rows, J, ovf, ovf_min, stats);
   }
 }
 

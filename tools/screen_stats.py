@@ -8,10 +8,12 @@ from deepsir_amd.synth import make_batch
 from deepsir_amd.weights import generate_state_dict
 
 P, N = int(sys.argv[1]) if len(sys.argv) > 1 else 8, int(sys.argv[2]) if len(sys.argv) > 2 else 5000
-cfg = NetConfig()
+SHAPE = sys.argv[3] if len(sys.argv) > 3 else "3dmatch"
+FL = 4 if SHAPE == "kitti" else 3
+cfg = NetConfig(feat_len=FL)
 eng = Engine(cfg, 0, max_points=N, max_pairs=P)
 eng.load_state_dict(generate_state_dict(cfg, 0))
-b = make_batch(N, list(range(10_000, 10_000 + P)), 3)
+b = make_batch(N, list(range(10_000, 10_000 + P)), FL, SHAPE)
 pts = torch.cat([torch.from_numpy(b["points_src"]), torch.from_numpy(b["points_ref"])], 0).cuda()
 xyz, neigh, sub, interp = eng.knn_pyramid(pts)
 feat, logits = eng.randla_forward("feat_extractor", pts, xyz, neigh, sub, interp)
@@ -20,5 +22,5 @@ desc = eng.aggregate(xyz[:, :N].contiguous(), feat, score)
 ds, dr = desc[:P].contiguous(), desc[P:].contiguous()
 idx, (ncand, nexh) = eng.nn_match_screened(ds, dr)
 exact = eng.nn_match(ds, dr)
-print(f"pairs {P} x {N}: {ncand / (P * N):.3f} candidates per row, {nexh} of {P * N} rows exhaustive, "
+print(f"{SHAPE} pairs {P} x {N}: {ncand / (P * N):.3f} candidates per row, {nexh} of {P * N} rows exhaustive, "
       f"equal to the exhaustive kernel: {bool(torch.equal(idx, exact))}")
