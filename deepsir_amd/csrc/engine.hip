@@ -805,13 +805,16 @@ int dsir_nn_match_screened(dsir_ctx* c, const float* a, const float* b, int pair
   float* sa = ws.get<float>((size_t)pairs * J); float* sb = ws.get<float>((size_t)pairs * K);
   void* scratch = ws.raw(nn_screen_scratch_bytes(pairs, J));
   unsigned long long* dstats = ws.get<unsigned long long>(2);
+  int32_t* bad = ws.get<int32_t>(1);   // raised by the split when an element is outside the screening's domain
   if (ws.overflow) return fail(c, "workspace exhausted in nn_match_screened");
   hipStream_t st = c->stream;
-  launch_split16(a, (int64_t)pairs * J, ah, al, st);
-  launch_split16(b, (int64_t)pairs * K, bh, bl, st);
+  HIP_OK(c, hipMemsetAsync(bad, 0, 4, st));
+  launch_split16(a, (int64_t)pairs * J, ah, al, st, bad);
+  launch_split16(b, (int64_t)pairs * K, bh, bl, st, bad);
   launch_sqnorm(a, (int64_t)pairs * J, sa, st);
   launch_sqnorm(b, (int64_t)pairs * K, sb, st);
-  launch_nn_screen(a, b, ah, al, bh, bl, sa, sb, pairs, J, K, idx, scratch, st, nullptr, nullptr, stats ? dstats : nullptr);
+  launch_nn_screen(a, b, ah, al, bh, bl, sa, sb, pairs, J, K, idx, scratch, st, nullptr, nullptr, stats ? dstats : nullptr,
+                   /*keep_gate=*/false, bad);
   if (stats) {
     HIP_OK(c, hipStreamSynchronize(st));
     unsigned long long h[2];

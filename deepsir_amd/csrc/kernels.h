@@ -166,11 +166,13 @@ void launch_sqnorm(const float* x, int64_t rows, float* out, hipStream_t st);   
 
 // nn_screen.hip — the same arg-min, screened with fp16 MFMAs under a rigorous bound and decided in exact fp32
 size_t nn_screen_scratch_bytes(int pairs, int J);
-void launch_split16(const float* x, int64_t rows, void* hi, void* lo, hipStream_t st);   // fp32 [rows][64] -> fp16 hi / lo
+// fp32 [rows][64] -> fp16 hi / lo; `bad` (optional device flag) is set when an element is outside the screening's domain
+void launch_split16(const float* x, int64_t rows, void* hi, void* lo, hipStream_t st, int32_t* bad = nullptr);
 void launch_nn_screen(const float* a, const float* b, const void* ah, const void* al, const void* bh, const void* bl,
                       const float* sa, const float* sb, int pairs, int J, int K, int32_t* idx, void* scratch, hipStream_t st,
                       hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, unsigned long long* stats = nullptr,
-                      bool keep_gate = false);   // keep_gate: pairs found not selective by the previous call on this scratch stay exhaustive
+                      bool keep_gate = false, const int32_t* bad = nullptr);
+// keep_gate: pairs found not selective by the previous call on this scratch stay exhaustive; bad: launch_split16's flag
 
 // weighted Kabsch + SE(3) bookkeeping (model.py:22-66, :586-595; se3_torch.py:28-77)
 struct KabschArgs {

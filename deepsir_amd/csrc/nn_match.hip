@@ -68,9 +68,18 @@ __global__ __launch_bounds__(256) void nn_match_kernel(const float* __restrict__
   const int nwg = gridDim.x, id = blockIdx.x;
   const int q8 = nwg >> 3, r8 = nwg & 7, xcd = id & 7;
   const int wi = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3);
-  const int rb = wi % rb_count;
-  const int split = (wi / rb_count) % splits;
-  const int pair = wi / (rb_count * splits);
+  int rb = wi % rb_count;
+  int split = (wi / rb_count) % splits;
+  int pair = wi / (rb_count * splits);
+  if (rowlist) {
+    // row-list use: only the first row blocks of a pair have work.  Row block slowest, in plain dispatch order: the
+    // working blocks come first and spread over all CUs (with the row block fastest every rb_count-th workgroup works,
+    // and round-robin dispatch piles them onto a few CUs)
+    const int ps = (int)(gridDim.x / rb_count);   // pairs * splits
+    rb = id / ps;
+    pair = (id % ps) / splits;
+    split = id % splits;
+  }
   // fallback use (nn_screen.hip), block-uniform exits before any barrier.  gate[pair] = src rows of the pair whose
   // screening failed.  Without a row list: all rows of the pairs with gate >= gate_min.  With one: only the listed rows
   // (rowlist[pair][0 .. gate)) of the pairs with gate < gate_min.

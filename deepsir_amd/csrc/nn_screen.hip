@@ -5,21 +5,31 @@
 // chip (fp32: 1/16 of fp16).  Only the ARG-MIN matters, so the contraction is first done approximately where a rigorous
 // error bound lets almost every column be discarded, and the exact fp32 formula is evaluated only for the survivors:
 //
-//   split   x = xh + 2^-11 xl + r,  xh = fp16(x) (flushed to 0 below 2^-14), xl = fp16((x - xh) 2^11), |r| <= 2^-22 |x|
-//   S = |a|^2 + |b|^2 - 2 (ah.bh + 2^-11 (ah.bl + al.bh))                     |S - D| <= d = 2^-14 (|a|^2 + |b|^2)
-//   pass 1  Umin[j] = min_k (S + d)              >= min_k D(j,k)
-//   pass 2  candidates(j) = { k : S - d <= Umin[j] }   contains every k with D(j,k) = min_k D(j,k)
-//           (a cheaper one-term pass 1 was measured: its 2^-8 bound admits ~100 candidates per row on real descriptors,
-//            whose distances sit within ~1e-2 of each other; with the tight bound 1.2-1.3 candidates survive on average)
-//   pass 3  exact D (the fmaf chain over channels 0..63 that v_mfma_f32_16x16x4_f32 evaluates, then the reference's two
-//           roundings) for the candidates only; arg-min with ties to the lower index.  A row with more than CAP
-//           candidates is scanned exhaustively in exact fp32 (nothing is ever decided by an approximate value).
+//   split   x = xh + 2^-11 xl + r,  xh = fp16(x) (flushed to 0 below 2^-14), xl = fp16((x - xh) 2^11)
+//   S = |a|^2 + |b|^2 - 2 (ah.bh + 2^-11 (ah.bl + al.bh))     |S - D| <= d = 2^-15 (|a|^2 + |b|^2) + 2^-20
+//   screen  ONE pass of fp16 MFMAs (v_mfma_f32_16x16x32_f16, fp32 accumulate; 3/16 of the fp32 MFMA time).  Every lane
+//           keeps, for each of its rows, the two smallest lower bounds L = S - d among the columns it sees (its class:
+//           columns = fr mod 16 of the workgroup's column range) and the column of the smallest.  At the end of the
+//           workgroup T = min over the lanes of (smallest L + 2 d) >= min_k D(row, k), and
+//             - every lane whose smallest L <= T emits that column as a candidate entry,
+//             - a lane whose runner-up is <= T as well emits its class (a second qualifying column exists, unknown which),
+//             - the row's global threshold is lowered to T (atomicMin over the workgroups that share the row).
+//           Every column with D = min D has L <= D <= T for every workgroup's T, so it is emitted, or covered by a class.
+//   pick    entries above the row's final threshold are dropped.  One column left: it IS the arg-min.  Several: their
+//           exact D (the fmaf chain over channels 0..63 that v_mfma_f32_16x16x4_f32 evaluates, then the reference's two
+//           roundings) decides, ties to the lower index.
+//   rest    rows with a surviving class entry or an overflowed entry list are searched by the exhaustive exact-fp32 MFMA
+//           kernel (nn_match.hip) through a row list; a pair with a quarter of its rows in that state is searched by it
+//           as a whole and skips the screening for the rest of the registration.  Nothing is ever decided by an
+//           approximate value.
 //
-// Error budget for |a|,|b| <= ~1 (descriptors are L2-normalised by the aggregation, model.py:232-233; the bounds scale
-// with |a|^2 + |b|^2): representation 3 * 2^-22, fp32 accumulation of 64 (+128 scaled) exact fp16 products <= 64 * 2^-24
-// relative to |a||b|, the reference's own fp32 chain <= 64 * 2^-24, final roundings 2^-22: |S2 - D| < 3e-5 for unit vectors
-// against d = 1.2e-4 (measured: 7e-7).  Both passes are fp16 MFMAs (v_mfma_f32_16x16x32_f16, fp32 accumulate): 6/16 of the
-// fp32 MFMA time.
+// Error budget, in units of M = |a|^2 + |b|^2 (|a||b| <= M/2): representation 2^-22 per element (3 2^-22 M with the
+// dropped al.bl term); fp32 accumulation of the 64 exact fp16 products per term, pessimistically one ulp per step:
+// 2^-17 M after the factor 2; the reference's own fmaf chain 64 * 2^-24 * 2 |a||b| <= 2^-18 M; final roundings 2^-22 M:
+// < 2^-15.6 M against 2^-15 M (measured on unit descriptors: 7e-7 against 6e-5).  Elements below 2^-25 lose their low part
+// (fp16 underflow): <= 2^-25 per element, 2^-21 (|a| + |b|) <= 2^-21 (1 + M/2) on the distance: the constant term 2^-20.
+// Elements beyond the fp16 range (|x| > 2^15) or not finite: split16_kernel raises a flag and every pair is searched
+// exhaustively (the engine's descriptors are L2-normalised, model.py:232-233, and never take that path).
 #include <hip/hip_fp16.h>
 #include <cstdio>
 #include <cstdlib>
@@ -39,10 +49,17 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 #define DSIR_SCREEN_BC 64
 #endif
 constexpr int SBC = DSIR_SCREEN_BC;   // ref columns per LDS tile
-constexpr int SRS = 72;     // halfs per LDS row: 64 + 8 pad (144 B: the 16 lanes of a ds_read_b128 group hit 16 distinct bank quads)
+#ifndef DSIR_SCREEN_SRS
+#define DSIR_SCREEN_SRS 72
+#endif
+#ifndef DSIR_SCREEN_RT
+#define DSIR_SCREEN_RT 2
+#endif
+constexpr int SRS = DSIR_SCREEN_SRS;     // halfs per LDS row: 64 + 8 pad (144 B: the 16 lanes of a ds_read_b128 group hit 16 distinct bank quads)
 constexpr int CAP = 16;     // candidates kept per row; more => exhaustive exact scan of that row
-constexpr float kC2 = 1.0f / 16384.0f;
-constexpr float kW2 = 2.0f * kC2 * 1.015625f;   // upper - lower bound, per unit of |a|^2 + |b|^2 (with slack for its own rounding)
+constexpr float kC1 = 1.0f / 32768.0f;      // bound width: d = kC1 (|a|^2 + |b|^2) + kC0 (see the header)
+constexpr float kC0 = 1.0f / 1048576.0f;
+constexpr float kW = 2.0f * 1.015625f;       // upper - lower bound = 2 d, with slack for the rounding of its own evaluation
 
 __device__ __forceinline__ unsigned int order_bits(float f) {
   const unsigned int u = __float_as_uint(f);
@@ -53,11 +70,15 @@ __device__ __forceinline__ float unorder_bits(unsigned int b) {
 }
 
 // x [rows][64] fp32 -> hi, lo [rows][64] fp16 (see header); one thread per 4 channels
+// `bad` (optional): set when an element is outside the domain of the error bound (|x| > 2^15 or not finite)
 __global__ __launch_bounds__(256) void split16_kernel(const float* __restrict__ x, int64_t n4, _Float16* __restrict__ hi,
-                                                      _Float16* __restrict__ lo) {
+                                                      _Float16* __restrict__ lo, int32_t* __restrict__ bad) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
     const float4 v = reinterpret_cast<const float4*>(x)[i];
     const float f[4] = {v.x, v.y, v.z, v.w};
+    if (bad && !(fmaxf(fmaxf(fabsf(f[0]), fabsf(f[1])), fmaxf(fabsf(f[2]), fabsf(f[3]))) <= 32768.f &&
+                 f[0] == f[0] && f[1] == f[1] && f[2] == f[2] && f[3] == f[3]))
+      *bad = 1;
     h4 h, l;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -71,20 +92,27 @@ __global__ __launch_bounds__(256) void split16_kernel(const float* __restrict__ 
   }
 }
 
-// Common skeleton of the two screening passes.  Block = 4 waves, wave w owns RT row tiles of 16 src rows whose fp16
-// fragments stay in registers; ref tiles of 64 columns stream through double-buffered LDS.  XCD-aware work mapping as
-// in nn_match.hip.  PASS 1: running min of the upper bound.  PASS 2: candidate collection against Umin.
-template <int RT, int PASS, int NWV>
-__global__ __launch_bounds__(NWV * 64) void screen_kernel(const _Float16* __restrict__ Ah, const _Float16* __restrict__ Al,
+// Block = NWV waves, wave w owns RT row tiles of 16 src rows whose fp16 fragments stay in registers; ref tiles of 64
+// columns stream through double-buffered LDS (fetched two tiles ahead through registers).  XCD-aware work mapping as in
+// nn_match.hip.  Software pipelined: the accumulators of a 16-column step are ranked (z = hh + 2^-11 mx; the lane's two
+// largest z and the column of the largest; L = |a|^2_low - 2 z) while the MFMAs of the next step run.  One workgroup of
+// 8 waves per CU (194 VGPRs): measured equal to two workgroups of a leaner, unpipelined variant on its own, and better
+// when other streams share the GPU.
+#ifndef DSIR_SCREEN_WPE
+#define DSIR_SCREEN_WPE 2
+#endif
+template <int RT, int NWV>
+__global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(DSIR_SCREEN_WPE, DSIR_SCREEN_WPE))) void screen_kernel(const _Float16* __restrict__ Ah, const _Float16* __restrict__ Al,
                                                      const _Float16* __restrict__ Bh, const _Float16* __restrict__ Bl,
                                                      const float* __restrict__ sa, const float* __restrict__ sb, int J, int K,
                                                      int cols_per_split, int rb_count, int splits,
                                                      unsigned int* __restrict__ umin, int32_t* __restrict__ cnt,
                                                      int2* __restrict__ cand, int32_t* __restrict__ ovf,
                                                      int32_t* __restrict__ rowlist, int ovf_min) {
-  constexpr int NB = 2;                             // B tiles per buffer: high and low parts
-  __shared__ _Float16 Bs[2][NB][SBC * SRS];
-  __shared__ float sbs[2][SBC];
+  static_assert(NWV * 64 == SBC * 8, "one 16-byte piece of each tile part per thread");
+  __shared__ _Float16 Bs[2][2][SBC * SRS];          // [buffer][high | low part]
+  __shared__ float4 sbs[2][2 * SBC];                // -(|b|^2 - d_b) / 2, replicated: the MFMA accumulators start from it
+                                                    // (two copies: one float per thread, no branch in the loop body)
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fq = lane >> 4;
   const int nwg = gridDim.x, id = blockIdx.x;
@@ -98,13 +126,9 @@ __global__ __launch_bounds__(NWV * 64) void screen_kernel(const _Float16* __rest
   // a pair with that many undecidable rows is searched exhaustively as a whole (block-uniform exit before any barrier;
   // the counter only grows, so exiting on a value seen mid-launch is safe)
   if (ovf[pair] >= ovf_min) return;
-  auto overflowed = [&](int row) { rowlist[arow + atomicAdd(ovf + pair, 1)] = row; };   // once per row: at most J entries
 
-  // A fragments (lane: row fr, channels 32 c + 8 fq .. +7) and the per-row constants of this lane's C rows (4 fq + r)
+  // A fragments: lane holds row fr, channels 32 c + 8 fq .. +7
   h8 ah[RT][2], al[RT][2];
-  float srow[RT][4], thr[RT][4];          // PASS 3: thr = smallest lower bound seen by this lane (l1)
-  float l2[RT][4];                        // PASS 3: second smallest
-  int k1[RT][4];                          // PASS 3: column of the smallest
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
     const int row = min(row0 + rt * 16 + fr, J - 1);
@@ -113,151 +137,143 @@ __global__ __launch_bounds__(NWV * 64) void screen_kernel(const _Float16* __rest
       ah[rt][c] = *reinterpret_cast<const h8*>(Ah + (arow + row) * 64 + 32 * c + 8 * fq);
       al[rt][c] = *reinterpret_cast<const h8*>(Al + (arow + row) * 64 + 32 * c + 8 * fq);
     }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int rr = min(row0 + rt * 16 + 4 * fq + r, J - 1);
-      const float s = sa[arow + rr];
-      srow[rt][r] = PASS == 1 ? s + kC2 * s : s - kC2 * s;
-      thr[rt][r] = PASS == 2 ? unorder_bits(umin[arow + rr]) : INFINITY;
-      l2[rt][r] = INFINITY;
-      k1[rt][r] = -1;
-    }
   }
+  // per C element (row 4 fq + r of tile rt, column class fr): the two largest z and the column of the largest
+  float z1[RT][4], z2[RT][4];
+  int k1[RT][4];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { z1[rt][r] = -INFINITY; z2[rt][r] = -INFINITY; k1[rt][r] = -1; }
 
   const int c_begin = split * cols_per_split;
   const int c_end = min(K, c_begin + cols_per_split);
-  // staging: thread -> 16-byte piece (8 channels) f of the tile: column f >> 3, piece f & 7; 512 pieces per part
-  constexpr int PIECES = SBC * 8;   // 16-byte pieces per part of a tile
-  constexpr int NP = (NWV * 64 >= PIECES) ? 1 : PIECES / (NWV * 64);
-  const bool stager = NWV * 64 <= PIECES || tid < PIECES;
-  h8 pre[NB][NP];
-  float pre_sb = 0.f;
-  auto gload = [&](int c0) {
-#pragma unroll
-    for (int i = 0; i < NP; ++i) {
-      const int f = stager ? tid + NWV * 64 * i : 0;
-      const int r = min(c0 + (f >> 3), K - 1);
-      pre[0][i] = *reinterpret_cast<const h8*>(Bh + (brow + r) * 64 + 8 * (f & 7));
-      pre[1][i] = *reinterpret_cast<const h8*>(Bl + (brow + r) * 64 + 8 * (f & 7));
-    }
-    if (tid < SBC) {
-      const int col = c0 + tid;
-      const float s = sb[brow + min(col, K - 1)];
-      // -(|b|^2 +- d_b) / 2: the accumulators START from it, so that -2 acc already contains the column term
-      pre_sb = col < c_end ? -0.5f * (PASS == 1 ? s + kC2 * s : s - kC2 * s) : -INFINITY;   // columns past the range never win
-    }
+  // staging: thread -> 16-byte piece (8 channels) of the tile: column tid >> 3, piece tid & 7
+  // two register sets: a tile is fetched two iterations before it is needed (the L2 / MALL latency under load exceeds
+  // the time of one tile) and written to the free LDS buffer at the end of the iteration before
+  struct Pre { h8 h, l; float sb; };
+  Pre preA, preB;
+  auto gload = [&](Pre& pre, int c0) {
+    const int r = min(c0 + (tid >> 3), K - 1);
+    pre.h = *reinterpret_cast<const h8*>(Bh + (brow + r) * 64 + 8 * (tid & 7));
+    pre.l = *reinterpret_cast<const h8*>(Bl + (brow + r) * 64 + 8 * (tid & 7));
+    const int col = c0 + ((tid >> 2) & (SBC - 1));
+    const float s = sb[brow + min(col, K - 1)];
+    pre.sb = col < c_end ? -0.5f * (s - kC1 * s) : -INFINITY;   // columns past the range never win
   };
-  auto lstore = [&](int buf) {
+  auto lstore = [&](const Pre& pre, int buf) {
+    *reinterpret_cast<h8*>(&Bs[buf][0][(tid >> 3) * SRS + 8 * (tid & 7)]) = pre.h;
+    *reinterpret_cast<h8*>(&Bs[buf][1][(tid >> 3) * SRS + 8 * (tid & 7)]) = pre.l;
+    reinterpret_cast<float*>(sbs[buf])[tid] = pre.sb;
+  };
+  f32x4 hhP[RT], mxP[RT];
+  int colP = 0;
 #pragma unroll
-    for (int i = 0; i < NP; ++i) {
-      const int f = tid + NWV * 64 * i;
-      if (stager) {
-        *reinterpret_cast<h8*>(&Bs[buf][0][(f >> 3) * SRS + 8 * (f & 7)]) = pre[0][i];
-        *reinterpret_cast<h8*>(&Bs[buf][1][(f >> 3) * SRS + 8 * (f & 7)]) = pre[1][i];
+  for (int rt = 0; rt < RT; ++rt) {
+    hhP[rt] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    mxP[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  // ranking of the pending accumulators: independent of the MFMAs of the running step, so the compiler's scheduler is
+  // free to issue it in their shadow
+  auto rank = [&]() {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float z = fmaf(mxP[rt][r], 4.8828125e-4f, hhP[rt][r]);
+        z2[rt][r] = __builtin_amdgcn_fmed3f(z1[rt][r], z2[rt][r], z);   // z1 >= z2: the median is the new runner-up
+        k1[rt][r] = z > z1[rt][r] ? colP : k1[rt][r];
+        z1[rt][r] = fmaxf(z1[rt][r], z);
       }
-    }
-    if (tid < SBC) sbs[buf][tid] = pre_sb;
   };
-  gload(c_begin);
-  lstore(0);
-  __syncthreads();
-  int buf = 0;
-  for (int c0 = c_begin; c0 < c_end; c0 += SBC) {
-    const bool has_next = c0 + SBC < c_end;
-    if (has_next) gload(c0 + SBC);
+  // one tile: ranks into (z1, z2, k1); `pre` holds the tile after it and is refilled with the one two further on
+  auto tile = [&](int c0, int buf, Pre& pre) {
+    const _Float16* bhp = &Bs[buf][0][fr * SRS + 8 * fq];
+    const _Float16* blp = &Bs[buf][1][fr * SRS + 8 * fq];
+    h8 bh0, bh1, bl0, bl1;
+    f32x4 cin;
+    // fragment loads of step t (each register is reloaded for the next step right after its last use)
+    auto ld_bh0 = [&](int t) { bh0 = *reinterpret_cast<const h8*>(bhp + 16 * t * SRS); };
+    auto ld_bh1 = [&](int t) { bh1 = *reinterpret_cast<const h8*>(bhp + 16 * t * SRS + 32); };
+    auto ld_bl0 = [&](int t) { bl0 = *reinterpret_cast<const h8*>(blp + 16 * t * SRS); };
+    auto ld_bl1 = [&](int t) { bl1 = *reinterpret_cast<const h8*>(blp + 16 * t * SRS + 32); };
+    auto ld_cin = [&](int t) { const float4 v = sbs[buf][16 * t + fr]; cin = f32x4{v.x, v.y, v.z, v.w}; };
+    ld_bh0(0); ld_cin(0); ld_bl0(0); ld_bh1(0); ld_bl1(0);
 #pragma unroll
     for (int t = 0; t < SBC / 16; ++t) {
-      f32x4 hh[RT], mx[RT];
-      const float h0 = sbs[buf][16 * t + fr];
+      const bool more = t + 1 < SBC / 16;
+      f32x4 hhN[RT], mxN[RT];
+      const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+#define DSIR_MFMA(acc, a, b, c) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt) {
-        hh[rt] = f32x4{h0, h0, h0, h0};
-        mx[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
+      for (int rt = 0; rt < RT; ++rt) DSIR_MFMA(hhN[rt], ah[rt][0], bh0, cin);
+      if (more) ld_cin(t + 1);
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const h8 bh = *reinterpret_cast<const h8*>(&Bs[buf][0][(16 * t + fr) * SRS + 32 * c + 8 * fq]);
-        const h8 bl = *reinterpret_cast<const h8*>(&Bs[buf][1][(16 * t + fr) * SRS + 32 * c + 8 * fq]);
+      for (int rt = 0; rt < RT; ++rt) DSIR_MFMA(mxN[rt], ah[rt][0], bl0, zero);
+      if (more) ld_bl0(t + 1);
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-          hh[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[rt][c], bh, hh[rt], 0, 0, 0);
-          mx[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[rt][c], bl, mx[rt], 0, 0, 0);
-          mx[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[rt][c], bh, mx[rt], 0, 0, 0);
-        }
-      }
-      const int col = c0 + 16 * t + fr;
+      for (int rt = 0; rt < RT; ++rt) DSIR_MFMA(hhN[rt], ah[rt][1], bh1, hhN[rt]);
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt)
+      for (int rt = 0; rt < RT; ++rt) DSIR_MFMA(mxN[rt], al[rt][0], bh0, mxN[rt]);
+      if (more) ld_bh0(t + 1);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          // |a|^2 -+ d_a  -  2 (hh + 2^-11 mx),  hh started at -(|b|^2 -+ d_b) / 2
-          const float x = fmaf(hh[rt][r], -2.f, fmaf(mx[rt][r], -9.765625e-4f, srow[rt][r]));
-          if (PASS == 1) {
-            thr[rt][r] = fminf(thr[rt][r], x);                                 // x = upper bound of D(row, col)
-          } else if (PASS == 3) {                                              // x = lower bound: keep the lane's two smallest
-            l2[rt][r] = __builtin_amdgcn_fmed3f(thr[rt][r], l2[rt][r], x);     // thr <= l2: the median is the new runner-up
-            k1[rt][r] = x < thr[rt][r] ? col : k1[rt][r];
-            thr[rt][r] = fminf(thr[rt][r], x);
-          } else {
-            const float l = x;                                                 // x = lower bound of D(row, col)
-            if (l <= thr[rt][r]) {
-              const int row = row0 + rt * 16 + 4 * fq + r;
-              if (row < J) {
-                const int slot = atomicAdd(cnt + arow + row, 1);
-                if (slot < CAP) cand[(arow + row) * CAP + slot] = make_int2(col, __float_as_int(l));
-                else if (slot == CAP) overflowed(row);                                 // this row just overflowed
-              }
-            }
-          }
-        }
+      for (int rt = 0; rt < RT; ++rt) DSIR_MFMA(mxN[rt], ah[rt][1], bl1, mxN[rt]);
+      if (more) ld_bl1(t + 1);
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) DSIR_MFMA(mxN[rt], al[rt][1], bh1, mxN[rt]);
+      if (more) ld_bh1(t + 1);
+#undef DSIR_MFMA
+      rank();
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) { hhP[rt] = hhN[rt]; mxP[rt] = mxN[rt]; }
+      colP = c0 + 16 * t + fr;
     }
-    if (has_next) lstore(buf ^ 1);
+    lstore(pre, buf ^ 1);
+    gload(pre, c0 + 3 * SBC);                         // clamped addresses: harmless past the range
     __syncthreads();
-    buf ^= 1;
+  };
+  gload(preA, c_begin);
+  lstore(preA, 0);
+  gload(preA, c_begin + SBC);
+  gload(preB, c_begin + 2 * SBC);
+  __syncthreads();
+  for (int c0 = c_begin; c0 < c_end; c0 += 2 * SBC) {
+    tile(c0, 0, preA);
+    if (c0 + SBC < c_end) tile(c0 + SBC, 1, preB);
   }
-  if (PASS == 1) {
+  rank();
+
+  // T = min over the lanes of (their smallest lower bound + its bound width) >= min_k D(row, k) over this block's
+  // columns, hence over all columns.  Every column of the block with lower bound <= T is either some lane's smallest
+  // (emitted) or makes that lane's runner-up <= T (class emitted).
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
+  for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float u = thr[rt][r];
+    for (int r = 0; r < 4; ++r) {
+      const int row = row0 + rt * 16 + 4 * fq + r;
+      const int rr = min(row, J - 1);
+      const float san = sa[arow + rr];
+      const float slo = san - kC1 * san - kC0;       // |a|^2 - d_a
+      const float l1 = fmaf(z1[rt][r], -2.f, slo), l2 = fmaf(z2[rt][r], -2.f, slo);
+      const int k = k1[rt][r];
+      float u = INFINITY;
+      if (k >= 0) u = l1 + kW * (kC1 * (san + sb[brow + k]) + kC0);
+      float T = u;
 #pragma unroll
-        for (int o = 1; o < 16; o <<= 1) u = fminf(u, __shfl_xor(u, o));
-        const int row = row0 + rt * 16 + 4 * fq + r;
-        if (fr == 0 && row < J) atomicMin(umin + arow + row, order_bits(u));
+      for (int o = 1; o < 16; o <<= 1) T = fminf(T, __shfl_xor(T, o));
+      if (row < J) {
+        if (fr == 0) atomicMin(umin + arow + row, order_bits(T));
+        auto emit = [&](int code, float lower) {
+          const int slot = atomicAdd(cnt + arow + row, 1);
+          if (slot < CAP) cand[(arow + row) * CAP + slot] = make_int2(code, __float_as_int(lower));
+          else if (slot == CAP) rowlist[arow + atomicAdd(ovf + pair, 1)] = row;   // this row just overflowed (once per row)
+        };
+        if (k >= 0 && l1 <= T) emit(k, l1);
+        // a second column of this lane's class (columns c_begin + fr + 16 m of this split) may qualify as well: which
+        // one is not tracked, so the class itself becomes an entry and the row goes to the exhaustive kernel
+        if (l2 <= T) emit(-(1 + split * 16 + fr), l2);
       }
-  }
-  if (PASS == 3) {
-    // T = min over the lanes of (their smallest lower bound + its bound width) >= min_k D(row, k) over this block's
-    // columns, hence over all columns.  Every column of the block with lower bound <= T is either some lane's smallest
-    // (emitted) or makes that lane's runner-up <= T (row flagged for the exhaustive scan).
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = row0 + rt * 16 + 4 * fq + r;
-        const int rr = min(row, J - 1);
-        const float l1 = thr[rt][r];
-        const int k = k1[rt][r];
-        float u = INFINITY;
-        if (k >= 0) u = l1 + kW2 * (sa[arow + rr] + sb[brow + k]);
-        float T = u;
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) T = fminf(T, __shfl_xor(T, o));
-        if (row < J) {
-          if (fr == 0) atomicMin(umin + arow + row, order_bits(T));
-          auto emit = [&](int code, float lower) {
-            const int slot = atomicAdd(cnt + arow + row, 1);
-            if (slot < CAP) cand[(arow + row) * CAP + slot] = make_int2(code, __float_as_int(lower));
-            else if (slot == CAP) overflowed(row);                                  // this row just overflowed
-          };
-          if (k >= 0 && l1 <= T) emit(k, l1);
-          // a second column of this lane's class (columns c_begin + fr + 16 m of this split) may qualify as well: which
-          // one is not tracked, so the class itself becomes a candidate (K / (16 splits) exact evaluations, not K)
-          if (l2[rt][r] <= T) emit(-(1 + split * 16 + fr), l2[rt][r]);
-        }
-      }
-  }
+    }
 }
 
 // exact D(row, k) exactly as nn_match.hip evaluates it: the k-ordered fmaf chain of v_mfma_f32_16x16x4_f32 from a zero
@@ -358,10 +374,10 @@ __global__ void screen_stats_kernel(const int32_t* __restrict__ cnt, int64_t row
 }
 
 // between the searches of one registration: a pair found not selective stays so (its descriptors barely change from one
-// iteration to the next), every other counter restarts
-__global__ void screen_reset_kernel(int32_t* __restrict__ ovf, int pairs, int ovf_min, int keep) {
+// iteration to the next), every other counter restarts.  Input outside the bound's domain: every pair exhaustive.
+__global__ void screen_reset_kernel(int32_t* __restrict__ ovf, int pairs, int ovf_min, int keep, const int32_t* __restrict__ bad) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p < pairs) ovf[p] = (keep && ovf[p] >= ovf_min) ? ovf[p] : 0;
+  if (p < pairs) ovf[p] = (bad && *bad) ? ovf_min : ((keep && ovf[p] >= ovf_min) ? ovf[p] : 0);
 }
 
 inline int grid_for(int64_t n) { const int64_t g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > 65535 ? 65535 : g)); }
@@ -376,16 +392,16 @@ size_t nn_screen_scratch_bytes(int pairs, int J) {
   return al(rows * 4) * 3 + al(rows * CAP * 8) + al((size_t)pairs * 4) + al(rows * 8);
 }
 
-void launch_split16(const float* x, int64_t rows, void* hi, void* lo, hipStream_t st) {
+void launch_split16(const float* x, int64_t rows, void* hi, void* lo, hipStream_t st, int32_t* bad) {
   const int64_t n4 = rows * 16;
   hipLaunchKernelGGL(split16_kernel, dim3(grid_for(n4)), dim3(256), 0, st, x, n4, reinterpret_cast<_Float16*>(hi),
-                     reinterpret_cast<_Float16*>(lo));
+                     reinterpret_cast<_Float16*>(lo), bad);
 }
 
 // a, b: fp32 descriptors [pairs][J|K][64] with their fp16 splits (ah, al, bh, bl) and squared norms (sa, sb)
 void launch_nn_screen(const float* a, const float* b, const void* ah, const void* al, const void* bh, const void* bl,
                       const float* sa, const float* sb, int pairs, int J, int K, int32_t* idx, void* scratch, hipStream_t st,
-                      hipEvent_t ev0, hipEvent_t ev1, unsigned long long* stats, bool keep_gate) {
+                      hipEvent_t ev0, hipEvent_t ev1, unsigned long long* stats, bool keep_gate, const int32_t* bad) {
   const size_t rows = (size_t)pairs * J;
   char* p = reinterpret_cast<char*>(scratch);
   auto take = [&](size_t bytes) { char* r = p; p += (bytes + 255) & ~(size_t)255; return r; };
@@ -403,15 +419,15 @@ void launch_nn_screen(const float* a, const float* b, const void* ah, const void
   if (ev0) (void)hipEventRecord(ev0, st);
   (void)hipMemsetAsync(umin, 0xff, rows * 4, st);
   (void)hipMemsetAsync(cnt, 0, rows * 4, st);
-  hipLaunchKernelGGL(screen_reset_kernel, dim3((pairs + 255) / 256), dim3(256), 0, st, ovf, pairs, ovf_min, keep_gate ? 1 : 0);
+  hipLaunchKernelGGL(screen_reset_kernel, dim3((pairs + 255) / 256), dim3(256), 0, st, ovf, pairs, ovf_min, keep_gate ? 1 : 0, bad);
   (void)hipMemsetAsync(packed, 0xff, rows * 8, st);
-  constexpr int RT = 2;
+  constexpr int RT = DSIR_SCREEN_RT;
   constexpr int NWV = 8;   // waves per block: 8 x 32 rows share one staged ref tile (the L2 -> LDS fill is the scarce resource)
   const int rows_per_block = NWV * 16 * RT;
   const int rb_count = (J + rows_per_block - 1) / rows_per_block;
   const int64_t base = (int64_t)pairs * rb_count;
   const int tiles = (K + SBC - 1) / SBC;
-  const int resident = 256 * (NWV == 16 ? 1 : (NWV == 8 ? 2 : 4));
+  const int resident = 256 * (DSIR_SCREEN_WPE * 4 / NWV);   // workgroups the chip holds at once
   int splits = 1;
   double best_eff = -1.0;
   for (int sp = 1; sp <= 16 && sp <= tiles; ++sp) {
@@ -429,16 +445,8 @@ void launch_nn_screen(const float* a, const float* b, const void* ah, const void
   const dim3 grid((unsigned)((int64_t)rb_count * splits * pairs));
   const _Float16 *Ah = reinterpret_cast<const _Float16*>(ah), *Al = reinterpret_cast<const _Float16*>(al);
   const _Float16 *Bh = reinterpret_cast<const _Float16*>(bh), *Bl = reinterpret_cast<const _Float16*>(bl);
-  static const bool two_pass = getenv("DSIR_SCREEN_2PASS") != nullptr;
-  if (two_pass) {
-    hipLaunchKernelGGL((screen_kernel<RT, 1, NWV>), grid, dim3(NWV * 64), 0, st, Ah, Al, Bh, Bl, sa, sb, J, K, cols, rb_count, splits,
-                       umin, cnt, cand, ovf, rowlist, ovf_min);
-    hipLaunchKernelGGL((screen_kernel<RT, 2, NWV>), grid, dim3(NWV * 64), 0, st, Ah, Al, Bh, Bl, sa, sb, J, K, cols, rb_count, splits,
-                       umin, cnt, cand, ovf, rowlist, ovf_min);
-  } else {
-    hipLaunchKernelGGL((screen_kernel<RT, 3, NWV>), grid, dim3(NWV * 64), 0, st, Ah, Al, Bh, Bl, sa, sb, J, K, cols, rb_count, splits,
-                       umin, cnt, cand, ovf, rowlist, ovf_min);
-  }
+  hipLaunchKernelGGL((screen_kernel<RT, NWV>), grid, dim3(NWV * 64), 0, st, Ah, Al, Bh, Bl, sa, sb, J, K, cols, rb_count, splits, umin,
+                     cnt, cand, ovf, rowlist, ovf_min);
   hipLaunchKernelGGL(exact_pick_kernel, dim3((J + 255) / 256, pairs), dim3(256), 0, st, a, b, sa, sb, J, K, umin, cnt, cand, ovf,
                      ovf_min, rowlist, idx);
   launch_nn_match_gated(a, b, sa, sb, pairs, J, K, packed, ovf, ovf_min, rowlist, st);
