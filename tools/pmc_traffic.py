@@ -6,7 +6,7 @@ import csv, glob, json, sys
 
 fetch_dir, write_dir, pairs, points, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
 # kernels that make up one arg-min launch: the exhaustive kernel, or the screened path's passes (argv[6] = "screened")
-NAMES = ("screen_kernel", "exact_pick_kernel") if len(sys.argv) > 6 and sys.argv[6] == "screened" else ("nn_match_kernel",)
+NAMES = ("screen_kernel", "exact_pick_kernel", "nn_match_kernel", "unpack_listed_kernel") if len(sys.argv) > 6 and sys.argv[6] == "screened" else ("nn_match_kernel",)
 
 
 def mean_counter(d, name):
