@@ -8,6 +8,7 @@ Per-stage float tensors are compared at rtol/atol 2e-4 against values of O(1)
 (fp32 summation-order noise of ~35 chained layers).
 """
 import json
+import os
 
 import numpy as np
 import pytest
@@ -564,4 +565,44 @@ def test_screened_argmin_equals_exhaustive(kind):
     assert np.array_equal(scr, exact)
     if kind in ("duplicates", "near_ties"):
         assert nexh > 0            # the overflow path is exercised
+    eng.close()
+
+
+def test_register_screened_equals_exhaustive(tmp_path):
+    """A whole registration large enough for the screened arg-min (P*J*K >= 2e8, csrc/engine.hip) must produce the same
+    bits - correspondences, inlier logits, transforms - as the same registration with the exhaustive exact-fp32 kernel
+    (DSIR_NO_SCREEN=1; the switch is read once per process, hence two child processes)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for name, extra in (("screened", {}), ("exhaustive", {"DSIR_NO_SCREEN": "1"})):
+        out = str(tmp_path / f"{name}.npz")
+        env = dict(os.environ, **extra)
+        env.pop("DSIR_SCREEN_OVF_MIN", None)
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "register_dump.py"), out, "10", "5000", "4"], env=env,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(out))
+    a, b = outs
+    for k in ("idx", "logits", "transforms"):
+        assert np.array_equal(a[k], b[k]), f"{k} differs between the screened and the exhaustive arg-min"
+
+
+def test_screened_argmin_out_of_domain_inputs():
+    """Elements beyond the fp16 range or not finite void the screening bound: split16 raises its flag and every pair is
+    searched by the exhaustive kernel, so the result still equals dsir_nn_match."""
+    from deepsir_amd.arch import NetConfig
+    from deepsir_amd.engine import Engine
+    rng = np.random.Generator(np.random.Philox(key=91))
+    P, J, K = 2, 1500, 1700
+    a = rng.standard_normal((P, J, 64)).astype(np.float32)
+    b = rng.standard_normal((P, K, 64)).astype(np.float32)
+    b[1, 17, 3] = 1.0e5                                        # beyond fp16
+    a[0, 5, :] *= 1.0e-9                                       # below the fp16 subnormals: covered by the bound's constant
+    eng = Engine(NetConfig(), 0, max_points=2048, max_pairs=2)
+    ta, tb = cu(a), cu(b)
+    exact = eng.nn_match(ta, tb).cpu().numpy()
+    scr, (ncand, nexh) = eng.nn_match_screened(ta, tb)
+    assert np.array_equal(scr.cpu().numpy(), exact)
+    assert nexh == P * J                                       # every row went to the exhaustive kernel
     eng.close()
