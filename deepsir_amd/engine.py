@@ -195,7 +195,7 @@ class Engine:
 
     def nn_match_screened(self, desc_src, desc_ref, want_stats=True):
         """Same arg-min as nn_match, computed the way dsir_register does (fp16-split screening + exact fp32 decision).
-        Returns (idx [p,J] i32, (total candidates, exhaustively scanned rows))."""
+        Returns (idx [p,J] i32, (candidate entries emitted by the screening, rows left to the exhaustive kernel))."""
         desc_src, desc_ref = _chk(desc_src, torch.float32, "desc_src"), _chk(desc_ref, torch.float32, "desc_ref")
         p, J, _ = desc_src.shape
         K = desc_ref.shape[1]

@@ -127,8 +127,10 @@ int dsir_nn_match(dsir_ctx* ctx, const float* desc_src, const float* desc_ref, i
 
 /* The same arg-min as dsir_nn_match, bit for bit, the way dsir_register computes it: columns are first discarded by an
  * fp16-split MFMA screening with a rigorous error bound, the exact fp32 formula then decides among the survivors
- * (csrc/nn_screen.hip).  Assumes |descriptor| <= ~1 per component (fp16 range; descriptors are L2-normalised).
- * stats (HOST, optional): [0] = total surviving candidates, [1] = rows that fell back to the exhaustive exact scan. */
+ * (csrc/nn_screen.hip); rows the screening cannot decide are searched by the exhaustive fp32 kernel of dsir_nn_match.
+ * Any finite input gives the exact result: components beyond the fp16 range (|x| > 2^15) or not finite switch the whole
+ * call to the exhaustive kernel.
+ * stats (HOST, optional): [0] = candidate entries emitted by the screening, [1] = rows left to the exhaustive kernel. */
 int dsir_nn_match_screened(dsir_ctx* ctx, const float* desc_src, const float* desc_ref, int pairs, int J, int K,
                            int32_t* idx, int64_t* stats);
 
