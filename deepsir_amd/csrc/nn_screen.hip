@@ -109,10 +109,11 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(DSIR_S
                                                      unsigned int* __restrict__ umin, int32_t* __restrict__ cnt,
                                                      int2* __restrict__ cand, int32_t* __restrict__ ovf,
                                                      int32_t* __restrict__ rowlist, int ovf_min) {
-  static_assert(NWV * 64 == SBC * 8, "one 16-byte piece of each tile part per thread");
+  constexpr int NP = SBC * 8 / (NWV * 64);          // 16-byte pieces of each tile part per thread
+  static_assert(NP >= 1 && NP * NWV * 64 == SBC * 8 && NWV * 64 % (4 * SBC) == 0, "staging layout");
   __shared__ _Float16 Bs[2][2][SBC * SRS];          // [buffer][high | low part]
-  __shared__ float4 sbs[2][2 * SBC];                // -(|b|^2 - d_b) / 2, replicated: the MFMA accumulators start from it
-                                                    // (two copies: one float per thread, no branch in the loop body)
+  __shared__ float4 sbs[2][NWV * 16];               // -(|b|^2 - d_b) / 2, replicated: the MFMA accumulators start from it
+                                                    // (one float per thread, no branch in the loop body)
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fq = lane >> 4;
   const int nwg = gridDim.x, id = blockIdx.x;
@@ -151,19 +152,27 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(DSIR_S
   // staging: thread -> 16-byte piece (8 channels) of the tile: column tid >> 3, piece tid & 7
   // two register sets: a tile is fetched two iterations before it is needed (the L2 / MALL latency under load exceeds
   // the time of one tile) and written to the free LDS buffer at the end of the iteration before
-  struct Pre { h8 h, l; float sb; };
+  struct Pre { h8 h[NP], l[NP]; float sb; };
   Pre preA, preB;
   auto gload = [&](Pre& pre, int c0) {
-    const int r = min(c0 + (tid >> 3), K - 1);
-    pre.h = *reinterpret_cast<const h8*>(Bh + (brow + r) * 64 + 8 * (tid & 7));
-    pre.l = *reinterpret_cast<const h8*>(Bl + (brow + r) * 64 + 8 * (tid & 7));
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int f = tid + NWV * 64 * i;
+      const int r = min(c0 + (f >> 3), K - 1);
+      pre.h[i] = *reinterpret_cast<const h8*>(Bh + (brow + r) * 64 + 8 * (f & 7));
+      pre.l[i] = *reinterpret_cast<const h8*>(Bl + (brow + r) * 64 + 8 * (f & 7));
+    }
     const int col = c0 + ((tid >> 2) & (SBC - 1));
     const float s = sb[brow + min(col, K - 1)];
     pre.sb = col < c_end ? -0.5f * (s - kC1 * s) : -INFINITY;   // columns past the range never win
   };
   auto lstore = [&](const Pre& pre, int buf) {
-    *reinterpret_cast<h8*>(&Bs[buf][0][(tid >> 3) * SRS + 8 * (tid & 7)]) = pre.h;
-    *reinterpret_cast<h8*>(&Bs[buf][1][(tid >> 3) * SRS + 8 * (tid & 7)]) = pre.l;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int f = tid + NWV * 64 * i;
+      *reinterpret_cast<h8*>(&Bs[buf][0][(f >> 3) * SRS + 8 * (f & 7)]) = pre.h[i];
+      *reinterpret_cast<h8*>(&Bs[buf][1][(f >> 3) * SRS + 8 * (f & 7)]) = pre.l[i];
+    }
     reinterpret_cast<float*>(sbs[buf])[tid] = pre.sb;
   };
   f32x4 hhP[RT], mxP[RT];
