@@ -384,9 +384,17 @@ __global__ void screen_stats_kernel(const int32_t* __restrict__ cnt, int64_t row
 
 // between the searches of one registration: a pair found not selective stays so (its descriptors barely change from one
 // iteration to the next), every other counter restarts.  Input outside the bound's domain: every pair exhaustive.
-__global__ void screen_reset_kernel(int32_t* __restrict__ ovf, int pairs, int ovf_min, int keep, const int32_t* __restrict__ bad) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p < pairs) ovf[p] = (bad && *bad) ? ovf_min : ((keep && ovf[p] >= ovf_min) ? ovf[p] : 0);
+// Also the per-row scratch of one search: threshold = +max, entry count = 0, packed result = all ones.
+__global__ void screen_reset_kernel(int32_t* __restrict__ ovf, int pairs, int ovf_min, int keep, const int32_t* __restrict__ bad,
+                                    unsigned int* __restrict__ umin, int32_t* __restrict__ cnt,
+                                    unsigned long long* __restrict__ packed, int64_t rows) {
+  const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i0 < pairs) ovf[i0] = (bad && *bad) ? ovf_min : ((keep && ovf[i0] >= ovf_min) ? ovf[i0] : 0);
+  for (int64_t i = i0; i < rows; i += (int64_t)gridDim.x * blockDim.x) {
+    umin[i] = 0xffffffffu;
+    cnt[i] = 0;
+    packed[i] = ~0ull;
+  }
 }
 
 inline int grid_for(int64_t n) { const int64_t g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > 65535 ? 65535 : g)); }
@@ -426,10 +434,12 @@ void launch_nn_screen(const float* a, const float* b, const void* ah, const void
   static const int force_min = getenv("DSIR_SCREEN_OVF_MIN") ? atoi(getenv("DSIR_SCREEN_OVF_MIN")) : 0;   // tuning/test hook
   const int ovf_min = force_min > 0 ? force_min : J / 4 + 1;
   if (ev0) (void)hipEventRecord(ev0, st);
-  (void)hipMemsetAsync(umin, 0xff, rows * 4, st);
-  (void)hipMemsetAsync(cnt, 0, rows * 4, st);
-  hipLaunchKernelGGL(screen_reset_kernel, dim3((pairs + 255) / 256), dim3(256), 0, st, ovf, pairs, ovf_min, keep_gate ? 1 : 0, bad);
-  (void)hipMemsetAsync(packed, 0xff, rows * 8, st);
+  {
+    const int64_t need = ((int64_t)rows + 255) / 256, min_blocks = (pairs + 255) / 256;
+    const int blocks = (int)(need > 2048 ? 2048 : (need < min_blocks ? min_blocks : need));
+    hipLaunchKernelGGL(screen_reset_kernel, dim3(blocks), dim3(256), 0, st, ovf, pairs, ovf_min, keep_gate ? 1 : 0, bad, umin, cnt,
+                       packed, (int64_t)rows);
+  }
   constexpr int RT = DSIR_SCREEN_RT;
   constexpr int NWV = 8;   // waves per block: 8 x 32 rows share one staged ref tile (the L2 -> LDS fill is the scarce resource)
   const int rows_per_block = NWV * 16 * RT;
