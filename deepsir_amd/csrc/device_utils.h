@@ -92,4 +92,13 @@ __device__ __forceinline__ void atomic_max_float(float* addr, float v) {
   else          atomicMin(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
 }
 
+
+// |x|^2 of a 64-channel descriptor row held by 16 consecutive lanes (float4 each), in the one summation order every
+// user of the descriptor distance shares (nn_match.hip, nn_screen.hip): the value enters D = (-2 a.b + |a|^2) + |b|^2.
+__device__ __forceinline__ float sqnorm_row16(const float4 v) {
+  float s = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
+  return s;
+}
+
 }  // namespace dsir

@@ -809,10 +809,8 @@ int dsir_nn_match_screened(dsir_ctx* c, const float* a, const float* b, int pair
   if (ws.overflow) return fail(c, "workspace exhausted in nn_match_screened");
   hipStream_t st = c->stream;
   HIP_OK(c, hipMemsetAsync(bad, 0, 4, st));
-  launch_split16(a, (int64_t)pairs * J, ah, al, st, bad);
-  launch_split16(b, (int64_t)pairs * K, bh, bl, st, bad);
-  launch_sqnorm(a, (int64_t)pairs * J, sa, st);
-  launch_sqnorm(b, (int64_t)pairs * K, sb, st);
+  launch_split16_norm(a, (int64_t)pairs * J, ah, al, sa, st, bad);
+  launch_split16_norm(b, (int64_t)pairs * K, bh, bl, sb, st, bad);
   launch_nn_screen(a, b, ah, al, bh, bl, sa, sb, pairs, J, K, idx, scratch, st, nullptr, nullptr, stats ? dstats : nullptr,
                    /*keep_gate=*/false, bad);
   if (stats) {
@@ -998,8 +996,7 @@ static int register_enqueue(dsir_ctx* c, const dsir_pair_batch* in, int n_iter, 
     run_att_proj(c, rxyz, (int64_t)pr.S * 3, score_r, F_r, P, K, desc_r);
     ws.release(mark1);
     if (screen) {
-      launch_split16(desc_r, (int64_t)P * K, sc_bh, sc_bl, st);
-      launch_sqnorm(desc_r, (int64_t)P * K, sc_sb, st);
+      launch_split16_norm(desc_r, (int64_t)P * K, sc_bh, sc_bl, sc_sb, st);
     }
     float* F_tmp = run_mlp_feat(c, feat_s, P, J);
     HIP_OK(c, hipMemcpyAsync(F_s, F_tmp, sizeof(float) * P * J * 64, hipMemcpyDeviceToDevice, st));
@@ -1030,8 +1027,7 @@ static int register_enqueue(dsir_ctx* c, const dsir_pair_batch* in, int n_iter, 
         ++c->match_events_used;
       }
       if (screen) {
-        launch_split16(desc_s, (int64_t)P * J, sc_ah, sc_al, st);
-        launch_sqnorm(desc_s, (int64_t)P * J, sc_sa, st);
+        launch_split16_norm(desc_s, (int64_t)P * J, sc_ah, sc_al, sc_sa, st);
         launch_nn_screen(desc_s, desc_r, sc_ah, sc_al, sc_bh, sc_bl, sc_sa, sc_sb, P, J, K, idx_out, sc_scratch, st, e0, e1, nullptr,
                          /*keep_gate=*/it > 0);
       } else {

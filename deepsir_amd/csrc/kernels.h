@@ -168,6 +168,8 @@ void launch_sqnorm(const float* x, int64_t rows, float* out, hipStream_t st);   
 size_t nn_screen_scratch_bytes(int pairs, int J);
 // fp32 [rows][64] -> fp16 hi / lo; `bad` (optional device flag) is set when an element is outside the screening's domain
 void launch_split16(const float* x, int64_t rows, void* hi, void* lo, hipStream_t st, int32_t* bad = nullptr);
+// the same split plus launch_sqnorm's |x|^2 per row, one pass
+void launch_split16_norm(const float* x, int64_t rows, void* hi, void* lo, float* sq, hipStream_t st, int32_t* bad = nullptr);
 void launch_nn_screen(const float* a, const float* b, const void* ah, const void* al, const void* bh, const void* bl,
                       const float* sa, const float* sb, int pairs, int J, int K, int32_t* idx, void* scratch, hipStream_t st,
                       hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, unsigned long long* stats = nullptr,

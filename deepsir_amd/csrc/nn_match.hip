@@ -35,12 +35,9 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ x
                                                      unsigned long long* __restrict__ init) {
   const int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
   const int l = threadIdx.x & 15;
-  float s = 0.f;
-  if (row < rows) {
-    const float4 v = *reinterpret_cast<const float4*>(x + row * 64 + l * 4);
-    s = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-  }
-  s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (row < rows) v = *reinterpret_cast<const float4*>(x + row * 64 + l * 4);
+  const float s = sqnorm_row16(v);
   if (row < rows && l == 0) {
     out[row] = s;
     if (init) init[row] = ~0ull;

@@ -98,6 +98,33 @@ __global__ __launch_bounds__(256) void split16_kernel(const float* __restrict__ 
 // largest z and the column of the largest; L = |a|^2_low - 2 z) while the MFMAs of the next step run.  One workgroup of
 // 8 waves per CU (194 VGPRs): measured equal to two workgroups of a leaner, unpipelined variant on its own, and better
 // when other streams share the GPU.
+// split16_kernel and the squared norm of each row (sqnorm_kernel's arithmetic) in one pass over the descriptors
+__global__ __launch_bounds__(256) void split_norm_kernel(const float* __restrict__ x, int64_t rows, _Float16* __restrict__ hi,
+                                                         _Float16* __restrict__ lo, float* __restrict__ sq,
+                                                         int32_t* __restrict__ bad) {
+  const int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int l = threadIdx.x & 15;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (row < rows) v = *reinterpret_cast<const float4*>(x + row * 64 + l * 4);
+  const float s = sqnorm_row16(v);
+  if (row >= rows) return;
+  const float f[4] = {v.x, v.y, v.z, v.w};
+  if (bad && !(fmaxf(fmaxf(fabsf(f[0]), fabsf(f[1])), fmaxf(fabsf(f[2]), fabsf(f[3]))) <= 32768.f &&
+               f[0] == f[0] && f[1] == f[1] && f[2] == f[2] && f[3] == f[3]))
+    *bad = 1;
+  h4 h, lw;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    _Float16 t = (_Float16)f[k];
+    if (fabsf((float)t) < 6.103515625e-05f) t = (_Float16)0.f;          // no fp16 subnormals in the high part
+    h[k] = t;
+    lw[k] = (_Float16)((f[k] - (float)t) * 2048.0f);
+  }
+  *reinterpret_cast<h4*>(hi + row * 64 + l * 4) = h;
+  *reinterpret_cast<h4*>(lo + row * 64 + l * 4) = lw;
+  if (l == 0) sq[row] = s;
+}
+
 #ifndef DSIR_SCREEN_WPE
 #define DSIR_SCREEN_WPE 2
 #endif
@@ -413,6 +440,11 @@ void launch_split16(const float* x, int64_t rows, void* hi, void* lo, hipStream_
   const int64_t n4 = rows * 16;
   hipLaunchKernelGGL(split16_kernel, dim3(grid_for(n4)), dim3(256), 0, st, x, n4, reinterpret_cast<_Float16*>(hi),
                      reinterpret_cast<_Float16*>(lo), bad);
+}
+
+void launch_split16_norm(const float* x, int64_t rows, void* hi, void* lo, float* sq, hipStream_t st, int32_t* bad) {
+  hipLaunchKernelGGL(split_norm_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, st, x, rows,
+                     reinterpret_cast<_Float16*>(hi), reinterpret_cast<_Float16*>(lo), sq, bad);
 }
 
 // a, b: fp32 descriptors [pairs][J|K][64] with their fp16 splits (ah, al, bh, bl) and squared norms (sa, sb)
