@@ -151,9 +151,13 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(DSIR_S
   const int pair = wi / (rb_count * splits);
   const int row0 = (rb * NWV + w) * (16 * RT);
   const int64_t arow = (int64_t)pair * J, brow = (int64_t)pair * K;
-  // a pair with that many undecidable rows is searched exhaustively as a whole (block-uniform exit before any barrier;
-  // the counter only grows, so exiting on a value seen mid-launch is safe)
-  if (ovf[pair] >= ovf_min) return;
+  // a pair with that many undecidable rows is searched exhaustively as a whole.  The counter grows while the kernel runs
+  // (other workgroups list rows), so ONE thread reads it and the workgroup decides together: exiting on a value seen
+  // mid-launch is safe, a workgroup whose threads disagree would hang at the first barrier
+  __shared__ int s_skip;
+  if (tid == 0) s_skip = ovf[pair] >= ovf_min ? 1 : 0;
+  __syncthreads();
+  if (s_skip) return;
 
   // A fragments: lane holds row fr, channels 32 c + 8 fq .. +7
   h8 ah[RT][2], al[RT][2];
