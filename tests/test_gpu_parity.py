@@ -606,3 +606,27 @@ def test_screened_argmin_out_of_domain_inputs():
     assert np.array_equal(scr.cpu().numpy(), exact)
     assert nexh == P * J                                       # every row went to the exhaustive kernel
     eng.close()
+
+
+@pytest.mark.parametrize("P,J,K", [(1, 1, 1), (3, 17, 63), (2, 257, 65), (1, 64, 64), (2, 255, 129), (1, 1000, 4097), (5, 300, 20),
+                                   (1, 4096, 16), (2, 513, 1025)])
+def test_screened_argmin_shapes(P, J, K):
+    """Ragged shapes of the screened arg-min (rows not a multiple of the 256-row workgroup, columns not a multiple of the
+    64-column tile, fewer columns than one tile, a single row / column): equal to the exhaustive kernel."""
+    from deepsir_amd.arch import NetConfig
+    from deepsir_amd.engine import Engine
+    rng = np.random.Generator(np.random.Philox(key=1000 * P + 10 * J + K))
+    a = rng.standard_normal((P, J, 64)).astype(np.float32)
+    b = rng.standard_normal((P, K, 64)).astype(np.float32)
+    if K > 3:
+        b[:, K // 2] = b[:, K // 3]                           # an exact tie between two columns
+    m = min(J, K)
+    a[:, :m:5] = b[:, :m:5] + 1e-4 * rng.standard_normal((P, len(range(0, m, 5)), 64)).astype(np.float32)   # near matches
+    a /= np.linalg.norm(a, axis=2, keepdims=True)
+    b /= np.linalg.norm(b, axis=2, keepdims=True)
+    eng = Engine(NetConfig(), 0, max_points=max(1024, J, K), max_pairs=P)
+    ta, tb = cu(a), cu(b)
+    exact = eng.nn_match(ta, tb).cpu().numpy()
+    scr, _ = eng.nn_match_screened(ta, tb)
+    assert np.array_equal(scr.cpu().numpy(), exact)
+    eng.close()
