@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--shape", default="3dmatch", choices=["3dmatch", "kitti"], help="extent of the synthetic clouds")
     ap.add_argument("--partial-overlap", action="store_true", help="config 5: 50 %% overlap crops + jitter")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 latency phase (profiling runs)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -212,7 +213,7 @@ def main():
     # batch-1 latency (the reference's own evaluation mode, test.py:56 BATCH_SIZE = 1): one pair in flight,
     # launch sequence replayed from a hipGraph.  Reported beside the throughput number, not as `value`.
     latency = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not a.no_latency:
         s1, r1 = src[:1].contiguous(), ref[:1].contiguous()
         eng.enable_graph(True)
         o1 = eng.register(s1, r1, n_iter, want_aux=False)
