@@ -39,8 +39,7 @@ def inference_align(pairs: Sequence[Dict[str, np.ndarray]], model, num_reg_iter:
     opt = (num_reg_iter, True)
     for b0 in range(0, len(mine), batch):
         ids = mine[b0:b0 + batch]
-        keys = [k for k in pairs[ids[0]] if k != "others" and isinstance(pairs[ids[0]][k], np.ndarray)]
-        data = {k: torch.from_numpy(np.concatenate([pairs[i][k] for i in ids], 0)).to(device) for k in keys}
+        data = _stack(pairs, ids, device)
         torch.cuda.synchronize(device)
         t0 = time.time()
         transforms, endpoints = model(data, opt)
@@ -64,7 +63,7 @@ def inference_align(pairs: Sequence[Dict[str, np.ndarray]], model, num_reg_iter:
             stats[row, :3] = rte_rre(T[j, -1], gt[j], rte_t, rre_t)
             stats[row, 3] = dt
             others = pairs[i].get("others")
-            stats[row, 4] = others[0]["seq"] if others else -1
+            stats[row, 4] = _seq_id(others[0]["seq"]) if others else -1
     pred = np.concatenate(preds, 0) if preds else np.zeros((0, num_reg_iter + 1, 3, 4), np.float32)
     if world > 1:
         sizes = shard_sizes(len(pairs), world)
@@ -103,9 +102,10 @@ def evaluate_align(pred_transforms: np.ndarray, pairs: Sequence[Dict[str, np.nda
     acc = [dict((k, []) for k in engine.METRIC_NAMES) for _ in range(n_it)]
     for b0 in range(0, len(pairs), batch):
         ids = range(b0, min(len(pairs), b0 + batch))
-        src = torch.from_numpy(np.concatenate([pairs[i]["points_src"][:, :1024] for i in ids], 0)).to(device)
-        ref = torch.from_numpy(np.concatenate([pairs[i]["points_ref"][:, :1024] for i in ids], 0)).to(device)
-        gt = torch.from_numpy(np.concatenate([pairs[i]["transform_gt"] for i in ids], 0)).float().to(device)
+        def head(k):   # numpy (reference collate) or device tensors (deepsir_amd.data)
+            return torch.cat([torch.as_tensor(pairs[i][k][:, :1024]).to(device) for i in ids], 0).float().contiguous()
+        src, ref = head("points_src"), head("points_ref")
+        gt = torch.cat([torch.as_tensor(pairs[i]["transform_gt"]).to(device) for i in ids], 0).float()
         for it in range(n_it):
             m = engine.eval_metrics(pred[b0:b0 + len(ids), it], gt, src, ref, rte_t, rre_t)
             for k, v in m.items():
@@ -185,11 +185,35 @@ class SemanticMetric:
         return out
 
 
+def _stack(pairs, ids, device):
+    """Batch the array entries of the pair dicts `ids` on the device: numpy (the reference's collate output) or torch
+    tensors (deepsir_amd.data: already resident), each with a leading batch dimension of 1."""
+    out = {}
+    for k, v in pairs[ids[0]].items():
+        if k == "others":
+            continue
+        if isinstance(v, np.ndarray):
+            out[k] = torch.from_numpy(np.concatenate([pairs[i][k] for i in ids], 0)).to(device)
+        elif isinstance(v, torch.Tensor):
+            out[k] = torch.cat([pairs[i][k].to(device) for i in ids], 0)
+    return out
+
+
+_SEQ_IDS: Dict[str, int] = {}
+
+
+def _seq_id(seq) -> float:
+    """The sequence column of the stats table (test.py:439) is numeric; scene NAMES (3DMatch) get a running index."""
+    try:
+        return float(seq)
+    except (TypeError, ValueError):
+        return float(_SEQ_IDS.setdefault(str(seq), len(_SEQ_IDS)))
+
+
 def _pair_batches(pairs, batch, device):
     for b0 in range(0, len(pairs), batch):
         ids = list(range(b0, min(b0 + batch, len(pairs))))
-        keys = [k for k in pairs[ids[0]] if k != "others" and isinstance(pairs[ids[0]][k], np.ndarray)]
-        yield ids, {k: torch.from_numpy(np.concatenate([pairs[i][k] for i in ids], 0)).to(device) for k in keys}
+        yield ids, _stack(pairs, ids, device)
 
 
 @torch.no_grad()
