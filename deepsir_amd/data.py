@@ -37,6 +37,12 @@ THREEDMATCH_TEST_SCENES = (
     "sun3d-mit_76_studyroom-76-1studyroom2", "sun3d-mit_lab_hj-lab_hj_tea_nov_2_2012_scan1_erika")
 KITTI_TEST_SEQUENCES = (8, 9, 10)
 
+# SemanticKITTI `learning_map` (raw label -> training class 0..19, 0 = unlabeled): the public SemanticKITTI API table the
+# reference reads from dataloader/semantic-kitti.yaml (kitti_loader.py:358-362)
+SEMANTIC_KITTI_LEARNING_MAP = {0: 0, 1: 0, 10: 1, 11: 2, 13: 5, 15: 3, 16: 5, 18: 4, 20: 5, 30: 6, 31: 7, 32: 8, 40: 9, 44: 10,
+                               48: 11, 49: 12, 50: 13, 51: 14, 52: 0, 60: 9, 70: 15, 71: 16, 72: 17, 80: 18, 81: 19, 99: 0,
+                               252: 1, 253: 7, 254: 6, 255: 8, 256: 5, 257: 5, 258: 4, 259: 5}
+
 # velodyne -> camera-0 calibration the reference hard-codes (kitti_loader.py:148-159)
 _VELO2CAM = np.array([[7.533745e-03, -9.999714e-01, -6.166020e-04, -4.069766e-03],
                       [1.480249e-02, 7.280733e-04, -9.998902e-01, -7.631618e-02],
@@ -127,6 +133,21 @@ def read_velodyne(path: str) -> np.ndarray:
     return a.reshape(-1, 4)
 
 
+def read_semantic_labels(path: str, n: Optional[int] = None) -> np.ndarray:
+    """SemanticKITTI `.label` file: one uint32 per point, semantic label in the lower 16 bits (instance id above), mapped
+    through `learning_map` -> [n] uint8 training classes (kitti_loader.py:368-377)."""
+    raw = np.fromfile(path, dtype=np.uint32) & 0xFFFF
+    if n is not None and raw.size != n:
+        raise ValueError(f"{path}: {raw.size} labels for {n} points")
+    lut = np.zeros(65536, dtype=np.int32) - 1
+    for k, v in SEMANTIC_KITTI_LEARNING_MAP.items():
+        lut[k] = v
+    out = lut[raw]
+    if (out < 0).any():
+        raise KeyError(f"{path}: label {int(raw[out < 0][0])} is not in the SemanticKITTI learning map")
+    return out.astype(np.uint8)
+
+
 def _to_device(engine, a: np.ndarray) -> torch.Tensor:
     return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(engine.device)
 
@@ -142,8 +163,12 @@ def _voxelize(engine, clouds: Sequence[np.ndarray], voxel_size: float, crop=None
 def as_batch(item: Dict[str, object]) -> Dict[str, object]:
     """One dataset sample -> the batch-of-one dict of the reference's collate (data_base.py:196-219), points staying on
     the device: what `harness.inference_align` / `evaluate_align` take as an element of `pairs`."""
-    return {"points_src": item["points_src"][None].contiguous(), "points_ref": item["points_ref"][None].contiguous(),
-            "transform_gt": np.asarray(item["transform_gt"], dtype=np.float32)[None], "others": [item["others"]]}
+    out = {"points_src": item["points_src"][None].contiguous(), "points_ref": item["points_ref"][None].contiguous(),
+           "transform_gt": np.asarray(item["transform_gt"], dtype=np.float32)[None], "others": [item["others"]]}
+    for k in ("labels_src", "labels_ref"):
+        if k in item:
+            out[k] = item[k][None].contiguous()
+    return out
 
 
 class ThreeDMatchTest:
@@ -190,18 +215,26 @@ class KittiOdometryTest:
     (3 m < r <= 60 m, -3 m <= z <= 10 m) and voxel-averaged at `voxel_size` with the reflectance as 4th channel, and
     the ground-truth pose: odometry poses through the velodyne calibration, refined by point-to-point ICP (0.2 m,
     <= 200 iterations, on 0.05 m voxels) and cached as `<root>/icp_opti_pose/<drive>_<t0>_<t1>.npy` - the
-    reference's cache file, so either side can reuse the other's."""
+    reference's cache file, so either side can reuse the other's.
+
+    Sizes: `num_points` None = what the reference's test split does (SemanticKITTIPair.__getitem__ with fixed=True,
+    apply_augment_V2, data_base.py:271-283): the cloud with fewer voxels is tiled (FixedResampler) to the size of the
+    other; an int = seeded random resample of both to that size (Resampler).  `with_labels`: the SemanticKITTI class of
+    every point rides through the voxel average as a 5th channel and is truncated to an integer afterwards, exactly the
+    reference's treatment (kitti_loader.py:324-341, :401-402): `labels_src` / `labels_ref` [n] int32."""
 
     MIN_DIST = 10.0
 
     def __init__(self, root: str, engine, sequences: Sequence[int] = KITTI_TEST_SEQUENCES, voxel_size: float = 0.3,
-                 feat_len: int = 4, num_points: Optional[int] = None, seed: int = 0, refine_pose: bool = True):
+                 feat_len: int = 4, num_points: Optional[int] = None, seed: int = 0, refine_pose: bool = True,
+                 with_labels: bool = False):
         self.root_path = os.path.join(root, "dataset")
         if not os.path.isdir(self.root_path):
             raise FileNotFoundError(f"Invalid path: {self.root_path}")
         self.icp_path = os.path.join(root, "icp_opti_pose")
         self.engine, self.voxel_size, self.feat_len = engine, float(voxel_size), int(feat_len)
         self.num_points, self.seed, self.refine_pose = num_points, int(seed), bool(refine_pose)
+        self.with_labels = bool(with_labels)
         self._poses: Dict[int, np.ndarray] = {}
         self.files: List[Tuple[int, int, int]] = []
         for drive in sequences:
@@ -290,11 +323,21 @@ class KittiOdometryTest:
             return c[(r2 <= crop[1] ** 2) & (r2 > crop[0] ** 2) & (c[:, 2] >= crop[2]) & (c[:, 2] <= crop[3])]
         T_gt = self.gt_pose(drive, t0, t1, crop_host(xyz0), crop_host(xyz1))
         C = max(3, min(self.feat_len, 4))
-        if self.num_points:
-            pts, _ = self.engine.preprocess([_to_device(self.engine, xyz0[:, :C]), _to_device(self.engine, xyz1[:, :C])],
-                                            self.voxel_size, int(self.num_points), seed=self.seed + index, crop=crop)
-            v0, v1 = pts[0], pts[1]
+        raw = [xyz0, xyz1]
+        if self.with_labels:
+            lab = os.path.join(self.root_path, "sequences", "%02d" % drive, "labels")
+            raw = [np.concatenate([c, read_semantic_labels(os.path.join(lab, "%06d.label" % t), len(c))[:, None].astype(np.float32)], 1)
+                   for c, t in ((xyz0, t0), (xyz1, t1))]          # [x, y, z, reflectance, class]
         else:
-            v0, v1 = _voxelize(self.engine, [xyz0[:, :C], xyz1[:, :C]], self.voxel_size, crop)
-        return {"points_src": v0, "points_ref": v1, "transform_gt": T_gt[:3, :].astype(np.float32),
-                "others": {"seq": drive, "id_src": t0, "id_ref": t1}}
+            raw = [c[:, :C] for c in raw]
+        vox, counts = self.engine.voxel_downsample([_to_device(self.engine, c) for c in raw], self.voxel_size, crop)
+        if self.num_points:
+            pts = self.engine.resample(vox, counts, int(self.num_points), self.seed + index, "random")
+        else:
+            pts = self.engine.resample(vox, counts, int(counts.max().item()), 0, "fixed")
+        out = {"points_src": pts[0, :, :C].contiguous(), "points_ref": pts[1, :, :C].contiguous(),
+               "transform_gt": T_gt[:3, :].astype(np.float32), "others": {"seq": drive, "id_src": t0, "id_ref": t1}}
+        if self.with_labels:
+            out["labels_src"] = pts[0, :, 4].to(torch.int32)       # astype(np.int32): truncation of the voxel mean
+            out["labels_ref"] = pts[1, :, 4].to(torch.int32)
+        return out

@@ -153,6 +153,20 @@ def test_kitti_drops_the_known_bad_pair(tmp_path, monkeypatch):
     assert ds.files == [(8, 0, 11), (8, 59, 70)]
 
 
+def test_read_semantic_labels(tmp_path):
+    raw = np.array([0, 1, 10, 252, 40, 60, 99, 259, 81], dtype=np.uint32)
+    inst = (np.arange(len(raw), dtype=np.uint32) + 3) << 16            # instance ids in the upper half are dropped
+    p = tmp_path / "000000.label"
+    (raw | inst).tofile(p)
+    got = D.read_semantic_labels(str(p), len(raw))
+    assert got.dtype == np.uint8 and got.tolist() == [0, 0, 1, 1, 9, 9, 0, 5, 19]
+    with pytest.raises(ValueError):
+        D.read_semantic_labels(str(p), 5)
+    np.array([7], dtype=np.uint32).tofile(p)                           # 7 is not a SemanticKITTI label
+    with pytest.raises(KeyError):
+        D.read_semantic_labels(str(p))
+
+
 # --------------------------------------------------------------------------------------------- GPU
 @pytest.mark.gpu
 def test_threedmatch_test_split_end_to_end(tmp_path):
@@ -259,3 +273,48 @@ def test_dataset_to_metrics_through_the_harness(tmp_path):
     assert pred.shape == (1, 3, 3, 4) and np.isfinite(pred).all() and stats.shape == (1, 5)
     metrics, summary = evaluate_align(pred, pairs, eng, "3DMatch")
     assert len(metrics) == 3 and all(np.isfinite(v).all() for v in metrics[-1].values())
+
+
+@pytest.mark.gpu
+def test_kitti_labels_and_fixed_equalisation(tmp_path):
+    """SemanticKITTIPair's test branch: labels ride through the voxel average as a channel and are truncated; the cloud
+    with fewer voxels is tiled to the size of the other (FixedResampler)."""
+    from deepsir_amd.arch import NetConfig
+    from deepsir_amd.engine import Engine
+    from oracle.preprocess import voxel_downsample
+    rng = np.random.default_rng(6)
+    scene = np.stack([rng.uniform(-30, 30, 40000), rng.uniform(-2, 1.6, 40000), rng.uniform(-10, 70, 40000)], 1)
+    root = str(tmp_path / "kitti")
+    make_kitti(root, 9, 14, 1.0, rng=rng, scene=scene)
+    lab_dir = os.path.join(root, "dataset", "sequences", "09", "labels")
+    os.makedirs(lab_dir)
+    keys = np.array(sorted(D.SEMANTIC_KITTI_LEARNING_MAP), dtype=np.uint32)
+    raw_labels = {}
+    for t in range(14):
+        raw_labels[t] = keys[rng.integers(0, len(keys), len(scene))] | (rng.integers(0, 900, len(scene)).astype(np.uint32) << 16)
+        raw_labels[t].tofile(os.path.join(lab_dir, "%06d.label" % t))
+    eng = Engine(NetConfig(feat_len=4), 0, max_points=65536, max_pairs=1)
+    ds = D.KittiOdometryTest(root, eng, sequences=[9], voxel_size=0.4, with_labels=True, refine_pose=False)
+    assert len(ds) >= 1
+    _, t0, t1 = ds.files[0]
+    item = ds[0]
+    n = item["points_src"].shape[0]
+    assert item["points_ref"].shape[0] == n and item["labels_src"].shape == (n,) and item["labels_src"].dtype == torch.int32
+    crop = (3.0, 60.0, -3.0, 10.0)
+    sizes = []
+    for side, t in (("src", t0), ("ref", t1)):
+        scan = D.read_velodyne(os.path.join(root, "dataset", "sequences", "09", "velodyne", "%06d.bin" % t))
+        cls = D.read_semantic_labels(os.path.join(lab_dir, "%06d.label" % t), len(scan)).astype(np.float32)
+        want = voxel_downsample(np.concatenate([scan, cls[:, None]], 1), 0.4, crop)
+        m = len(want)
+        sizes.append(m)
+        got_p = item[f"points_{side}"].cpu().numpy()
+        got_l = item[f"labels_{side}"].cpu().numpy()
+        np.testing.assert_allclose(got_p[:m], want[:, :4], rtol=0, atol=1e-6)
+        assert np.array_equal(got_l[:m], want[:, 4].astype(np.int32))
+        # FixedResampler: np.tile(points, (k // m, 1)) then the first k % m rows
+        assert np.array_equal(got_p[m:], got_p[np.arange(m, n) % m]) and np.array_equal(got_l[m:], got_l[np.arange(m, n) % m])
+    assert n == max(sizes)
+    batch = D.as_batch(item)
+    assert tuple(batch["labels_ref"].shape) == (1, n)
+    eng.close()
