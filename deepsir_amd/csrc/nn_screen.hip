@@ -56,7 +56,7 @@ constexpr int SBC = DSIR_SCREEN_BC;   // ref columns per LDS tile
 #define DSIR_SCREEN_RT 2
 #endif
 constexpr int SRS = DSIR_SCREEN_SRS;     // halfs per LDS row: 64 + 8 pad (144 B: the 16 lanes of a ds_read_b128 group hit 16 distinct bank quads)
-constexpr int CAP = 16;     // candidates kept per row; more => exhaustive exact scan of that row
+constexpr int CAP = 16;     // entries kept per row; more => the row goes to the exhaustive kernel
 constexpr float kC1 = 1.0f / 32768.0f;      // bound width: d = kC1 (|a|^2 + |b|^2) + kC0 (see the header)
 constexpr float kC0 = 1.0f / 1048576.0f;
 constexpr float kW = 2.0f * 1.015625f;       // upper - lower bound = 2 d, with slack for the rounding of its own evaluation
@@ -69,36 +69,35 @@ __device__ __forceinline__ float unorder_bits(unsigned int b) {
   return __uint_as_float((b & 0x80000000u) ? (b & 0x7fffffffu) : ~b);
 }
 
-// x [rows][64] fp32 -> hi, lo [rows][64] fp16 (see header); one thread per 4 channels
-// `bad` (optional): set when an element is outside the domain of the error bound (|x| > 2^15 or not finite)
+// four channels fp32 -> fp16 high / low parts (see the header); *bad is raised when one of them is outside the domain of
+// the error bound (|x| > 2^15 or not finite)
+__device__ __forceinline__ void split4(const float4 v, h4& h, h4& l, int32_t* __restrict__ bad) {
+  const float f[4] = {v.x, v.y, v.z, v.w};
+  if (bad && !(fmaxf(fmaxf(fabsf(f[0]), fabsf(f[1])), fmaxf(fabsf(f[2]), fabsf(f[3]))) <= 32768.f &&
+               f[0] == f[0] && f[1] == f[1] && f[2] == f[2] && f[3] == f[3]))
+    *bad = 1;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    _Float16 t = (_Float16)f[k];
+    if (fabsf((float)t) < 6.103515625e-05f) t = (_Float16)0.f;          // no fp16 subnormals in the high part
+    h[k] = t;
+    l[k] = (_Float16)((f[k] - (float)t) * 2048.0f);
+  }
+}
+
+// x [rows][64] fp32 -> hi, lo [rows][64] fp16; one thread per 4 channels
 __global__ __launch_bounds__(256) void split16_kernel(const float* __restrict__ x, int64_t n4, _Float16* __restrict__ hi,
                                                       _Float16* __restrict__ lo, int32_t* __restrict__ bad) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-    const float4 v = reinterpret_cast<const float4*>(x)[i];
-    const float f[4] = {v.x, v.y, v.z, v.w};
-    if (bad && !(fmaxf(fmaxf(fabsf(f[0]), fabsf(f[1])), fmaxf(fabsf(f[2]), fabsf(f[3]))) <= 32768.f &&
-                 f[0] == f[0] && f[1] == f[1] && f[2] == f[2] && f[3] == f[3]))
-      *bad = 1;
     h4 h, l;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      _Float16 t = (_Float16)f[k];
-      if (fabsf((float)t) < 6.103515625e-05f) t = (_Float16)0.f;          // no fp16 subnormals in the high part
-      h[k] = t;
-      l[k] = (_Float16)((f[k] - (float)t) * 2048.0f);
-    }
+    split4(reinterpret_cast<const float4*>(x)[i], h, l, bad);
     reinterpret_cast<h4*>(hi)[i] = h;
     reinterpret_cast<h4*>(lo)[i] = l;
   }
 }
 
-// Block = NWV waves, wave w owns RT row tiles of 16 src rows whose fp16 fragments stay in registers; ref tiles of 64
-// columns stream through double-buffered LDS (fetched two tiles ahead through registers).  XCD-aware work mapping as in
-// nn_match.hip.  Software pipelined: the accumulators of a 16-column step are ranked (z = hh + 2^-11 mx; the lane's two
-// largest z and the column of the largest; L = |a|^2_low - 2 z) while the MFMAs of the next step run.  One workgroup of
-// 8 waves per CU (194 VGPRs): measured equal to two workgroups of a leaner, unpipelined variant on its own, and better
-// when other streams share the GPU.
-// split16_kernel and the squared norm of each row (sqnorm_kernel's arithmetic) in one pass over the descriptors
+// the same split and the squared norm of each row (sqnorm_kernel's arithmetic) in one pass over the descriptors:
+// 16 lanes per row, float4 each
 __global__ __launch_bounds__(256) void split_norm_kernel(const float* __restrict__ x, int64_t rows, _Float16* __restrict__ hi,
                                                          _Float16* __restrict__ lo, float* __restrict__ sq,
                                                          int32_t* __restrict__ bad) {
@@ -108,23 +107,19 @@ __global__ __launch_bounds__(256) void split_norm_kernel(const float* __restrict
   if (row < rows) v = *reinterpret_cast<const float4*>(x + row * 64 + l * 4);
   const float s = sqnorm_row16(v);
   if (row >= rows) return;
-  const float f[4] = {v.x, v.y, v.z, v.w};
-  if (bad && !(fmaxf(fmaxf(fabsf(f[0]), fabsf(f[1])), fmaxf(fabsf(f[2]), fabsf(f[3]))) <= 32768.f &&
-               f[0] == f[0] && f[1] == f[1] && f[2] == f[2] && f[3] == f[3]))
-    *bad = 1;
   h4 h, lw;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    _Float16 t = (_Float16)f[k];
-    if (fabsf((float)t) < 6.103515625e-05f) t = (_Float16)0.f;          // no fp16 subnormals in the high part
-    h[k] = t;
-    lw[k] = (_Float16)((f[k] - (float)t) * 2048.0f);
-  }
+  split4(v, h, lw, bad);
   *reinterpret_cast<h4*>(hi + row * 64 + l * 4) = h;
   *reinterpret_cast<h4*>(lo + row * 64 + l * 4) = lw;
   if (l == 0) sq[row] = s;
 }
 
+// Block = NWV waves, wave w owns RT row tiles of 16 src rows whose fp16 fragments stay in registers; ref tiles of 64
+// columns stream through double-buffered LDS (fetched two tiles ahead through registers).  XCD-aware work mapping as in
+// nn_match.hip.  Software pipelined: the accumulators of a 16-column step are ranked (z = hh + 2^-11 mx; the lane's two
+// largest z and the column of the largest; L = |a|^2_low - 2 z) while the MFMAs of the next step run.  One workgroup of
+// 8 waves per CU (194 VGPRs): measured equal to two workgroups of a leaner, unpipelined variant on its own, and better
+// when other streams share the GPU.
 #ifndef DSIR_SCREEN_WPE
 #define DSIR_SCREEN_WPE 2
 #endif
