@@ -1,74 +1,48 @@
 #!/usr/bin/env python3
-"""Headline benchmark: registered pairs/sec on 3DMatch-shaped 5000-point pairs.
+"""Headline benchmark: registered pairs/sec on 3DMatch-shaped 5000-point pairs (BASELINE.json configs[1]/[3], "C2").
 
-    python bench.py --gpus N --steps K --warmup W            (N = 1)
+    python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one pass of the whole hot path (KNN pyramid -> 2x feature RandLA +
-score -> 5 x {aggregation, NN match, inlier RandLA, weighted Kabsch}) over one
-batch of P synthetic pairs per GPU, through the C ABI (dsir_register).  Inputs
-(raw [P,5000,3] clouds) are resident in HBM before the timed region; outputs
-(R,t per iteration) stay in HBM.  Pairs shard across ranks with no data-path
-collective; one RCCL all_gather of the (R,t) results closes the timed region.
+One "step" = one pass of the whole hot path (KNN pyramid -> 2x feature RandLA + score -> 5 x {aggregation, nearest
+descriptor, inlier RandLA, weighted Kabsch}) over one batch of P synthetic pairs per GPU, through the C ABI
+(dsir_register).  Inputs (raw [P,5000,3] clouds) are resident in HBM before the timed region; outputs (R,t per
+iteration) stay in HBM.  Pairs shard across ranks with no data-path collective; one RCCL all_gather of the (R,t)
+results closes the timed region.
 
-Prints ONE JSON line on rank 0 (see README / DESIGN.md §Measurement).
+Launched WITHOUT a torchrun environment and with --gpus N > 1, the script re-launches itself as N ranks through
+``python -m torch.distributed.run`` (before anything touches the GPU) and forwards rank 0's JSON line.
+``--dry-run`` rehearses the launch / shard / gather / n_gpus logic on CPU with gloo (no engine, no number).
+
+Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F16_MFMA_TFLOPS = 2500.0   # dense fp16/bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
-PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+PEAK_F32_MFMA_TFLOPS = 157.3    # same guide: v_mfma_f32_16x16x4_f32 dense peak (= the fp32 vector peak)
+PEAK_HBM_GBPS = 8000.0          # HBM3E spec (6.3 TB/s measured achievable)
+SCREEN_MIN_WORK = 200_000_000   # csrc/engine.hip: P*J*K from which dsir_register screens the arg-min
 
 
 def match_flops(P, J, K):
-    """Algorithmic FLOPs of one nn_match launch (128 J K + 3 J K per pair)."""
+    """Algorithmic FLOPs of one nearest-descriptor search (128 J K + 3 J K per pair)."""
     return float(P) * (128.0 * J * K + 3.0 * J * K)
 
 
-def cpu_baseline(cfg, sd, n_points, n_iter, budget_s=15.0):
-    """The oracle (CPU port of the reference path) timed on this box's host cores.
-    Model-only window, as the reference times it (test.py:399-402): the KNN pyramid is built beforehand."""
-    from deepsir_amd.synth import make_pair
-    from oracle.knn import add_pyramids
-    from oracle.network import OracleNet, to_torch
-
-    # the GPU box gives one GPU a share of 16 host cores; never oversubscribe (affinity may list far more)
-    try:
-        avail = len(os.sched_getaffinity(0))
-    except AttributeError:
-        avail = os.cpu_count() or 1
-    threads = max(1, min(avail, int(os.environ.get("DSIR_CPU_THREADS", "16"))))
-    torch.set_num_threads(threads)
-    net = OracleNet(cfg, sd)
-    data = to_torch(add_pyramids(make_pair(n_points, 1001, cfg.feat_len), cfg.num_knn, cfg.sub_sampling_ratio))
-    t0 = time.time()
-    net.register(data, n_iter)  # warm-up (timed only to bound the sample)
-    warm = time.time() - t0
-    times = []
-    t_end = time.time() + budget_s
-    # ~15 s of CPU work (bounded sample): at least 3 runs, at most 60
-    while (len(times) < 3 and warm < budget_s / 3) or (time.time() < t_end and len(times) < 60):
-        t0 = time.time()
-        net.register(data, n_iter)
-        times.append(time.time() - t0)
-    if not times:
-        times = [warm]
-    med = float(np.median(times))
-    return {"value": round(1.0 / med, 4), "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{len(times)} timed runs of 1 pair x {n_points} pts x {n_iter} iters after 1 warm-up, median; "
-                      f"model-only window (KNN pyramid pre-built, as reference test.py:399-402); oracle = PyTorch-CPU "
-                      f"restatement, bit-identical to the imported reference on the golden fixtures"}
+def screen_flops(P, J, K):
+    """MFMA FLOPs screen_kernel executes: three fp16 products (ah.bh, ah.bl, al.bh) x 2 x 64 per (row, column)."""
+    return float(P) * 384.0 * J * K
 
 
 def path_flops(n, n_iter):
@@ -84,7 +58,7 @@ def path_flops(n, n_iter):
     return 2 * R + n_iter * (2 * A + 131.0 * n * n + R + 40.0 * n) + knn
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -97,16 +71,150 @@ def main():
     ap.add_argument("--feat-len", type=int, default=3, help="3 = xyz (3DMatch), 4 = xyz + reflectance (KITTI)")
     ap.add_argument("--shape", default="3dmatch", choices=["3dmatch", "kitti"], help="extent of the synthetic clouds")
     ap.add_argument("--partial-overlap", action="store_true", help="config 5: 50 %% overlap crops + jitter")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg (baseline + parity check)")
     ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 latency phase (profiling runs)")
-    a = ap.parse_args()
+    ap.add_argument("--no-companion", action="store_true", help="skip the exhaustive-arg-min companion run (profiling runs)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="CPU rehearsal of the launcher, the sharding and the result gather (gloo); no engine, no number")
+    return ap.parse_args(argv)
 
+
+def relaunch_as_ranks(a, argv):
+    """--gpus N > 1 without a torchrun environment: become N ranks.  Runs before torch.cuda is touched in this process
+    (a process that has initialised the GPU must not exec or fork GPU children), as a child process whose exit code is
+    passed on."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_run(a, rank, local_rank, world):
+    """The N > 1 plumbing on CPU: rendezvous, world-size check, n_gpus by all_reduce, block sharding of a pair list,
+    padded all_gather of per-pair results (deepsir_amd/dist.py) - everything of the multi-GPU path but the engine."""
+    import torch
+    import torch.distributed as dist
+    from deepsir_amd.dist import gather_results, shard_range, shard_sizes
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    assert world == a.gpus, f"launched as {world} ranks but --gpus {a.gpus}"
+    ones = torch.ones(1, dtype=torch.int64)
+    if world > 1:
+        dist.all_reduce(ones)
+    total = a.pairs * world + 3                                   # unequal shards on purpose
+    mine = shard_range(total, rank, world)
+    local = torch.stack([torch.full((a.iters, 3, 4), float(i)) for i in mine]) if len(mine) else torch.zeros(0, a.iters, 3, 4)
+    out = gather_results(local, dist if world > 1 else None, sizes=shard_sizes(total, world))
+    ok = out.shape[0] == total and out[:, 0, 0, 0].tolist() == [float(i) for i in range(total)]
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": int(ones.item()), "world_size": world, "pairs_total": total,
+                          "gather_ok": bool(ok), "backend": "gloo", "value": None}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0 if ok else 1
+
+
+def cpu_leg(cfg, sd, n_points, n_iter, checks, budget_s=15.0):
+    """The CPU oracle leg (rank 0, N = 1 only): (1) the oracle - the PyTorch-CPU port of the reference path, bit-identical
+    to the imported reference on the golden fixtures - timed on this box's host cores over a bounded sample, in both
+    windows: model-only (the reference's own, test.py:399-402, KNN pyramid pre-built) and with the CPU KNN pyramid;
+    (2) the oracle as CHECKER of what was just measured: for each sampled pair of the benchmarked batch the engine's
+    correspondences are forced into the oracle and the poses compared at every iteration."""
+    import numpy as np
+    import torch
+    from deepsir_amd.synth import make_pair
+    from oracle.knn import add_pyramids
+    from oracle.network import OracleNet, to_torch
+
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    # the GPU box gives one GPU a share of 16 host cores; never oversubscribe (affinity may list far more)
+    threads = max(1, min(avail, int(os.environ.get("DSIR_CPU_THREADS", "16"))))
+    torch.set_num_threads(threads)
+    net = OracleNet(cfg, sd)
+    raw = make_pair(n_points, 1001, cfg.feat_len)
+    t0 = time.time()
+    data_np = add_pyramids(raw, cfg.num_knn, cfg.sub_sampling_ratio)
+    knn_s = [time.time() - t0]
+    data = to_torch(data_np)
+    t0 = time.time()
+    net.register(data, n_iter)  # warm-up (timed only to bound the sample)
+    warm = time.time() - t0
+    times = []
+    t_end = time.time() + budget_s
+    while (len(times) < 3 and warm < budget_s / 3) or (time.time() < t_end and len(times) < 60):
+        t0 = time.time()
+        net.register(data, n_iter)
+        times.append(time.time() - t0)
+    if not times:
+        times = [warm]
+    for _ in range(2 if knn_s[0] < 3.0 else 0):
+        t0 = time.time()
+        add_pyramids(raw, cfg.num_knn, cfg.sub_sampling_ratio)
+        knn_s.append(time.time() - t0)
+    med, knn_med = float(np.median(times)), float(np.median(knn_s))
+    base = {"value": round(1.0 / med, 4), "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+            "window": "model-only (KNN pyramid pre-built, the reference's own timing window test.py:399-402)",
+            "with_cpu_knn": {"value": round(1.0 / (med + knn_med), 4), "unit": "pairs/s", "knn_s_per_pair": round(knn_med, 4),
+                             "note": "plus the oracle's exact numpy KNN pyramid of both clouds (1 thread; the reference runs "
+                                     "nanoflann in DataLoader workers outside its timing window) - compare with `value` of this line"},
+            "sample": f"{len(times)} timed runs of 1 pair x {n_points} pts x {n_iter} iters after 1 warm-up, median; "
+                      f"oracle = PyTorch-CPU restatement, bit-identical to the imported reference on the golden fixtures"}
+    parity = None
+    if checks:
+        worst_r = worst_t = 0.0
+        clear_ok, clear_rows, rows = True, 0, 0
+        for raw_p, idx_e, T_e in checks:
+            d = to_torch(add_pyramids(raw_p, cfg.num_knn, cfg.sub_sampling_ratio))
+            taps = {}
+            T_o, _ = net.register(d, n_iter, forced_idx=[idx_e[i][None].long() for i in range(n_iter)], taps=taps)
+            for i in range(n_iter):
+                A, B = T_e[i].astype(np.float64), T_o[i][0].numpy().astype(np.float64)
+                D = A[:, :3].T @ B[:, :3]
+                v = 0.5 * np.array([D[2, 1] - D[1, 2], D[0, 2] - D[2, 0], D[1, 0] - D[0, 1]])
+                worst_r = max(worst_r, float(np.arctan2(np.linalg.norm(v), 0.5 * (np.trace(D) - 1.0))))
+                worst_t = max(worst_t, float(np.linalg.norm(A[:, 3] - B[:, 3])))
+                best, second, arg = OracleNet.nn_gap(taps["desc_src"][i], taps["desc_ref"][i])
+                clear = ((second - best) > 1e-4 * (1.0 + best.abs()))[0].numpy()
+                clear_ok = clear_ok and bool(np.array_equal(idx_e[i].numpy()[clear], arg[0].numpy()[clear]))
+                clear_rows += int(clear.sum()); rows += int(clear.size)
+        parity = {"pairs_checked": len(checks), "iterations": n_iter,
+                  "max_rot_err_rad": float(f"{worst_r:.3e}"), "max_trans_err_m": float(f"{worst_t:.3e}"),
+                  "tolerance": "1e-4 rad / 1e-4 m (BASELINE north_star)", "argmin_rows_with_clear_fp64_gap": clear_rows,
+                  "argmin_rows": rows, "argmin_equal_on_clear_rows": clear_ok,
+                  "ok": bool(worst_r < 1e-4 and worst_t < 1e-4 and clear_ok),
+                  "method": "pairs sampled from the benchmarked batch, registered by the benchmarked configuration; the engine's "
+                            "correspondences forced into the CPU oracle, poses compared at every iteration; arg-min compared "
+                            "with the oracle's fp64 arg-min wherever its top-2 gap exceeds 1e-4 (1 + |d|)"}
+    return base, parity
+
+
+def main():
+    argv = sys.argv[1:]
+    a = parse_args(argv)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(relaunch_as_ranks(a, argv))
+    if a.dry_run:
+        sys.exit(dry_run(a, rank, local_rank, world))
+
+    import numpy as np
+    import torch
+    assert torch.cuda.is_available(), "bench.py needs a GPU (use --dry-run to rehearse the multi-rank plumbing on CPU)"
+    assert world == a.gpus, f"launched as {world} ranks but --gpus {a.gpus}"
     ndev = torch.cuda.device_count()
-    dev_index = local_rank % max(ndev, 1)      # rehearsing N ranks on fewer GPUs (gloo) maps ranks round-robin
+    dev_index = local_rank % max(ndev, 1)      # rehearsing N ranks on fewer GPUs maps ranks round-robin
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None
@@ -123,7 +231,7 @@ def main():
     from deepsir_amd.arch import NetConfig
     from deepsir_amd.dist import gather_results
     from deepsir_amd.engine import Engine, EnginePool
-    from deepsir_amd.synth import make_batch
+    from deepsir_amd.synth import make_batch, make_pair
     from deepsir_amd.weights import generate_state_dict
 
     cfg = NetConfig(feat_len=a.feat_len)
@@ -131,17 +239,17 @@ def main():
     P, N, n_iter = a.pairs, a.points, a.iters
     S = max(1, a.streams)
     eng = EnginePool(cfg, dev_index, max_points=N, max_pairs=P, streams=S) if S > 1 else Engine(cfg, dev_index, max_points=N, max_pairs=P)
-    P_launch = (P + S - 1) // S   # pairs per nn_match launch
+    P_launch = (P + S - 1) // S   # pairs per arg-min search
     eng.load_state_dict(sd)
     # every rank registers different pairs (weak scaling): seeds partitioned by rank
-    batch = make_batch(N, [10_000 + rank * P + i for i in range(P)], cfg.feat_len, a.shape, a.partial_overlap)
+    seeds = [10_000 + rank * P + i for i in range(P)]
+    batch = make_batch(N, seeds, cfg.feat_len, a.shape, a.partial_overlap)
     src = torch.from_numpy(batch["points_src"]).to(dev)
     ref = torch.from_numpy(batch["points_ref"]).to(dev)
-    outs = [None] * max(a.steps, 1)
     out_buf = eng.register(src, ref, n_iter, want_aux=False)   # allocates the output buffer once
 
-    def step(i):
-        outs[i % len(outs)] = eng.register(src, ref, n_iter, want_aux=False, sync=False, out={"transforms": out_buf["transforms"]})
+    def step():
+        eng.register(src, ref, n_iter, want_aux=False, sync=False, out={"transforms": out_buf["transforms"]})
 
     def fence():
         eng.sync()
@@ -149,32 +257,78 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    for i in range(a.warmup):
-        step(i)
+    # number of distinct GPUs in the job, from a collective (not from the environment)
+    n_gpus = 1
+    if dist is not None:
+        on = dev if dist.get_backend() == "nccl" else "cpu"
+        ids = [torch.zeros(1, dtype=torch.int64, device=on) for _ in range(world)]
+        dist.all_gather(ids, torch.tensor([dev_index], dtype=torch.int64, device=on))
+        ones = torch.ones(1, dtype=torch.int64, device=on)
+        dist.all_reduce(ones)
+        assert int(ones.item()) == world
+        n_gpus = len({int(t.item()) for t in ids})
+
+    for _ in range(a.warmup):
+        step()
     fence()
     eng.enable_match_timer(True)
-    eng.match_timer(reset=True)
-    eng.match_timer_device(reset=True)
+    eng.match_timer2(reset=True)
+    eng.screen_stats(reset=True)
     fence()
     t0 = time.perf_counter()
-    for i in range(a.steps):
-        step(i)
+    for _ in range(a.steps):
+        step()
     eng.sync()
-    results = gather_results(out_buf["transforms"], dist)   # RCCL all_gather of (R,t) — the only collective
+    results = gather_results(out_buf["transforms"], dist)   # RCCL all_gather of (R,t) - the only collective
     fence()
     dt = time.perf_counter() - t0
-    match_ms, match_n = eng.match_timer(reset=True)
-    dev_ms, dev_n = eng.match_timer_device(reset=True)
+    c_op_ms, c_k_ms, c_n = eng.match_timer2(reset=True)
+    sstats = eng.screen_stats(reset=True)
     eng.enable_match_timer(False)
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert results.shape[0] == world * P and torch.isfinite(results).all()
+    screened = sstats["screened_searches"] > 0
 
-    # model-only rate = the reference's own timing window (test.py:399-402): KNN pyramids pre-built and passed in
-    model_only = None
-    if rank == 0 and world == 1:
+    # ------------------------------------------------------------------ rank-0 extras (outside the timed region)
+    model_only = single = single_ex = companion = latency = None
+    checks = []
+    if rank == 0:
+        e0 = eng.engines[0] if hasattr(eng, "engines") else eng
+        # Roofline pass: the dominant kernel timed with HIP events on its stream while ONE engine runs the hot path over
+        # its share of the batch (same shapes and launches as above).  With several engines in flight a bracket also
+        # contains the time the launch shares the CUs with other engines' kernels (roofline.concurrent); on one stream it
+        # is the kernel's own duration - what rocprofv3's kernel trace of this command averages to.
+        s0, r0 = src[:P_launch].contiguous(), ref[:P_launch].contiguous()
+        o0 = e0.register(s0, r0, n_iter, want_aux=False)
+
+        def one_engine_pass():
+            e0.enable_match_timer(True)
+            e0.match_timer2(reset=True)
+            for _ in range(3):
+                e0.register(s0, r0, n_iter, want_aux=False, sync=False, out={"transforms": o0["transforms"]})
+            e0.sync()
+            op, k, n = e0.match_timer2(reset=True)
+            e0.enable_match_timer(False)
+            return (op / n, k / n, int(n)) if n else None
+
+        single = one_engine_pass()
+        if screened and not a.no_companion:
+            e0.enable_screen(False)
+            e0.register(s0, r0, n_iter, want_aux=False, out={"transforms": o0["transforms"]})
+            single_ex = one_engine_pass()
+            e0.enable_screen(True)
+        del s0, r0
+
+    if world == 1:
+        # model-only rate = the reference's own timing window (test.py:399-402): KNN pyramids pre-built and passed in
         e0 = eng.engines[0] if hasattr(eng, "engines") else eng
         half = (P + 1) // 2
         pyr = {}
         for side, pts in (("src", src), ("ref", ref)):
-            parts = [e0.knn_pyramid(pts[a:a + half]) for a in range(0, P, half)]   # 2 calls: stays inside the workspace
+            parts = [e0.knn_pyramid(pts[b:b + half]) for b in range(0, P, half)]   # 2 calls: stays inside the workspace
             for k, j in (("xyz", 0), ("neigh_idx", 1), ("sub_idx", 2), ("interp_idx", 3)):
                 pyr[f"points_{side}_{k}"] = torch.cat([q[j] for q in parts], 0)
         for _ in range(2):
@@ -189,112 +343,156 @@ def main():
                       "note": "KNN pyramids supplied by the caller (reference timing window, test.py:399-402)"}
         del pyr
 
-    # Roofline pass: the dominant kernel timed with HIP events on its stream while ONE engine runs the hot path over its
-    # share of the batch (P_launch pairs, same shapes and launches as in the region above).  With several engines in
-    # flight the bracket around a launch also contains the time it shares the CUs with the other engines' kernels
-    # (reported as roofline.concurrent); on one stream it is the kernel's own duration, which is what rocprofv3's
-    # kernel trace of this command averages to.
-    single = None
-    if rank == 0:
-        e0 = eng.engines[0] if hasattr(eng, "engines") else eng
-        s0, r0 = src[:P_launch].contiguous(), ref[:P_launch].contiguous()
-        o0 = e0.register(s0, r0, n_iter, want_aux=False)
-        e0.enable_match_timer(True)
-        e0.match_timer(reset=True)
-        for _ in range(3):
-            e0.register(s0, r0, n_iter, want_aux=False, sync=False, out={"transforms": o0["transforms"]})
-        e0.sync()
-        sms, scnt = e0.match_timer(reset=True)
-        e0.enable_match_timer(False)
-        if scnt:
-            single = (sms / scnt, int(scnt))
-        del s0, r0
+        # companion: the same step with the exhaustive exact-fp32 arg-min kernel throughout (same bits).  How much of
+        # `value` survives a descriptor distribution the screening cannot thin out (its floor).
+        if screened and not a.no_companion:
+            eng.enable_screen(False)
+            step(); eng.sync()
+            reps = max(2, min(a.steps, 4))
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                step()
+            eng.sync()
+            companion = {"value": round(P * reps / (time.perf_counter() - t1), 3), "unit": "pairs/s", "steps": reps,
+                         "note": "dsir_enable_screen(0): every arg-min by the exhaustive exact-fp32 MFMA kernel (csrc/nn_match.hip); "
+                                 "same results bit for bit"}
+            eng.enable_screen(True)
 
-    # batch-1 latency (the reference's own evaluation mode, test.py:56 BATCH_SIZE = 1): one pair in flight,
-    # launch sequence replayed from a hipGraph.  Reported beside the throughput number, not as `value`.
-    latency = None
-    if rank == 0 and world == 1 and not a.no_latency:
-        s1, r1 = src[:1].contiguous(), ref[:1].contiguous()
-        eng.enable_graph(True)
-        o1 = eng.register(s1, r1, n_iter, want_aux=False)
-        for _ in range(3):
-            eng.register(s1, r1, n_iter, want_aux=False, sync=False, out={"transforms": o1["transforms"]})
-        eng.sync()
-        reps = 20
-        t1 = time.perf_counter()
-        for _ in range(reps):
-            eng.register(s1, r1, n_iter, want_aux=False, sync=False, out={"transforms": o1["transforms"]})
-        eng.sync()
-        ms = (time.perf_counter() - t1) / reps * 1e3
-        eng.enable_graph(False)
-        latency = {"pairs_in_flight": 1, "ms_per_pair": round(ms, 4), "pairs_per_s": round(1e3 / ms, 2), "hipgraph": True}
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    assert results.shape[0] == world * P and torch.isfinite(results).all()
+        # batch-1 latency (the reference's own evaluation mode, test.py:56 BATCH_SIZE = 1): one pair in flight,
+        # launch sequence replayed from a hipGraph.  Reported beside the throughput number, not as `value`.
+        if not a.no_latency:
+            s1, r1 = src[:1].contiguous(), ref[:1].contiguous()
+            eng.enable_graph(True)
+            o1 = eng.register(s1, r1, n_iter, want_aux=False)
+            for _ in range(3):
+                eng.register(s1, r1, n_iter, want_aux=False, sync=False, out={"transforms": o1["transforms"]})
+            eng.sync()
+            reps = 20
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                eng.register(s1, r1, n_iter, want_aux=False, sync=False, out={"transforms": o1["transforms"]})
+            eng.sync()
+            ms = (time.perf_counter() - t1) / reps * 1e3
+            eng.enable_graph(False)
+            latency = {"pairs_in_flight": 1, "ms_per_pair": round(ms, 4), "pairs_per_s": round(1e3 / ms, 2), "hipgraph": True,
+                       "note": "the reference's own evaluation mode (test.py:56 BATCH_SIZE = 1, BASELINE configs[1] 'batch=1')"}
+
+        # parity of what was just measured: the benchmarked configuration once more with the aux outputs, two pairs
+        # (first stream's first, last stream's last) handed to the CPU oracle in cpu_leg
+        if not a.no_cpu_baseline and not a.partial_overlap and N <= 16384:
+            aux = eng.register(src, ref, n_iter, want_aux=True)
+            assert torch.equal(aux["transforms"], out_buf["transforms"]), "aux and timed runs disagree"
+            for p in sorted({0, P - 1}):
+                raw_p = make_pair(N, seeds[p], cfg.feat_len, a.shape)
+                assert np.array_equal(raw_p["points_src"][0], batch["points_src"][p])
+                checks.append((raw_p, aux["idx"][:, p].cpu(), aux["transforms"][p].cpu().numpy()))
+            del aux
 
     if rank == 0:
         total_pairs = world * P * a.steps
-        avg_match_s = (match_ms / 1e3) / max(match_n, 1)
-        achieved = match_flops(P_launch, N, N) / avg_match_s / 1e12 if match_n else None
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "nn_match_pmc.json")
-        if os.path.exists(pmc):
-            try:
-                with open(pmc) as f:
-                    j = json.load(f)
-                if j.get("pairs") == P_launch and j.get("points") == N:
-                    traffic = j.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        # same dispatch rule as csrc/engine.hip (both paths return the same bits)
-        screened = not os.environ.get("DSIR_NO_SCREEN") and P_launch * N * N >= 200000000
+        wl = {"3dmatch": "3DMatch-shaped pairs, uniform [0,3]^3 m clouds", "kitti": "KITTI-shaped pairs, uniform [-50,50]^2 x [-3,3] m clouds"}[a.shape]
+        cname = "C2" if (N == 5000 and a.shape == "3dmatch") else ("C3" if a.shape == "kitti" else ("C5" if a.partial_overlap else "C1" if N == 2048 else "custom"))
         line = {
             "metric": "registered pairs/sec (5k-pt 3DMatch-shaped synthetic pairs, 5 registration iterations, KNN pyramid included)",
-            "value": round(total_pairs / dt, 3), "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "value": round(total_pairs / dt, 3), "unit": "pairs/s", "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "C2: 3DMatch-shaped pairs, uniform [0,3]^3 m clouds, random SO(3)+t, raw clouds resident in HBM -> (R,t) in HBM",
-                       "points_per_cloud": N, "pairs_per_step_per_gpu": P, "num_reg_iter": n_iter, "knn": 16,
-                       "weights": "seeded random state-dict (checkpoint not available)", "parallelism": f"pair-sharded x{world}, RCCL all_gather of results"},
-            "roofline": {"kernel": ("nn_match: arg-min of the 64-channel descriptor distance - fp16-split MFMA screening under a rigorous "
-                                    "bound (one pass, per-lane top-2) + exact fp32 decision among the survivors (csrc/nn_screen.hip); same result, bit "
-                                    "for bit, as the exhaustive exact-fp32 MFMA kernel (csrc/nn_match.hip)"),
-                         "bound": "mfma",
-                         "achieved": None if single is None else round(match_flops(P_launch, N, N) / (single[0] / 1e3) / 1e12, 3),
-                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": None if single is None else round(match_flops(P_launch, N, N) / (single[0] / 1e3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-                         "traffic": traffic,
-                         "launches": None if single is None else single[1],
-                         "avg_launch_ms": None if single is None else round(single[0], 5),
-                         "flops_per_launch": match_flops(P_launch, N, N), "pairs_per_launch": P_launch,
-                         "executed": None if (single is None or not screened) else {
-                             "dtype": "f16 (fp32 accumulate)", "mfma_flops_per_launch": 384.0 * P_launch * N * N,
-                             "achieved": round(384.0 * P_launch * N * N / (single[0] / 1e3) / 1e12, 3), "peak": PEAK_F16_MFMA_TFLOPS,
-                             "frac": round(384.0 * P_launch * N * N / (single[0] / 1e3) / 1e12 / PEAK_F16_MFMA_TFLOPS, 4),
-                             "note": "(ah.bh + ah.bl + al.bh) x 2*64 flop per (row, column) on v_mfma_f32_16x16x32_f16; the rows the screening cannot decide (a few %) are redone by the exact fp32 MFMA kernel and not counted here"},
-                         "concurrent": {"streams": S, "launches": int(match_n), "avg_launch_ms": round(avg_match_s * 1e3, 5),
-                                        "achieved": None if achieved is None else round(achieved, 3),
-                                        "frac": None if achieved is None else round(achieved / PEAK_F32_MFMA_TFLOPS, 4)},
-                         "note": ("achieved = ALGORITHMIC flops of the operation (131 N^2 per pair, SURVEY 8d: the exhaustive fp32 distance "
-                                  "GEMM + arg-min) / average duration of the whole operation (HIP events on the engine's stream around its "
-                                  "kernels while ONE engine registers its share of the batch), against the exact-fp32 MFMA peak - the "
-                                  "ceiling of the exhaustive formulation (that kernel reaches 119 TFLOP/s = 0.757; DSIR_NO_SCREEN=1 runs it). "
-                                  "The screened path does the bulk of the contraction on the 16x faster fp16 MFMA, so it can pass that "
-                                  "ceiling; `executed` prices the fp16 work against the fp16 peak.  concurrent: the same bracket inside "
-                                  "the throughput region, where `streams` engines share the GPU.  whole_path: algorithmic FLOPs of the "
-                                  "entire job (SURVEY 8d formula) / wall time of the throughput region"),
-                         "whole_path": {"flops_per_pair": path_flops(N, n_iter),
-                                        "achieved": round(path_flops(N, n_iter) * total_pairs / dt / 1e12, 3),
-                                        "frac": round(path_flops(N, n_iter) * total_pairs / dt / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}},
+            "config": {"workload": (f"{cname}: {wl}{', 50 % overlap crops + jitter' if a.partial_overlap else ''}, random SO(3)+t, raw clouds "
+                                    f"resident in HBM -> (R,t) in HBM; THROUGHPUT mode: {P} pairs in flight per GPU per step on {S} HIP "
+                                    f"streams ({P_launch} pairs per engine call) - the reference evaluates one pair at a time "
+                                    f"(test.py:56), see batch1_latency for that mode"),
+                       "points_per_cloud": N, "pairs_per_step_per_gpu": P, "pairs_in_flight_per_gpu": P, "streams_per_gpu": S,
+                       "num_reg_iter": n_iter, "knn": 16, "world_size": world,
+                       "weights": "seeded random state-dict (checkpoint not available)",
+                       "parallelism": f"pair-sharded x{world}, RCCL all_gather of results"},
         }
+        # ---- roofline of the dominant kernel
+        roof = {"bound": "mfma", "unit": "TFLOP/s"}
+        if single is not None:
+            op_ms, k_ms, nl = single
+            if screened:
+                ex = screen_flops(P_launch, N, N)
+                roof.update({
+                    "kernel": "screen_kernel<2,8> (csrc/nn_screen.hip): fp16-split MFMA screening of the 64-channel descriptor arg-min "
+                              "under a rigorous bound; the exact fp32 decision among the survivors follows in exact_pick_kernel / nn_match_kernel",
+                    "dtype": "f16 in, f32 accumulate (v_mfma_f32_16x16x32_f16)",
+                    "achieved": round(ex / (k_ms / 1e3) / 1e12, 3), "peak": PEAK_F16_MFMA_TFLOPS,
+                    "frac": round(ex / (k_ms / 1e3) / 1e12 / PEAK_F16_MFMA_TFLOPS, 4),
+                    "flops_per_launch": ex, "flops_note": "EXECUTED MFMA flops: (ah.bh + ah.bl + al.bh) x 2 x 64 per (row, column) = 384 J K per pair"})
+            else:
+                ex = match_flops(P_launch, N, N)
+                roof.update({
+                    "kernel": "nn_match_kernel (csrc/nn_match.hip): exhaustive exact-fp32 MFMA distance GEMM + row arg-min",
+                    "dtype": "f32 (v_mfma_f32_16x16x4_f32)",
+                    "achieved": round(ex / (k_ms / 1e3) / 1e12, 3), "peak": PEAK_F32_MFMA_TFLOPS,
+                    "frac": round(ex / (k_ms / 1e3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                    "flops_per_launch": ex, "flops_note": "algorithmic = executed: 131 J K per pair (SURVEY 8d)"})
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "nn_match_pmc.json")
+            if os.path.exists(pmc):
+                try:
+                    with open(pmc) as f:
+                        j = json.load(f)
+                    if j.get("pairs") == P_launch and j.get("points") == N and screened:
+                        traffic = j.get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            alg = match_flops(P_launch, N, N)
+            roof.update({
+                "traffic": traffic, "launches": nl, "avg_launch_ms": round(k_ms, 5), "pairs_per_launch": P_launch,
+                "operation": {"avg_ms": round(op_ms, 5), "algorithmic_flops_per_launch": alg,
+                              "algorithmic_tflops": round(alg / (op_ms / 1e3) / 1e12, 3),
+                              "algorithmic_speedup_vs_fp32_peak": round(alg / (op_ms / 1e3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                              "note": "every kernel of one nearest-descriptor search (split, screening, exact pick, fallback, unpack); "
+                                      "algorithmic = the exhaustive fp32 formulation's 131 J K per pair (SURVEY 8d) / that time, against "
+                                      "the fp32 MFMA peak it would be bound by - a speed-up over that formulation's ceiling, NOT a roofline fraction"},
+                "concurrent": {"streams": S, "launches": int(c_n), "avg_launch_ms": round(c_k_ms / max(c_n, 1), 5),
+                               "avg_operation_ms": round(c_op_ms / max(c_n, 1), 5),
+                               "note": "the same brackets inside the timed region, where `streams` engines share the GPU"},
+                "note": "achieved = flops the dominant kernel executes per launch / its average duration (HIP events on the engine's "
+                        "stream around that kernel alone, ONE engine registering its share of the batch; rocprofv3 --kernel-trace of "
+                        "this command agrees, profiles/), against the dense MFMA peak of the dtype it issues"})
+            if single_ex is not None:
+                op2, k2, n2 = single_ex
+                roof["exhaustive_kernel"] = {
+                    "kernel": "nn_match_kernel<2> (csrc/nn_match.hip), dsir_enable_screen(0)", "dtype": "f32", "avg_launch_ms": round(k2, 5),
+                    "achieved": round(alg / (k2 / 1e3) / 1e12, 3), "peak": PEAK_F32_MFMA_TFLOPS,
+                    "frac": round(alg / (k2 / 1e3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4), "launches": n2}
+        roof["whole_path"] = {"flops_per_pair": path_flops(N, n_iter),
+                              "achieved": round(path_flops(N, n_iter) * total_pairs / dt / 1e12, 3),
+                              "algorithmic_speedup_vs_fp32_peak": round(path_flops(N, n_iter) * total_pairs / dt / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                              "note": "algorithmic FLOPs of the entire job (SURVEY 8d formula, reference formulation, nothing subtracted for "
+                                      "hoisting / screening) / wall time; part of the work runs on fp16 MFMA, so this is not a fraction of one peak"}
+        # whole-step HBM traffic from the PMC passes of the same command (profiles/README.md), divided by the live step time
+        hb = os.path.join(ROOT, "profiles", "step_hbm.json")
+        if os.path.exists(hb):
+            try:
+                with open(hb) as f:
+                    j = json.load(f)
+                if (j.get("pairs"), j.get("points"), j.get("streams"), j.get("iters")) == (P, N, S, n_iter):
+                    gbps = j["hbm_bytes_per_step"] / (dt / a.steps) / 1e9
+                    roof["hbm_gbps"] = {"value": round(gbps, 1), "peak": PEAK_HBM_GBPS, "frac": round(gbps / PEAK_HBM_GBPS, 4),
+                                        "bytes_per_step": j["hbm_bytes_per_step"], "source": j.get("method")}
+            except Exception:
+                pass
+        line["roofline"] = roof
+        if sstats["rows_searched"]:
+            line["screening"] = {"searches": sstats["screened_searches"], "undecided_row_rate": round(sstats["rows_undecided"] / sstats["rows_searched"], 5),
+                                 "pairs_searched_exhaustively": sstats["pairs_exhaustive"],
+                                 "pair_searches": sstats["screened_searches"] * P_launch,
+                                 "note": "rows the fp16 screening could not decide (searched by the exact fp32 kernel) / rows searched, inside "
+                                         "the timed region; workload dependent (random weights here, checkpoint absent)"}
+        if companion is not None:
+            line["exhaustive_argmin"] = companion
         if model_only is not None:
             line["model_only"] = model_only
         if latency is not None:
             line["batch1_latency"] = latency
         if world == 1 and not a.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(cfg, sd, N, n_iter)
+            base, parity = cpu_leg(cfg, sd, N, n_iter, checks)
+            line["cpu_baseline"] = base
+            if parity is not None:
+                line["parity_check"] = parity
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

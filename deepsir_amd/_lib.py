@@ -87,9 +87,12 @@ SYMBOLS = {
     "dsir_icp_refine": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
                                   C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dsir_match_timer": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), c_i64_p]),
+    "dsir_match_timer2": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), c_i64_p]),
+    "dsir_enable_screen": (C.c_int, [C.c_void_p, C.c_int]),
     "dsir_match_timer_device": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), c_i64_p]),
     "dsir_enable_match_timer": (C.c_int, [C.c_void_p, C.c_int]),
     "dsir_enable_graph": (C.c_int, [C.c_void_p, C.c_int]),
+    "dsir_screen_stats": (C.c_int, [C.c_void_p, C.c_int, c_i64_p]),
     "dsir_voxel_downsample": (C.c_int, [C.c_void_p, C.c_void_p, c_i64_p, C.c_int, C.c_int, C.c_float, c_float_p, C.c_int,
                                         C.c_void_p, C.c_void_p]),
     "dsir_resample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64,

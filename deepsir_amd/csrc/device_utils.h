@@ -20,6 +20,12 @@ __device__ __forceinline__ void st_f32(float* base, uint32_t byte_off, float v) 
   *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byte_off) = v;
 }
 
+// index half of a packed (order-preserving distance bits << 32 | column) arg-min slot.  A slot still at its preset
+// (all ones: every distance of the row was NaN, nothing ever won) yields 0, never -1: consumers gather by it.
+__device__ __forceinline__ int32_t packed_index(unsigned long long p) {
+  return p == ~0ull ? 0 : (int32_t)(p & 0xffffffffull);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

@@ -95,15 +95,21 @@ struct dsir_ctx {
   bool use_graph = false;
   hipGraphExec_t graph_exec = nullptr;
   std::vector<unsigned char> graph_key;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> match_events;
+  struct MatchEvents { hipEvent_t op0, op1, k0, k1; };   // whole operation / its dominant kernel alone
+  std::vector<MatchEvents> match_events;
   size_t match_events_used = 0;
-  double match_ms = 0.0;
+  double match_ms = 0.0, match_kernel_ms = 0.0;
   int64_t match_launches = 0;
+  // arg-min path of dsir_register: 1 = screened (nn_screen.hip) for large problems, 0 = always the exhaustive kernel
+  int screen_mode = 1;
   // device-clock brackets {first wave start, last wave end} of the timed nn_match launches
   unsigned long long* match_ts = nullptr;    // [kMatchSlots][2]
   size_t match_ts_used = 0;
   double match_dev_ms = 0.0;
   int64_t match_dev_launches = 0;
+  // running totals of the screened arg-min inside dsir_register (dsir_screen_stats)
+  unsigned long long* screen_acc = nullptr;   // device, 4 x u64
+  int64_t exhaustive_searches = 0;            // searches that took the exhaustive kernel directly (small problems)
 };
 constexpr size_t kMatchSlots = 4096;
 
@@ -585,6 +591,16 @@ int post(dsir_ctx* c) {
   return 0;
 }
 
+dsir_ctx::MatchEvents* match_event_slot(dsir_ctx* c) {
+  if (!c->time_match) return nullptr;
+  if (c->match_events_used == c->match_events.size()) {
+    dsir_ctx::MatchEvents e{};
+    hipEventCreate(&e.op0); hipEventCreate(&e.op1); hipEventCreate(&e.k0); hipEventCreate(&e.k1);
+    c->match_events.push_back(e);
+  }
+  return &c->match_events[c->match_events_used++];
+}
+
 }  // namespace
 
 // =================================================================== C ABI
@@ -608,6 +624,7 @@ int dsir_create(int device, const dsir_cfg* cfg, dsir_ctx** out) {
   if (device < 0 || device >= ndev) return fail(nullptr, "device %d out of range (%d devices)", device, ndev);
   dsir_ctx* c = new dsir_ctx();
   c->device = device; c->cfg = *cfg;
+  c->screen_mode = getenv("DSIR_NO_SCREEN") ? 0 : 1;
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
     delete c;
     return fail(nullptr, "cannot initialise device %d", device);
@@ -636,6 +653,12 @@ int dsir_create(int device, const dsir_cfg* cfg, dsir_ctx** out) {
     delete c;
     return fail(nullptr, "cannot allocate the statistics arena");
   }
+  if (hipMalloc((void**)&c->screen_acc, 4 * sizeof(unsigned long long)) != hipSuccess ||
+      hipMemset(c->screen_acc, 0, 4 * sizeof(unsigned long long)) != hipSuccess) {
+    hipFree(c->stats); hipFree(c->ws.base); hipStreamDestroy(c->stream);
+    delete c;
+    return fail(nullptr, "cannot allocate the screening counters");
+  }
   *out = c;
   return 0;
 }
@@ -644,10 +667,11 @@ void dsir_destroy(dsir_ctx* c) {
   if (!c) return;
   hipSetDevice(c->device);
   hipStreamSynchronize(c->stream);
-  for (auto& e : c->match_events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+  for (auto& e : c->match_events) { hipEventDestroy(e.op0); hipEventDestroy(e.op1); hipEventDestroy(e.k0); hipEventDestroy(e.k1); }
   if (c->graph_exec) hipGraphExecDestroy(c->graph_exec);
   if (c->dweights) hipFree(c->dweights);
   if (c->match_ts) hipFree(c->match_ts);
+  if (c->screen_acc) hipFree(c->screen_acc);
   if (c->stats) hipFree(c->stats);
   if (c->ws.base) hipFree(c->ws.base);
   hipStreamDestroy(c->stream);
@@ -702,6 +726,9 @@ int dsir_finalize_weights(dsir_ctx* c) {
   }
   HIP_OK(c, hipSetDevice(c->device));
   HIP_OK(c, hipStreamSynchronize(c->stream));
+  // a captured registration holds the addresses of the old weight blob: drop it, the next call re-captures
+  if (c->graph_exec) { hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
+  c->graph_key.clear();
   if (c->dweights) { hipFree(c->dweights); c->dweights = nullptr; }
   HIP_OK(c, hipMalloc((void**)&c->dweights, u.blob.size() * sizeof(float)));
   HIP_OK(c, hipMemcpy(c->dweights, u.blob.data(), u.blob.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -755,10 +782,13 @@ int dsir_score(dsir_ctx* c, const float* feat, const float* logits, const float*
                const int32_t* neigh, int64_t neigh_cs, int clouds, int n, float* score, int32_t* label) {
   if (check_ready(c)) return 1;
   HIP_OK(c, hipSetDevice(c->device));
+  if (!feat || !logits || !xyz || !neigh || !score || clouds < 1 || n < 1) return fail(c, "dsir_score: bad arguments");
+  if (clouds > 2 * c->cfg.max_pairs || n > c->cfg.max_points) return fail(c, "dsir_score: batch exceeds max_pairs/max_points");
   ScoreScratch s;
   s.red = c->ws.get<float>((size_t)clouds * 4);
   s.prob = c->ws.get<float>((size_t)clouds * n);
   s.label = c->ws.get<int32_t>((size_t)clouds * n);
+  if (c->ws.overflow) return fail(c, "workspace exhausted in dsir_score");
   launch_score(feat, logits, c->cfg.num_classes, xyz, xyz_cs, neigh, neigh_cs, clouds, n, s, score, label, c->stream);
   return post(c);
 }
@@ -768,6 +798,9 @@ int dsir_aggregate(dsir_ctx* c, const float* xyz, int64_t xyz_cs, const float* f
   if (check_ready(c)) return 1;
   if (c->cfg.pipeline == DSIR_PIPELINE_LABEL) return fail(c, "dsir_aggregate: a label-pipeline context has no aggregation layers");
   HIP_OK(c, hipSetDevice(c->device));
+  if (!xyz || !feat0 || !score || !desc || clouds < 1 || n < 1) return fail(c, "dsir_aggregate: bad arguments");
+  // the workspace is sized from these two limits: inside them no allocation below can overflow
+  if (clouds > 2 * c->cfg.max_pairs || n > c->cfg.max_points) return fail(c, "dsir_aggregate: batch exceeds max_pairs/max_points");
   float* F = run_mlp_feat(c, feat0, clouds, n);
   run_att_proj(c, xyz, xyz_cs, score, F, clouds, n, desc);
   return post(c);
@@ -775,21 +808,15 @@ int dsir_aggregate(dsir_ctx* c, const float* xyz, int64_t xyz_cs, const float* f
 
 int dsir_nn_match(dsir_ctx* c, const float* a, const float* b, int pairs, int J, int K, int32_t* idx) {
   if (!c) return 1;
+  if (!a || !b || !idx || pairs < 1 || J < 1 || K < 1) return fail(c, "dsir_nn_match: bad arguments");
   HIP_OK(c, hipSetDevice(c->device));
   c->ws.top = 0; c->ws.overflow = false;
   void* scratch = c->ws.raw(nn_match_scratch_bytes(pairs, J, K));
   if (c->ws.overflow) return fail(c, "workspace exhausted in nn_match");
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (c->time_match) {
-    if (c->match_events_used == c->match_events.size()) {
-      hipEvent_t a0, a1;
-      hipEventCreate(&a0); hipEventCreate(&a1);
-      c->match_events.push_back({a0, a1});
-    }
-    e0 = c->match_events[c->match_events_used].first; e1 = c->match_events[c->match_events_used].second;
-    ++c->match_events_used;
-  }
-  launch_nn_match_ws(a, b, pairs, J, K, idx, scratch, c->stream, e0, e1);
+  dsir_ctx::MatchEvents* ev = match_event_slot(c);
+  if (ev) hipEventRecord(ev->op0, c->stream);
+  launch_nn_match_ws(a, b, pairs, J, K, idx, scratch, c->stream, ev ? ev->k0 : nullptr, ev ? ev->k1 : nullptr);
+  if (ev) hipEventRecord(ev->op1, c->stream);
   return post(c);
 }
 
@@ -825,6 +852,7 @@ int dsir_nn_match_screened(dsir_ctx* c, const float* a, const float* b, int pair
 int dsir_kabsch(dsir_ctx* c, const float* src, const float* tgt, const float* w, int pairs, int m, float* T,
                 int32_t* invalid) {
   if (!c) return 1;
+  if (!src || !tgt || !w || !T || pairs < 1 || m < 1) return fail(c, "dsir_kabsch: bad arguments");
   HIP_OK(c, hipSetDevice(c->device));
   if (invalid) HIP_OK(c, hipMemsetAsync(invalid, 0, sizeof(int32_t) * pairs, c->stream));
   KabschArgs a{};
@@ -841,7 +869,8 @@ struct PairStage {
   int32_t *label_s, *label_r;     // only when want_label
   float *rxyz;                    // == pr.xyz
 };
-static int forward_pair_stage(dsir_ctx* c, const dsir_pair_batch* in, bool want_score, bool want_label, PairStage& S) {
+static int forward_pair_stage(dsir_ctx* c, const dsir_pair_batch* in, bool want_score, bool want_label, PairStage& S,
+                              int32_t* invalid = nullptr) {
   const dsir_cfg& g = c->cfg;
   const int P = in->pairs, J = in->n_src, K = in->n_ref, cin = g.feat_len;
   if (P < 1 || P > g.max_pairs) return fail(c, "pairs=%d outside [1,%d]", P, g.max_pairs);
@@ -886,12 +915,19 @@ static int forward_pair_stage(dsir_ctx* c, const dsir_pair_batch* in, bool want_
   if (have_py) {
     HIP_OK(c, hipMemcpyAsync(pxyz, in->src_xyz, sizeof(float) * P * ps.S * 3, hipMemcpyDeviceToDevice, st));
     HIP_OK(c, hipMemcpyAsync(rxyz, in->ref_xyz, sizeof(float) * P * pr.S * 3, hipMemcpyDeviceToDevice, st));
-    HIP_OK(c, hipMemcpyAsync(pneigh, in->src_neigh, sizeof(int32_t) * P * ps.S * kKnn, hipMemcpyDeviceToDevice, st));
-    HIP_OK(c, hipMemcpyAsync(rneigh, in->ref_neigh, sizeof(int32_t) * P * pr.S * kKnn, hipMemcpyDeviceToDevice, st));
-    HIP_OK(c, hipMemcpyAsync(psub, in->src_sub, sizeof(int32_t) * P * ps.S1 * kKnn, hipMemcpyDeviceToDevice, st));
-    HIP_OK(c, hipMemcpyAsync(rsub, in->ref_sub, sizeof(int32_t) * P * pr.S1 * kKnn, hipMemcpyDeviceToDevice, st));
-    HIP_OK(c, hipMemcpyAsync(pinterp, in->src_interp, sizeof(int32_t) * P * ps.S, hipMemcpyDeviceToDevice, st));
-    HIP_OK(c, hipMemcpyAsync(rinterp, in->ref_interp, sizeof(int32_t) * P * pr.S, hipMemcpyDeviceToDevice, st));
+    // caller-supplied indices: copied with every entry clamped into its level's range (a bad index can never fault a
+    // gather), out-of-range entries reported through bit 1 of the pair's invalid flag
+    auto copy_idx = [&](const Pyramid& py, const int32_t* nb, const int32_t* sb, const int32_t* ip, int32_t* nbo, int32_t* sbo,
+                        int32_t* ipo) {
+      PyramidIdxCopy a{};
+      a.neigh = nb; a.sub = sb; a.interp = ip; a.neigh_out = nbo; a.sub_out = sbo; a.interp_out = ipo;
+      a.S = py.S; a.S1 = py.S1; a.levels = g.num_layers;
+      for (int l = 0; l <= g.num_layers; ++l) { a.nl[l] = py.nl[l]; a.off[l] = py.off[l]; a.soff[l] = py.soff[l]; }
+      a.flag = invalid; a.flag_mod = P;
+      launch_copy_pyramid_idx(a, P, st);
+    };
+    copy_idx(ps, in->src_neigh, in->src_sub, in->src_interp, pneigh, psub, pinterp);
+    copy_idx(pr, in->ref_neigh, in->ref_sub, in->ref_interp, rneigh, rsub, rinterp);
   } else if (joint) {
     if (int r = build_pyramid(c, feats_in, cin, 2 * P, J, pxyz, pneigh, psub, pinterp)) return r;
   } else {
@@ -943,7 +979,8 @@ static int register_enqueue(dsir_ctx* c, const dsir_pair_batch* in, int n_iter, 
   hipStream_t st = c->stream;
   Arena& ws = c->ws;
   PairStage S;
-  if (int r = forward_pair_stage(c, in, true, false, S)) return r;
+  if (out->invalid) HIP_OK(c, hipMemsetAsync(out->invalid, 0, sizeof(int32_t) * P, st));
+  if (int r = forward_pair_stage(c, in, true, false, S, out->invalid)) return r;
   const Pyramid& ps = S.ps; const Pyramid& pr = S.pr;
   float *feat_s = S.feat_s, *feat_r = S.feat_r, *score_s = S.score_s, *score_r = S.score_r, *rxyz = S.rxyz;
   const float* pxyz = ps.xyz;
@@ -958,10 +995,10 @@ static int register_enqueue(dsir_ctx* c, const dsir_pair_batch* in, int n_iter, 
   float* T_it = ws.get<float>((size_t)P * 12);
   void* match_scratch = ws.raw(nn_match_scratch_bytes(P, J, K));
   // fp16-screened arg-min (nn_screen.hip): split descriptors, norms, candidate scratch.  The ref side is loop invariant.
-  static const bool no_screen = getenv("DSIR_NO_SCREEN") != nullptr;   // A/B switch: exhaustive fp32 kernel
   // both paths return the same bits, so the choice is free: small problems (latency-bound, e.g. one pair in flight) take
-  // the single exhaustive kernel, large ones the three-kernel screened path
-  const bool screen = !no_screen && !in->forced_idx && (int64_t)P * J * K >= 200000000ll;
+  // the single exhaustive kernel, large ones the three-kernel screened path.  dsir_enable_screen / DSIR_NO_SCREEN: A/B
+  // switch to the exhaustive fp32 kernel throughout
+  const bool screen = c->screen_mode && !in->forced_idx && (int64_t)P * J * K >= 200000000ll;
   void *sc_ah = nullptr, *sc_al = nullptr, *sc_bh = nullptr, *sc_bl = nullptr, *sc_scratch = nullptr;
   float *sc_sa = nullptr, *sc_sb = nullptr;
   if (screen) {
@@ -1004,7 +1041,6 @@ static int register_enqueue(dsir_ctx* c, const dsir_pair_batch* in, int n_iter, 
   }
   // xyz_cur = level-0 src coordinates
   launch_copy_xyz(pxyz, (int64_t)ps.S * 3, 3, J, P, xyz_cur, (int64_t)J * 3, st);
-  if (out->invalid) HIP_OK(c, hipMemsetAsync(out->invalid, 0, sizeof(int32_t) * P, st));
 
   for (int it = 0; it < n_iter; ++it) {
     int32_t* idx_out = out->idx ? out->idx + (size_t)it * P * J : idx_it;
@@ -1014,25 +1050,23 @@ static int register_enqueue(dsir_ctx* c, const dsir_pair_batch* in, int n_iter, 
     ws.release(mark1);
     // nearest ref descriptor
     if (in->forced_idx) {
-      HIP_OK(c, hipMemcpyAsync(idx_out, in->forced_idx + (size_t)it * P * J, sizeof(int32_t) * P * J, hipMemcpyDeviceToDevice, st));
+      // caller-supplied correspondences: clamped into [0, K), out-of-range entries reported through the pair's flag
+      launch_copy_idx_clamped(in->forced_idx + (size_t)it * P * J, J, J, K, P, idx_out, J, out->invalid, P, st);
     } else {
-      hipEvent_t e0 = nullptr, e1 = nullptr;
-      if (c->time_match) {
-        if (c->match_events_used == c->match_events.size()) {
-          hipEvent_t a0, a1;
-          hipEventCreate(&a0); hipEventCreate(&a1);
-          c->match_events.push_back({a0, a1});
-        }
-        e0 = c->match_events[c->match_events_used].first; e1 = c->match_events[c->match_events_used].second;
-        ++c->match_events_used;
-      }
+      // HIP events on the engine's stream: op0..op1 around every kernel of the operation (split, screening, pick,
+      // fallback / norms, search, unpack), k0..k1 around its dominant kernel alone
+      dsir_ctx::MatchEvents* ev = match_event_slot(c);
+      if (ev) hipEventRecord(ev->op0, st);
       if (screen) {
         launch_split16_norm(desc_s, (int64_t)P * J, sc_ah, sc_al, sc_sa, st);
-        launch_nn_screen(desc_s, desc_r, sc_ah, sc_al, sc_bh, sc_bl, sc_sa, sc_sb, P, J, K, idx_out, sc_scratch, st, e0, e1, nullptr,
-                         /*keep_gate=*/it > 0);
+        launch_nn_screen(desc_s, desc_r, sc_ah, sc_al, sc_bh, sc_bl, sc_sa, sc_sb, P, J, K, idx_out, sc_scratch, st, nullptr, nullptr, nullptr,
+                         /*keep_gate=*/it > 0, nullptr, c->screen_acc, ev ? ev->k0 : nullptr, ev ? ev->k1 : nullptr);
       } else {
-        launch_nn_match_ws(desc_s, desc_r, P, J, K, idx_out, match_scratch, st, e0, e1, /*ref_norms_cached=*/it > 0, match_ts_slot(c));
+        ++c->exhaustive_searches;
+        launch_nn_match_ws(desc_s, desc_r, P, J, K, idx_out, match_scratch, st, ev ? ev->k0 : nullptr, ev ? ev->k1 : nullptr,
+                           /*ref_norms_cached=*/it > 0, match_ts_slot(c));
       }
+      if (ev) hipEventRecord(ev->op1, st);
     }
     // inlier RandLA on [xyz_src(t); xyz_ref[idx]] with the SRC pyramid (model.py:574-577)
     const Seg s0 = plain_seg(xyz_cur, (int64_t)J * 3, 3, 3);
@@ -1267,19 +1301,59 @@ int dsir_match_timer_device(dsir_ctx* c, int reset, double* total_ms, int64_t* l
   return 0;
 }
 
-int dsir_match_timer(dsir_ctx* c, int reset, double* total_ms, int64_t* launches) {
-  if (!c) return 1;
+int dsir_screen_stats(dsir_ctx* c, int reset, int64_t* out) {
+  if (!c || !out) return 1;
+  HIP_OK(c, hipSetDevice(c->device));
+  HIP_OK(c, hipStreamSynchronize(c->stream));
+  unsigned long long h[4];
+  HIP_OK(c, hipMemcpy(h, c->screen_acc, sizeof h, hipMemcpyDeviceToHost));
+  for (int i = 0; i < 4; ++i) out[i] = (int64_t)h[i];
+  out[4] = c->exhaustive_searches;
+  if (reset) {
+    HIP_OK(c, hipMemset(c->screen_acc, 0, sizeof h));
+    c->exhaustive_searches = 0;
+  }
+  return 0;
+}
+
+static int collect_match_events(dsir_ctx* c) {
   HIP_OK(c, hipStreamSynchronize(c->stream));
   for (size_t i = 0; i < c->match_events_used; ++i) {
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, c->match_events[i].first, c->match_events[i].second) == hipSuccess) {
-      c->match_ms += ms; ++c->match_launches;
+    float ms = 0.f, kms = 0.f;
+    const auto& e = c->match_events[i];
+    if (hipEventElapsedTime(&ms, e.op0, e.op1) == hipSuccess && hipEventElapsedTime(&kms, e.k0, e.k1) == hipSuccess) {
+      c->match_ms += ms; c->match_kernel_ms += kms; ++c->match_launches;
     }
   }
   c->match_events_used = 0;
+  return 0;
+}
+
+int dsir_match_timer(dsir_ctx* c, int reset, double* total_ms, int64_t* launches) {
+  if (!c) return 1;
+  if (int r = collect_match_events(c)) return r;
   if (total_ms) *total_ms = c->match_ms;
   if (launches) *launches = c->match_launches;
-  if (reset) { c->match_ms = 0.0; c->match_launches = 0; }
+  if (reset) { c->match_ms = 0.0; c->match_kernel_ms = 0.0; c->match_launches = 0; }
+  return 0;
+}
+
+int dsir_match_timer2(dsir_ctx* c, int reset, double* op_ms, double* kernel_ms, int64_t* launches) {
+  if (!c) return 1;
+  if (int r = collect_match_events(c)) return r;
+  if (op_ms) *op_ms = c->match_ms;
+  if (kernel_ms) *kernel_ms = c->match_kernel_ms;
+  if (launches) *launches = c->match_launches;
+  if (reset) { c->match_ms = 0.0; c->match_kernel_ms = 0.0; c->match_launches = 0; }
+  return 0;
+}
+
+int dsir_enable_screen(dsir_ctx* c, int enable) {
+  if (!c) return 1;
+  c->screen_mode = enable != 0;
+  // a captured registration has the choice baked in
+  if (c->graph_exec) { hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
+  c->graph_key.clear();
   return 0;
 }
 

@@ -38,7 +38,10 @@ __global__ void icp_apply_kernel(const float* __restrict__ src, int stride, int 
 
 __global__ __launch_bounds__(QB * NW) void icp_nn_kernel(const float* __restrict__ cur, const float* __restrict__ ref,
                                                          int ref_stride, int J, int K, float r2,
-                                                         int32_t* __restrict__ idx, float* __restrict__ d2) {
+                                                         int32_t* __restrict__ idx, float* __restrict__ d2,
+                                                         const int32_t* __restrict__ skip) {
+  // a converged pair keeps the correspondences of its last search: its points no longer move (block-uniform exit)
+  if (skip && skip[blockIdx.y]) return;
   __shared__ float4 tile[NW][TILE];
   __shared__ float md[NW][QB];
   __shared__ int mi[NW][QB];
@@ -153,7 +156,7 @@ void launch_icp_refine(const float* src, const float* ref, int pairs, int J, int
   hipMemcpyAsync(Ta, T_init, (size_t)pairs * 48, hipMemcpyDeviceToDevice, st);
   const dim3 gj((J + 255) / 256, pairs), gq((J + QB - 1) / QB, pairs);
   hipLaunchKernelGGL(icp_apply_kernel, gj, dim3(256), 0, st, src, stride, J, Ta, cur);
-  hipLaunchKernelGGL(icp_nn_kernel, gq, dim3(QB * NW), 0, st, cur, ref, stride, J, K, r2, idx, d2);
+  hipLaunchKernelGGL(icp_nn_kernel, gq, dim3(QB * NW), 0, st, cur, ref, stride, J, K, r2, idx, d2, (const int32_t*)nullptr);
   hipLaunchKernelGGL(icp_stats_kernel, dim3(pairs), dim3(256), 0, st, idx, d2, w, J, 0, rel_fitness, rel_rmse, state);
   float *Tp = Ta, *Tn = Tb;
   for (int it = 0; it < max_iter; ++it) {
@@ -163,7 +166,7 @@ void launch_icp_refine(const float* src, const float* ref, int pairs, int J, int
     a.ref_ld = stride; a.sigmoid = 0; a.pairs = pairs; a.m = J; a.T = Tstep; a.invalid = nullptr;
     a.src_out = cur; a.src_out_stride = (int64_t)J * 3; a.T_prev = Tp; a.T_cum = Tn; a.T_stride = 12; a.skip = skip;
     launch_kabsch(a, st);
-    hipLaunchKernelGGL(icp_nn_kernel, gq, dim3(QB * NW), 0, st, cur, ref, stride, J, K, r2, idx, d2);
+    hipLaunchKernelGGL(icp_nn_kernel, gq, dim3(QB * NW), 0, st, cur, ref, stride, J, K, r2, idx, d2, (const int32_t*)skip);
     hipLaunchKernelGGL(icp_stats_kernel, dim3(pairs), dim3(256), 0, st, idx, d2, w, J, 1, rel_fitness, rel_rmse, state);
     float* t = Tp; Tp = Tn; Tn = t;
   }

@@ -127,6 +127,19 @@ void launch_gather_max_combine(const float* a, GnRef ga, const float* b, GnRef g
 
 void launch_narrow_i64(const int64_t* src, int32_t* dst, int64_t n, hipStream_t st);
 
+// Caller-supplied index tensors are copied with every entry clamped into its valid range (no gather can leave its
+// tensor); an out-of-range entry raises bit 1 (value 2) of flag[cloud % flag_mod] (flag may be nullptr).
+void launch_copy_idx_clamped(const int32_t* src, int64_t src_cloud_stride, int count, int limit, int clouds, int32_t* dst,
+                             int64_t dst_cloud_stride, int32_t* flag, int flag_mod, hipStream_t st);
+struct PyramidIdxCopy {
+  const int32_t *neigh, *sub, *interp;      // [clouds][S][16], [clouds][S1][16], [clouds][S]
+  int32_t *neigh_out, *sub_out, *interp_out;
+  int S, S1, levels;
+  int nl[6], off[6], soff[6];               // level sizes / offsets (data_base.py:178-181)
+  int32_t* flag; int flag_mod;
+};
+void launch_copy_pyramid_idx(const PyramidIdxCopy& a, int clouds, hipStream_t st);
+
 // KNN (data_base.py:153-183): one level.  support = first n_support points of `pts`.
 void launch_knn16(const float* pts, int64_t cloud_stride, int stride, int n, int clouds, int32_t* out,
                   int64_t out_cloud_stride, hipStream_t st);
@@ -173,8 +186,11 @@ void launch_split16_norm(const float* x, int64_t rows, void* hi, void* lo, float
 void launch_nn_screen(const float* a, const float* b, const void* ah, const void* al, const void* bh, const void* bl,
                       const float* sa, const float* sb, int pairs, int J, int K, int32_t* idx, void* scratch, hipStream_t st,
                       hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, unsigned long long* stats = nullptr,
-                      bool keep_gate = false, const int32_t* bad = nullptr);
-// keep_gate: pairs found not selective by the previous call on this scratch stay exhaustive; bad: launch_split16's flag
+                      bool keep_gate = false, const int32_t* bad = nullptr, unsigned long long* acc = nullptr,
+                      hipEvent_t evk0 = nullptr, hipEvent_t evk1 = nullptr);   // evk0/evk1 bracket screen_kernel alone
+// keep_gate: pairs found not selective by the previous call on this scratch stay exhaustive; bad: launch_split16's flag;
+// acc (device, 4 x u64, optional): running totals {searches, rows, rows left to the exhaustive kernel, pairs searched
+// exhaustively as a whole}
 
 // weighted Kabsch + SE(3) bookkeeping (model.py:22-66, :586-595; se3_torch.py:28-77)
 struct KabschArgs {

@@ -117,6 +117,9 @@ __global__ __launch_bounds__(QB * NW) void knn16_kernel(const float* __restrict_
       for (int t = 0; t < kKnn; ++t) top.insert(md[s][t][lane], mi[s][t][lane]);
     }
     int32_t* o = out + cloud * ocs + (int64_t)q * kKnn;
+    // fewer than 16 finite distances (non-finite coordinates): the empty slots point at the query itself, never out of range
+#pragma unroll
+    for (int t = 0; t < kKnn; ++t) top.i[t] = top.i[t] < 0 ? q : top.i[t];
 #pragma unroll
     for (int t = 0; t < kKnn; t += 4) *reinterpret_cast<int4*>(o + t) = make_int4(top.i[t], top.i[t + 1], top.i[t + 2], top.i[t + 3]);
   }
@@ -163,7 +166,7 @@ __global__ __launch_bounds__(QB * NW) void nn1_kernel(const float* __restrict__ 
       const float d = md[s][lane];
       if (d < bd) { bd = d; bi = mi[s][lane]; }
     }
-    out[cloud * ocs + q] = bi;
+    out[cloud * ocs + q] = bi < 0 ? 0 : bi;   // no finite distance (non-finite coordinates): stay in range
   }
 }
 

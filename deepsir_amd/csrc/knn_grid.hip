@@ -84,6 +84,7 @@ __global__ __launch_bounds__(1024) void grid_setup_kernel(const float* __restric
       }
       if (prod <= max_cells) break;
       h *= 1.26f;
+      if (it == 63) g[0] = g[1] = g[2] = 1;   // infinite extent: one cell (the search degenerates to the brute force)
     }
     GridParams q;
     q.ox = mn[0]; q.oy = mn[1]; q.oz = mn[2]; q.h = h; q.inv_h = 1.f / h; q.gx = g[0]; q.gy = g[1]; q.gz = g[2];
@@ -164,7 +165,11 @@ struct TopLex {
     for (int t = 0; t < kKnn; ++t) k[t] = 0x7f8000007fffffffull;   // (+inf, INT_MAX)
   }
   __device__ __forceinline__ float worst() const { return __uint_as_float((unsigned)(k[kKnn - 1] >> 32)); }
-  __device__ __forceinline__ int index(int t) const { return (int)(unsigned)(k[t] & 0xffffffffull); }
+  // an empty slot (fewer than 16 finite distances: non-finite coordinates) points at `self`, never out of range
+  __device__ __forceinline__ int index(int t, int self) const {
+    const int i = (int)(unsigned)(k[t] & 0xffffffffull);
+    return i == 0x7fffffff ? self : i;
+  }
   __device__ __forceinline__ void insert(float dist, int idx) {
     const unsigned long long x = ((unsigned long long)__float_as_uint(dist) << 32) | (unsigned)idx;
     if (x < k[kKnn - 1]) {
@@ -277,7 +282,7 @@ __global__ __launch_bounds__(KB) void grid_knn_kernel(const float4* __restrict__
   if (live) {
     int32_t* o = out + cloud * ocs + (int64_t)qidx * kKnn;
 #pragma unroll
-    for (int k = 0; k < kKnn; k += 4) *reinterpret_cast<int4*>(o + k) = make_int4(top.index(k), top.index(k + 1), top.index(k + 2), top.index(k + 3));
+    for (int k = 0; k < kKnn; k += 4) *reinterpret_cast<int4*>(o + k) = make_int4(top.index(k, qidx), top.index(k + 1, qidx), top.index(k + 2, qidx), top.index(k + 3, qidx));
   }
 }
 

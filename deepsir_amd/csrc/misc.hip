@@ -127,6 +127,44 @@ __global__ void copy_rows_i32_kernel(const int32_t* __restrict__ src, int64_t sc
     dst[cloud * dcs + e] = src[cloud * scs + e];
 }
 
+// Caller-supplied indices (forced correspondences, the reference's pyramids): copied with every entry clamped into
+// [0, limit) so that no gather can leave its tensor; an out-of-range entry raises bit 1 of flag[cloud % flag_mod].
+__global__ void copy_idx_clamped_kernel(const int32_t* __restrict__ src, int64_t scs, int count, int limit,
+                                        int32_t* __restrict__ dst, int64_t dcs, int32_t* __restrict__ flag, int flag_mod) {
+  const int cloud = blockIdx.y;
+  bool bad = false;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < count; e += gridDim.x * blockDim.x) {
+    const int v = src[cloud * scs + e];
+    const bool oob = v < 0 || v >= limit;
+    bad |= oob;
+    dst[cloud * dcs + e] = oob ? (v < 0 ? 0 : limit - 1) : v;
+  }
+  if (bad && flag) atomicOr(flag + cloud % flag_mod, 2);
+}
+
+// the three index tensors of a KNN pyramid in one launch: level l of neigh / sub holds indices into level l's n_l points,
+// level l of interp into the n_{l+1} points of the level below
+__global__ void copy_pyramid_idx_kernel(PyramidIdxCopy a) {
+  const int cloud = blockIdx.y;
+  const int64_t total = (int64_t)a.S * kKnn + (int64_t)a.S1 * kKnn + a.S;
+  bool bad = false;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t* src; int32_t* dst; int64_t i; int row; bool is_sub = false, is_interp = false;
+    if (e < (int64_t)a.S * kKnn) { i = e; src = a.neigh + cloud * (int64_t)a.S * kKnn; dst = a.neigh_out + cloud * (int64_t)a.S * kKnn; row = (int)(i / kKnn); }
+    else if (e < (int64_t)(a.S + a.S1) * kKnn) { i = e - (int64_t)a.S * kKnn; src = a.sub + cloud * (int64_t)a.S1 * kKnn; dst = a.sub_out + cloud * (int64_t)a.S1 * kKnn; row = (int)(i / kKnn); is_sub = true; }
+    else { i = e - (int64_t)(a.S + a.S1) * kKnn; src = a.interp + cloud * (int64_t)a.S; dst = a.interp_out + cloud * (int64_t)a.S; row = (int)i; is_interp = true; }
+    int lvl = 0;
+    if (is_sub) { while (lvl + 1 < a.levels && row >= a.soff[lvl + 1]) ++lvl; }
+    else { while (lvl + 1 < a.levels && row >= a.off[lvl + 1]) ++lvl; }
+    const int limit = is_interp ? a.nl[lvl + 1] : a.nl[lvl];
+    const int v = src[i];
+    const bool oob = v < 0 || v >= limit;
+    bad |= oob;
+    dst[i] = oob ? (v < 0 ? 0 : limit - 1) : v;
+  }
+  if (bad && a.flag) atomicOr(a.flag + cloud % a.flag_mod, 2);
+}
+
 inline int grid_for(int64_t total, int block = 256, int cap = 2048) {
   int64_t g = (total + block - 1) / block;
   return (int)(g < 1 ? 1 : (g > cap ? cap : g));
@@ -170,6 +208,19 @@ void launch_copy_rows_i32(const int32_t* src, int64_t scs, int rows, int width, 
   if (rows <= 0) return;
   dim3 grid(grid_for((int64_t)rows * width), clouds);
   hipLaunchKernelGGL(copy_rows_i32_kernel, grid, dim3(256), 0, st, src, scs, rows * width, dst, dcs);
+}
+
+void launch_copy_idx_clamped(const int32_t* src, int64_t scs, int count, int limit, int clouds, int32_t* dst, int64_t dcs,
+                             int32_t* flag, int flag_mod, hipStream_t st) {
+  if (count <= 0 || clouds <= 0) return;
+  dim3 grid(grid_for(count), clouds);
+  hipLaunchKernelGGL(copy_idx_clamped_kernel, grid, dim3(256), 0, st, src, scs, count, limit, dst, dcs, flag, flag_mod < 1 ? 1 : flag_mod);
+}
+
+void launch_copy_pyramid_idx(const PyramidIdxCopy& a, int clouds, hipStream_t st) {
+  if (clouds <= 0) return;
+  dim3 grid(grid_for((int64_t)a.S * kKnn + (int64_t)a.S1 * kKnn + a.S), clouds);
+  hipLaunchKernelGGL(copy_pyramid_idx_kernel, grid, dim3(256), 0, st, a);
 }
 
 }  // namespace dsir

@@ -202,9 +202,12 @@ __global__ __launch_bounds__(256) void nn_match_kernel(const float* __restrict__
   if (tstamp && threadIdx.x == 0) atomicMax(tstamp + 1, (unsigned long long)wall_clock64());
 }
 
+// A row whose distances are all NaN (non-finite descriptors) never updates its slot: index 0, like torch.min over an
+// all-NaN row (the first NaN), never -1 - the consumers gather by this index.  The pair ends as identity + invalid
+// flag in the Kabsch step (model.py:61-64).
 __global__ void unpack_idx_kernel(const unsigned long long* __restrict__ packed, int64_t n, int32_t* __restrict__ idx) {
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
-    idx[e] = (int32_t)(packed[e] & 0xffffffffull);
+    idx[e] = packed_index(packed[e]);
 }
 
 }  // namespace

@@ -388,10 +388,10 @@ __global__ __launch_bounds__(256) void unpack_listed_kernel(const unsigned long 
   const int i = blockIdx.x * 256 + threadIdx.x;
   const int64_t base = (int64_t)pair * J;
   if (g >= ovf_min) {
-    if (i < J) idx[base + i] = (int32_t)(packed[base + i] & 0xffffffffull);
+    if (i < J) idx[base + i] = packed_index(packed[base + i]);
   } else if (i < g) {
     const int r = rowlist[base + i];
-    idx[base + r] = (int32_t)(packed[base + r] & 0xffffffffull);
+    idx[base + r] = packed_index(packed[base + r]);
   }
 }
 
@@ -423,6 +423,21 @@ __global__ void screen_reset_kernel(int32_t* __restrict__ ovf, int pairs, int ov
   }
 }
 
+// running totals of a context (dsir_screen_stats): searches, rows searched, rows left to the exhaustive kernel, pairs
+// searched exhaustively as a whole
+__global__ void screen_account_kernel(const int32_t* __restrict__ ovf, int pairs, int ovf_min, int J,
+                                      unsigned long long* __restrict__ acc) {
+  unsigned long long rows = 0, full = 0;
+  for (int p = threadIdx.x; p < pairs; p += blockDim.x) {
+    const int g = ovf[p];
+    rows += (unsigned long long)(g >= ovf_min ? J : g);
+    full += g >= ovf_min ? 1ull : 0ull;
+  }
+  if (rows) atomicAdd(acc + 2, rows);
+  if (full) atomicAdd(acc + 3, full);
+  if (threadIdx.x == 0) { atomicAdd(acc, 1ull); atomicAdd(acc + 1, (unsigned long long)pairs * (unsigned long long)J); }
+}
+
 inline int grid_for(int64_t n) { const int64_t g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > 65535 ? 65535 : g)); }
 
 }  // namespace
@@ -449,7 +464,8 @@ void launch_split16_norm(const float* x, int64_t rows, void* hi, void* lo, float
 // a, b: fp32 descriptors [pairs][J|K][64] with their fp16 splits (ah, al, bh, bl) and squared norms (sa, sb)
 void launch_nn_screen(const float* a, const float* b, const void* ah, const void* al, const void* bh, const void* bl,
                       const float* sa, const float* sb, int pairs, int J, int K, int32_t* idx, void* scratch, hipStream_t st,
-                      hipEvent_t ev0, hipEvent_t ev1, unsigned long long* stats, bool keep_gate, const int32_t* bad) {
+                      hipEvent_t ev0, hipEvent_t ev1, unsigned long long* stats, bool keep_gate, const int32_t* bad,
+                      unsigned long long* acc, hipEvent_t evk0, hipEvent_t evk1) {
   const size_t rows = (size_t)pairs * J;
   char* p = reinterpret_cast<char*>(scratch);
   auto take = [&](size_t bytes) { char* r = p; p += (bytes + 255) & ~(size_t)255; return r; };
@@ -495,13 +511,16 @@ void launch_nn_screen(const float* a, const float* b, const void* ah, const void
   const dim3 grid((unsigned)((int64_t)rb_count * splits * pairs));
   const _Float16 *Ah = reinterpret_cast<const _Float16*>(ah), *Al = reinterpret_cast<const _Float16*>(al);
   const _Float16 *Bh = reinterpret_cast<const _Float16*>(bh), *Bl = reinterpret_cast<const _Float16*>(bl);
+  if (evk0) (void)hipEventRecord(evk0, st);
   hipLaunchKernelGGL((screen_kernel<RT, NWV>), grid, dim3(NWV * 64), 0, st, Ah, Al, Bh, Bl, sa, sb, J, K, cols, rb_count, splits, umin,
                      cnt, cand, ovf, rowlist, ovf_min);
+  if (evk1) (void)hipEventRecord(evk1, st);
   hipLaunchKernelGGL(exact_pick_kernel, dim3((J + 255) / 256, pairs), dim3(256), 0, st, a, b, sa, sb, J, K, umin, cnt, cand, ovf,
                      ovf_min, rowlist, idx);
   launch_nn_match_gated(a, b, sa, sb, pairs, J, K, packed, ovf, ovf_min, rowlist, st);
   hipLaunchKernelGGL(unpack_listed_kernel, dim3((J + 255) / 256, pairs), dim3(256), 0, st, packed, ovf, ovf_min, rowlist, J, idx);
   if (ev1) (void)hipEventRecord(ev1, st);
+  if (acc) hipLaunchKernelGGL(screen_account_kernel, dim3(1), dim3(256), 0, st, ovf, pairs, ovf_min, J, acc);
   static const bool debug = getenv("DSIR_SCREEN_DEBUG") != nullptr;   // diagnostic: rows left to the exhaustive kernel (synchronises)
   if (debug) {
     std::vector<int32_t> h(pairs);

@@ -386,6 +386,25 @@ class Engine:
         self._call(self.lib.dsir_match_timer(self.h, 1 if reset else 0, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def match_timer2(self, reset=True):
+        """(operation ms, dominant-kernel ms, launches) of the timed arg-min searches (HIP events on the engine's stream)."""
+        op, k, n = C.c_double(), C.c_double(), C.c_int64()
+        self._call(self.lib.dsir_match_timer2(self.h, 1 if reset else 0, C.byref(op), C.byref(k), C.byref(n)))
+        return op.value, k.value, n.value
+
+    def enable_screen(self, on=True):
+        """A/B switch: off = the exhaustive exact-fp32 arg-min kernel throughout (same bits, include/dsir.h)."""
+        self._call(self.lib.dsir_enable_screen(self.h, 1 if on else 0))
+
+    SCREEN_STAT_NAMES = ("screened_searches", "rows_searched", "rows_undecided", "pairs_exhaustive", "exhaustive_searches")
+
+    def screen_stats(self, reset=True) -> Dict[str, int]:
+        """Which arg-min path dsir_register took since the last reset and how selective the screening was
+        (include/dsir.h, dsir_screen_stats)."""
+        out = (C.c_int64 * 5)()
+        self._call(self.lib.dsir_screen_stats(self.h, 1 if reset else 0, out))
+        return {k: int(out[i]) for i, k in enumerate(self.SCREEN_STAT_NAMES)}
+
     def match_timer_device(self, reset=True):
         """(total ms, launches) of the timed nn_match launches on the device clock (first wave start .. last wave end)."""
         ms, n = C.c_double(), C.c_int64()
@@ -425,6 +444,8 @@ class EnginePool:
     def register(self, points_src, points_ref, n_iter: int = 5, want_aux: bool = True, sync: bool = True,
                  out: Optional[dict] = None, pyramids: Optional[dict] = None):
         P = points_src.shape[0]
+        if P > self.per * self.streams:
+            raise EngineError(f"pairs={P} exceeds the pool's max_pairs={self.per * self.streams}")
         sl = self._slices(P)
         if out is None:
             out = {"transforms": torch.empty((P, n_iter, 3, 4), dtype=torch.float32, device=self.device)}
@@ -466,3 +487,21 @@ class EnginePool:
     def enable_graph(self, on=True):
         for e in self.engines:
             e.enable_graph(on)
+
+    def match_timer2(self, reset=True):
+        op = k = n = 0
+        for e in self.engines:
+            a, b, c = e.match_timer2(reset)
+            op, k, n = op + a, k + b, n + c
+        return op, k, n
+
+    def enable_screen(self, on=True):
+        for e in self.engines:
+            e.enable_screen(on)
+
+    def screen_stats(self, reset=True) -> Dict[str, int]:
+        tot: Dict[str, int] = {}
+        for e in self.engines:
+            for k, v in e.screen_stats(reset).items():
+                tot[k] = tot.get(k, 0) + v
+        return tot

@@ -122,7 +122,7 @@ class Network(nn.Module):
             "pt_ref": ref[:, :, :3].contiguous(),
             "perm_matrices": [out["logits"][i] for i in range(num_reg_iter)],
             "pred_pairs": [torch.cat([ar, idx_cpu[i][:, :, None]], dim=2) for i in range(num_reg_iter)],
-            "invalid_gradient": bool(out["invalid"].any().item()),
+            "invalid_gradient": bool((out["invalid"] & 1).any().item()),   # bit 0 = SVD failure (model.py:61-64)
             "pt_ref_new": out["pt_ref_new"],
         }
         return transforms, endpoints

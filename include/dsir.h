@@ -153,7 +153,9 @@ typedef struct dsir_pair_batch {
    * already int32.  All NULL => built on device (dsir_knn_pyramid). */
   const float* src_xyz;   const int32_t* src_neigh;   const int32_t* src_sub;   const int32_t* src_interp;
   const float* ref_xyz;   const int32_t* ref_neigh;   const int32_t* ref_sub;   const int32_t* ref_interp;
-  /* Optional teacher forcing (tests): correspondences per iteration [n_iter][P][J] i32. */
+  /* Optional teacher forcing (tests): correspondences per iteration [n_iter][P][J] i32.
+   * Caller-supplied indices (these and the pyramids) are clamped into their valid range on device, so a bad index
+   * can never fault a gather; the pair's invalid flag then carries bit 1 (value 2). */
   const int32_t* forced_idx;
 } dsir_pair_batch;
 
@@ -162,7 +164,10 @@ typedef struct dsir_pair_result {
   int32_t* idx;          /* [n_iter][P][J] arg-min correspondences (pred_pairs[...,1])   or NULL  */
   float* logits;         /* [n_iter][P][J] inlier logits (endpoints['perm_matrices'])    or NULL  */
   float* pt_ref_new;     /* [P][J][3] matched ref points of the last iteration           or NULL  */
-  int32_t* invalid;      /* [P] OR over iterations (endpoints['invalid_gradient'])       or NULL  */
+  int32_t* invalid;      /* [P] OR over iterations: bit 0 = non-finite Kabsch covariance, identity returned
+                          *     (endpoints['invalid_gradient'], model.py:61-64; also the outcome of a non-finite
+                          *     input point: that pair alone, the other pairs of the batch are unaffected);
+                          *     bit 1 = a caller-supplied index was out of range and clamped       or NULL  */
 } dsir_pair_result;
 
 /* Replaces Network.forward -> forward_align_4 (network/model.py:297-298,
@@ -244,11 +249,23 @@ int dsir_enable_graph(dsir_ctx* ctx, int enable);
  * with HIP events on the engine stream since the last reset: total ms and
  * launch count. */
 int dsir_match_timer(dsir_ctx* ctx, int reset, double* total_ms, int64_t* launches);
+/* The same launches with the operation's dominant kernel (screen_kernel of csrc/nn_screen.hip, or nn_match_kernel when
+ * the exhaustive path runs) bracketed on its own: op_ms = every kernel of the operation, kernel_ms = that kernel. */
+int dsir_match_timer2(dsir_ctx* ctx, int reset, double* op_ms, double* kernel_ms, int64_t* launches);
+/* A/B switch (measurement): 0 = dsir_register always takes the exhaustive exact-fp32 arg-min kernel, 1 (default) = the
+ * fp16-screened path for large problems.  Both return the same bits.  Initialised from DSIR_NO_SCREEN. */
+int dsir_enable_screen(dsir_ctx* ctx, int enable);
 /* Same launches, bracketed on the DEVICE's constant-rate clock inside the kernel (first wave start .. last wave end,
  * the quantity a kernel trace reports): unlike the HIP-event bracket it does not include time the launch spends
  * queued behind other streams' kernels when several engines share the GPU. */
 int dsir_match_timer_device(dsir_ctx* ctx, int reset, double* total_ms, int64_t* launches);
 int dsir_enable_match_timer(dsir_ctx* ctx, int enable);
+/* Which arg-min path dsir_register took since the last reset, and how selective the screening was.  out (HOST, 5 x i64):
+ * [0] searches through the screened path (csrc/nn_screen.hip), [1] src rows they searched, [2] of those the rows the
+ * screening left undecided (searched by the exhaustive exact-fp32 kernel), [3] pairs searched exhaustively as a whole,
+ * [4] searches that took the exhaustive kernel directly (small problems, forced runs excluded).  Synchronises.
+ * Not counted while a hipGraph replays (dsir_enable_graph): [4] is a host-side counter. */
+int dsir_screen_stats(dsir_ctx* ctx, int reset, int64_t* out);
 
 #ifdef __cplusplus
 }

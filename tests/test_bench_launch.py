@@ -1,0 +1,40 @@
+"""bench.py's multi-rank plumbing on CPU: `--gpus N` without a torchrun environment re-launches the script as
+N ranks, the ranks agree on the world size through a collective, pairs shard in contiguous blocks and the per-pair results
+come back through one padded all_gather.  `--dry-run` swaps RCCL for gloo and leaves the engine out."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, env_extra=None, timeout=300):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True,
+                          timeout=timeout)
+
+
+def _json_line(stdout):
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, stdout
+    return json.loads(lines[0])
+
+
+def test_gpus_2_spawns_two_ranks_and_counts_them():
+    r = _run(["--gpus", "2", "--dry-run", "--pairs", "5"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _json_line(r.stdout)
+    assert j["n_gpus"] == 2 and j["world_size"] == 2 and j["gather_ok"] and j["pairs_total"] == 13
+
+
+def test_single_rank_dry_run():
+    j = _json_line(_run(["--dry-run", "--pairs", "4"]).stdout)
+    assert j["n_gpus"] == 1 and j["gather_ok"]
+
+
+def test_world_size_mismatch_is_an_error():
+    """A rank started by someone else's launcher with a different world size than --gpus says must not print a number."""
+    r = _run(["--gpus", "4", "--dry-run"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "launched as 1 ranks" in r.stderr

@@ -1,0 +1,196 @@
+"""GPU parity on the configuration bench.py measures: many 5000-point pairs per call through
+``EnginePool`` on 4 HIP streams, large enough per engine (P*J*K >= 2e8, csrc/engine.hip) for the fp16-screened
+arg-min (csrc/nn_screen.hip) to run - the path every golden / oracle test of tests/test_gpu_parity.py misses
+because one or two pairs take the exhaustive kernel.  Checked directly against the CPU oracle, not against
+another HIP kernel.  Robustness of the same path to non-finite input, bad caller indices and weight reloads
+under hipGraph replay lives here too.
+"""
+import numpy as np
+import pytest
+import torch
+
+from test_gpu_parity import assert_pose_close, cu, _dev
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_check(cfg, sd, raw_pair, idx_engine, T_engine, logits_engine, n_iter, tag):
+    """Teacher-force the oracle with the engine's correspondences of ONE pair: poses within 1e-4 rad / 1e-4 m at every
+    iteration; and wherever the oracle's own descriptors show a clear fp64 top-2 gap the engine's arg-min must be the
+    oracle's (the rows without a clear gap are the fp32 near-ties no implementation reproduces)."""
+    from oracle.knn import add_pyramids
+    from oracle.network import OracleNet, to_torch
+    data = to_torch(add_pyramids(raw_pair, cfg.num_knn, cfg.sub_sampling_ratio))
+    taps = {}
+    T_forced, ep = OracleNet(cfg, sd).register(data, n_iter, forced_idx=[idx_engine[i][None].long() for i in range(n_iter)], taps=taps)
+    assert_pose_close(T_engine, np.stack([t.numpy()[0] for t in T_forced]), 1e-4, 1e-4, tag)
+    np.testing.assert_allclose(logits_engine, np.stack([l.numpy()[0] for l in ep["perm_matrices"]]), rtol=2e-3, atol=2e-3)
+    clear_frac = []
+    for i in range(n_iter):
+        best, second, arg = OracleNet.nn_gap(taps["desc_src"][i], taps["desc_ref"][i])
+        clear = ((second - best) > 1e-4 * (1.0 + best.abs()))[0].numpy()
+        clear_frac.append(float(clear.mean()))
+        assert np.array_equal(idx_engine[i].numpy()[clear], arg[0].numpy()[clear]), f"{tag}: iteration {i}"
+    print(f"[bench-config] {tag}: rows with a clear fp64 gap per iteration {['%.3f' % c for c in clear_frac]} - all equal to the oracle's arg-min")
+    assert clear_frac[0] > 0.3
+
+
+def test_pool_screened_path_vs_oracle():
+    """32 pairs x 5000 points on EnginePool(streams=4): 8 pairs per engine = 2e8 (row, column) pairs per search, the
+    threshold from which dsir_register screens (bench.py default: 64 per engine).  The engine's correspondences of two
+    pairs (first engine, last engine) are forced into the oracle."""
+    from deepsir_amd.arch import NetConfig
+    from deepsir_amd.engine import EnginePool
+    from deepsir_amd.synth import make_batch, make_pair
+    from deepsir_amd.weights import generate_state_dict
+    torch.set_num_threads(16)
+    cfg = NetConfig(feat_len=3)
+    sd = generate_state_dict(cfg, 0)
+    P, N, n_iter = 32, 5000, 5
+    seeds = [10_000 + i for i in range(P)]                       # bench.py's seeds of rank 0
+    b = make_batch(N, seeds, 3)
+    pool = EnginePool(cfg, 0, max_points=N, max_pairs=P, streams=4)
+    pool.load_state_dict(sd)
+    pool.screen_stats(reset=True)
+    out = pool.register(cu(b["points_src"]), cu(b["points_ref"]), n_iter)
+    st = pool.screen_stats()
+    print(f"[bench-config] screening: {st}")
+    assert st["screened_searches"] == 4 * n_iter and st["exhaustive_searches"] == 0, "the screened path did not run"
+    assert st["rows_searched"] == P * N * n_iter
+    assert not bool(out["invalid"].any())
+    idx, T, lg = out["idx"].cpu(), out["transforms"].cpu().numpy(), out["logits"].cpu().numpy()
+    assert int(idx.min()) >= 0 and int(idx.max()) < N
+    for p in (0, P - 1):
+        raw = make_pair(N, seeds[p], 3)
+        assert np.array_equal(raw["points_src"][0], b["points_src"][p])
+        _oracle_check(cfg, sd, raw, idx[:, p], T[p], lg[:, p], n_iter, f"pair {p} of {P} (4 streams, screened)")
+    # same call without the aux outputs (what bench.py times) returns the same transforms
+    q = pool.register(cu(b["points_src"]), cu(b["points_ref"]), n_iter, want_aux=False)
+    assert torch.equal(q["transforms"], out["transforms"])
+    pool.close()
+
+
+@pytest.mark.parametrize("where,value", [("src", float("nan")), ("ref", float("nan")), ("src", float("inf")), ("src", -float("inf"))])
+def test_non_finite_point_poisons_only_its_pair(where, value):
+    """One non-finite coordinate in one cloud (reference: the whole forward ends in the SVD's except branch, identity +
+    invalid_gradient, model.py:45-64).  Here: that pair alone returns the identity with invalid bit 0, the other pairs of
+    the batch are bitwise what they are without it, every index stays in range, nothing faults."""
+    from deepsir_amd.arch import NetConfig
+    from deepsir_amd.engine import Engine
+    from deepsir_amd.synth import make_batch
+    from deepsir_amd.weights import generate_state_dict
+    cfg = NetConfig(feat_len=3)
+    P, N = 3, 2048
+    eng = Engine(cfg, 0, max_points=N, max_pairs=P)
+    eng.load_state_dict(generate_state_dict(cfg, 0))
+    b = make_batch(N, [61, 62, 63], 3)
+    src, ref = cu(b["points_src"]), cu(b["points_ref"])
+    clean = {k: v.clone() for k, v in eng.register(src, ref, 3).items() if isinstance(v, torch.Tensor)}
+    assert not bool(clean["invalid"].any())
+    (src if where == "src" else ref)[1, 100, 1] = value
+    out = eng.register(src, ref, 3)
+    assert [int(v) for v in out["invalid"]] == [0, 1, 0]
+    eye = torch.eye(3, 4, device=src.device)[None].expand(3, 3, 4)
+    assert torch.equal(out["transforms"][1], eye)
+    assert int(out["idx"].min()) >= 0 and int(out["idx"].max()) < N
+    for p in (0, 2):
+        for k in ("transforms", "logits", "pt_ref_new"):
+            assert torch.equal(out[k][p] if k != "logits" else out[k][:, p], clean[k][p] if k != "logits" else clean[k][:, p]), (k, p)
+        assert torch.equal(out["idx"][:, p], clean["idx"][:, p])
+    # the stage entry point stays in range as well
+    xyz, neigh, sub, interp = eng.knn_pyramid(src)
+    for t, hi in ((neigh, N), (sub, N), (interp, N)):
+        assert int(t.min()) >= 0 and int(t.max()) < hi
+    eng.close()
+
+
+def test_non_finite_point_in_a_screened_batch():
+    """The same with the fp16-screened arg-min engaged (8 pairs x 5000 on one engine): the rows of the poisoned pair go
+    through the exhaustive fallback, come back as index 0 instead of -1, and the other pairs keep their bits."""
+    from deepsir_amd.arch import NetConfig
+    from deepsir_amd.engine import Engine
+    from deepsir_amd.synth import make_batch
+    from deepsir_amd.weights import generate_state_dict
+    cfg = NetConfig(feat_len=3)
+    P, N = 8, 5000
+    eng = Engine(cfg, 0, max_points=N, max_pairs=P)
+    eng.load_state_dict(generate_state_dict(cfg, 0))
+    b = make_batch(N, list(range(71, 71 + P)), 3)
+    src, ref = cu(b["points_src"]), cu(b["points_ref"])
+    clean = {k: v.clone() for k, v in eng.register(src, ref, 2).items() if isinstance(v, torch.Tensor)}
+    eng.screen_stats(reset=True)
+    src[5, 4321, 0] = float("nan")
+    out = eng.register(src, ref, 2)
+    assert eng.screen_stats()["screened_searches"] == 2
+    assert [int(v) for v in out["invalid"]] == [0, 0, 0, 0, 0, 1, 0, 0]
+    assert int(out["idx"].min()) >= 0 and int(out["idx"].max()) < N
+    keep = [p for p in range(P) if p != 5]
+    assert torch.equal(out["transforms"][keep], clean["transforms"][keep])
+    assert torch.equal(out["idx"][:, keep], clean["idx"][:, keep])
+    assert torch.equal(out["transforms"][5], torch.eye(3, 4, device=src.device)[None].expand(2, 3, 4))
+    eng.close()
+
+
+def test_bad_caller_indices_are_clamped_and_flagged():
+    """forced_idx / caller pyramids with out-of-range entries: clamped on device (no fault), reported as invalid bit 1."""
+    from deepsir_amd.arch import NetConfig
+    from deepsir_amd.engine import Engine
+    from deepsir_amd.synth import make_batch
+    from deepsir_amd.weights import generate_state_dict
+    cfg = NetConfig(feat_len=3)
+    P, N = 2, 2048
+    eng = Engine(cfg, 0, max_points=N, max_pairs=P)
+    eng.load_state_dict(generate_state_dict(cfg, 0))
+    b = make_batch(N, [81, 82], 3)
+    src, ref = cu(b["points_src"]), cu(b["points_ref"])
+    good = eng.register(src, ref, 2)
+    forced = good["idx"].clone()
+    ok = eng.register(src, ref, 2, forced_idx=forced)
+    assert torch.equal(ok["transforms"], good["transforms"]) and not bool(ok["invalid"].any())
+    forced[1, 1, 7] = -5
+    forced[0, 1, 9] = 1 << 30
+    bad = eng.register(src, ref, 2, forced_idx=forced)
+    assert [int(v) for v in bad["invalid"]] == [0, 2]
+    assert torch.equal(bad["transforms"][0], good["transforms"][0])
+    assert torch.isfinite(bad["transforms"]).all()
+    xyz, neigh, sub, interp = eng.knn_pyramid(torch.cat([src, ref], 0))
+    pyr = {"points_src_xyz": xyz[:P], "points_ref_xyz": xyz[P:], "points_src_neigh_idx": neigh[:P].clone(), "points_ref_neigh_idx": neigh[P:],
+           "points_src_sub_idx": sub[:P], "points_ref_sub_idx": sub[P:].clone(), "points_src_interp_idx": interp[:P].clone(),
+           "points_ref_interp_idx": interp[P:]}
+    sup = eng.register(src, ref, 2, pyramids=pyr)
+    assert torch.equal(sup["transforms"], good["transforms"]) and not bool(sup["invalid"].any())
+    pyr["points_src_neigh_idx"][0, N + 3, 2] = N            # level 1 has N/4 points: far out of range
+    pyr["points_ref_sub_idx"][1, 0, 0] = -1
+    pyr["points_src_interp_idx"][0, 5, 0] = N // 4          # level-0 interp indexes the N/4 points of level 1
+    sup = eng.register(src, ref, 2, pyramids=pyr)
+    assert [int(v) & 2 for v in sup["invalid"]] == [2, 2]
+    assert torch.isfinite(sup["transforms"]).all()
+    eng.close()
+
+
+def test_graph_replay_after_weight_reload():
+    """dsir_finalize_weights drops a captured hipGraph (it holds the old weight blob's addresses): graph on, register,
+    load other weights, register again into the same buffers == a fresh engine with those weights."""
+    from deepsir_amd.arch import NetConfig
+    from deepsir_amd.engine import Engine
+    from deepsir_amd.synth import make_batch
+    from deepsir_amd.weights import generate_state_dict
+    cfg = NetConfig(feat_len=3)
+    sd0, sd1 = generate_state_dict(cfg, 0), generate_state_dict(cfg, 5)
+    b = make_batch(2048, [91], 3)
+    src, ref = cu(b["points_src"]), cu(b["points_ref"])
+    eng = Engine(cfg, 0, max_points=2048, max_pairs=1)
+    eng.load_state_dict(sd0)
+    eng.enable_graph(True)
+    first = eng.register(src, ref, 3)
+    keep = {k: v for k, v in first.items() if isinstance(v, torch.Tensor)}
+    T0 = keep["transforms"].clone()
+    eng.load_state_dict(sd1)
+    second = eng.register(src, ref, 3, out=keep)
+    fresh = Engine(cfg, 0, max_points=2048, max_pairs=1)
+    fresh.load_state_dict(sd1)
+    want = fresh.register(src, ref, 3)
+    for k in ("transforms", "idx", "logits"):
+        assert torch.equal(second[k], want[k]), k
+    assert not torch.equal(T0, want["transforms"])
+    eng.close(); fresh.close()
