@@ -34,7 +34,7 @@ def main(ref_root="/root/reference"):
     import common.math.so3 as ref_so3  # type: ignore
     if not hasattr(Rotation, "from_dcm"):
         ref_so3.Rotation = _RotationCompat      # module global of the imported reference, in memory only
-    from common.metrics_util import compute_metrics  # type: ignore
+    from common.metrics_util import compute_metrics, rte_rre  # type: ignore
 
     rng = np.random.Generator(np.random.Philox(key=4242))
     out = {}
@@ -57,6 +57,11 @@ def main(ref_root="/root/reference"):
         out[f"c{i}_gt"], out[f"c{i}_pred"] = p["transform_gt"], pred[None]
         for k, v in m.items():
             out[f"c{i}_{k}"] = np.asarray(v, dtype=np.float64)
+        # the harness's own criterion (metrics_util.py:13-24, called at test.py:432-441) on the same poses, fp32 as the
+        # harness holds them, under both threshold sets (test.py:49-54)
+        out[f"c{i}_rte_rre_3dmatch"] = np.asarray(rte_rre(pred, p["transform_gt"][0], 0.3, 15.0), dtype=np.float64)
+        out[f"c{i}_rte_rre_kitti"] = np.asarray(rte_rre(pred, p["transform_gt"][0], 0.6, 5.0), dtype=np.float64)
+    out["rte_rre_none"] = np.asarray(rte_rre(None, cases[0][0]["transform_gt"][0], 0.3, 15.0), dtype=np.float64)
     out["n_cases"] = np.asarray(len(cases))
     out["thresholds"] = np.asarray([0.3, 15.0])
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "metrics_cases.npz"), **out)

@@ -301,6 +301,9 @@ def _assert_flips_are_near_ties(name, g, m, cfg, sd, data, eng, idx, it):
     # and the reference's bar wherever it is meaningful: most flips are ties at fp32 resolution
     tight = d_e - dmin <= 1e-6 * (1.0 + np.abs(dmin))
     print(f"[near-tie] {int(tight.sum())} of {len(bad)} flips within 1e-6 (1 + |d|) of the fp64 minimum")
+    # measured on MI355X: every flip on every fixture sits within 4e-7 of the fp64 minimum (one row per case), so SURVEY's
+    # own bar holds as written; the derived bound above stays as the principled ceiling
+    assert tight.all(), "a disagreeing row is further than 1e-6 (1 + |d|) from the fp64 minimum"
 
 
 def test_register_with_supplied_pyramids_and_batch():

@@ -117,3 +117,22 @@ def test_semantic_metric_matches_hand_computation():
     assert iou[7] == pytest.approx(1.0) and iou[2] == 0.0 and iou[5] == 0.0
     assert mean_iou == pytest.approx((1 / 3 + 1 / 2 + 1.0) / 19) and mean_acc == pytest.approx(3 / 5)
     assert m.seen == 0                              # result() resets, like semantic_metric()
+
+
+def test_rte_rre_matches_reference_vectors():
+    """deepsir_amd.metrics.rte_rre against the reference's own rte_rre (common/metrics_util.py:13-24), vectors generated by
+    oracle/gen_golden_metrics.py from the imported reference: six poses, both threshold sets of test.py:49-54, and None."""
+    import os
+    from conftest import GOLD
+    from deepsir_amd.metrics import THRESHOLDS, rte_rre
+    g = np.load(os.path.join(GOLD, "metrics_cases.npz"))
+    succ = []
+    for i in range(int(g["n_cases"])):
+        pred, gt = g[f"c{i}_pred"][0], g[f"c{i}_gt"][0]
+        for name, key in (("3DMatch", "3dmatch"), ("KITTI", "kitti")):
+            got = rte_rre(pred, gt, *THRESHOLDS[name])
+            want = g[f"c{i}_rte_rre_{key}"]
+            assert np.array_equal(got, want), (i, name, got, want)       # same fp operations in the same order: equal bits
+            succ.append(bool(want[0]))
+    assert any(succ) and not all(succ)                                   # both outcomes are exercised
+    assert np.array_equal(rte_rre(None, g["c0_gt"][0], 0.3, 15.0), g["rte_rre_none"])
