@@ -74,6 +74,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg (baseline + parity check)")
     ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 latency phase (profiling runs)")
     ap.add_argument("--no-companion", action="store_true", help="skip the exhaustive-arg-min companion run (profiling runs)")
+    ap.add_argument("--timed-only", action="store_true",
+                    help="nothing but the allocation call, the warm-up and the timed steps (PMC passes: every dispatch then belongs to a step)")
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU rehearsal of the launcher, the sharding and the result gather (gloo); no engine, no number")
     return ap.parse_args(argv)
@@ -295,7 +297,9 @@ def main():
     # ------------------------------------------------------------------ rank-0 extras (outside the timed region)
     model_only = single = single_ex = companion = latency = None
     checks = []
-    if rank == 0:
+    if a.timed_only:
+        a.no_cpu_baseline = a.no_latency = a.no_companion = True
+    if rank == 0 and not a.timed_only:
         e0 = eng.engines[0] if hasattr(eng, "engines") else eng
         # Roofline pass: the dominant kernel timed with HIP events on its stream while ONE engine runs the hot path over
         # its share of the batch (same shapes and launches as above).  With several engines in flight a bracket also
@@ -322,7 +326,7 @@ def main():
             e0.enable_screen(True)
         del s0, r0
 
-    if world == 1:
+    if world == 1 and not a.timed_only:
         # model-only rate = the reference's own timing window (test.py:399-402): KNN pyramids pre-built and passed in
         e0 = eng.engines[0] if hasattr(eng, "engines") else eng
         half = (P + 1) // 2
