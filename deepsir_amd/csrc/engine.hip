@@ -1208,6 +1208,19 @@ int dsir_icp_refine(dsir_ctx* c, const float* points_src, const float* points_re
   return post(c);
 }
 
+int dsir_pose_finetune(dsir_ctx* c, const float* xyz_src, const float* xyz_ref, const float* weights, int weights_are_logits,
+                       int pairs, int m, const float* T_init, float quantization_size, int max_iter, float break_threshold_ratio,
+                       int max_break_count, float* T_out, double* stats) {
+  if (!c) return 1;
+  if (!xyz_src || !xyz_ref || !T_init || !T_out || pairs < 1 || m < 1 || max_iter < 0 || max_break_count < 1 ||
+      !(quantization_size > 0.f) || !(break_threshold_ratio >= 0.f))
+    return fail(c, "dsir_pose_finetune: bad arguments");
+  HIP_OK(c, hipSetDevice(c->device));
+  launch_pose_finetune(xyz_src, xyz_ref, weights, weights_are_logits ? 1 : 0, pairs, m, T_init, quantization_size, max_iter,
+                       break_threshold_ratio, max_break_count, T_out, stats, c->stream);
+  return post(c);
+}
+
 int dsir_enable_graph(dsir_ctx* c, int enable) {
   if (!c) return 1;
   c->use_graph = enable != 0;

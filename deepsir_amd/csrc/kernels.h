@@ -221,6 +221,11 @@ void launch_icp_refine(const float* src, const float* ref, int pairs, int J, int
                        int max_iter, float rel_fitness, float rel_rmse, const float* T_init, float* T_out,
                        double* stats_out, void* scratch, hipStream_t st);
 
+// finetune.hip — Adam fine-tune of the pose on matched points (test.py:159-207), one workgroup per pair
+void launch_pose_finetune(const float* src, const float* ref, const float* w, int sigmoid, int pairs, int m, const float* T_init,
+                          float quant, int max_iter, float break_ratio, int max_break, float* T_out, double* stats,
+                          hipStream_t st);
+
 // pre-processing on ragged batches (preprocess.hip); return 0 on success
 size_t voxel_downsample_scratch_bytes(int64_t total, int clouds);
 int launch_voxel_downsample(const float* pts, const int64_t* offsets_host, int clouds, int stride, float voxel,

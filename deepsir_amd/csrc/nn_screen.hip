@@ -24,12 +24,15 @@
 //           approximate value.
 //
 // Error budget, in units of M = |a|^2 + |b|^2 (|a||b| <= M/2): representation 2^-22 per element (3 2^-22 M with the
-// dropped al.bl term); fp32 accumulation of the 64 exact fp16 products per term, pessimistically one ulp per step:
-// 2^-17 M after the factor 2; the reference's own fmaf chain 64 * 2^-24 * 2 |a||b| <= 2^-18 M; final roundings 2^-22 M:
-// < 2^-15.6 M against 2^-15 M (measured on unit descriptors: 7e-7 against 6e-5).  Elements below 2^-25 lose their low part
+// dropped al.bl term); fp32 accumulation: the kernel forms z' = 2^11 (c + ah.bh) + ah.bl + al.bh in ONE chain of six
+// MFMAs (192 exact fp16 products + the seed), pessimistically one fp32 rounding per addition relative to the sum of the
+// magnitudes 2^11 (|a||b| + |b|^2 / 2) <= 2^11 M: 198 2^-24 M on z, 2^-15.4 M after the factor 2; the reference's own
+// fmaf chain 64 * 2^-24 * 2 |a||b| <= 2^-18 M; final roundings 2^-22 M: 2.8e-5 M against 2^-15 M = 3.05e-5 M (measured on
+// unit descriptors: < 1e-6 against 6e-5).  Elements below 2^-25 lose their low part
 // (fp16 underflow): <= 2^-25 per element, 2^-21 (|a| + |b|) <= 2^-21 (1 + M/2) on the distance: the constant term 2^-20.
-// Elements beyond the fp16 range (|x| > 2^15) or not finite: split16_kernel raises a flag and every pair is searched
-// exhaustively (the engine's descriptors are L2-normalised, model.py:232-233, and never take that path).
+// Elements with |x| > 16 (the 2^11 pre-scaling of the high part must stay inside fp16) or not finite: split16_kernel
+// raises a flag and every pair is searched exhaustively (the engine's descriptors are L2-normalised, model.py:232-233,
+// and never take that path).
 #include <hip/hip_fp16.h>
 #include <cstdio>
 #include <cstdlib>
@@ -70,10 +73,10 @@ __device__ __forceinline__ float unorder_bits(unsigned int b) {
 }
 
 // four channels fp32 -> fp16 high / low parts (see the header); *bad is raised when one of them is outside the domain of
-// the error bound (|x| > 2^15 or not finite)
+// the error bound (|x| > 16 or not finite)
 __device__ __forceinline__ void split4(const float4 v, h4& h, h4& l, int32_t* __restrict__ bad) {
   const float f[4] = {v.x, v.y, v.z, v.w};
-  if (bad && !(fmaxf(fmaxf(fabsf(f[0]), fabsf(f[1])), fmaxf(fabsf(f[2]), fabsf(f[3]))) <= 32768.f &&
+  if (bad && !(fmaxf(fmaxf(fabsf(f[0]), fabsf(f[1])), fmaxf(fabsf(f[2]), fabsf(f[3]))) <= 16.f &&
                f[0] == f[0] && f[1] == f[1] && f[2] == f[2] && f[3] == f[3]))
     *bad = 1;
 #pragma unroll
@@ -114,15 +117,27 @@ __global__ __launch_bounds__(256) void split_norm_kernel(const float* __restrict
   if (l == 0) sq[row] = s;
 }
 
-// Block = NWV waves, wave w owns RT row tiles of 16 src rows whose fp16 fragments stay in registers; ref tiles of 64
+// Block = NWV waves, wave w owns RT row tiles of 16 src rows whose fp16 fragments stay in registers; ref tiles of SBC
 // columns stream through double-buffered LDS (fetched two tiles ahead through registers).  XCD-aware work mapping as in
-// nn_match.hip.  Software pipelined: the accumulators of a 16-column step are ranked (z = hh + 2^-11 mx; the lane's two
-// largest z and the column of the largest; L = |a|^2_low - 2 z) while the MFMAs of the next step run.  One workgroup of
-// 8 waves per CU (194 VGPRs): measured equal to two workgroups of a leaner, unpipelined variant on its own, and better
-// when other streams share the GPU.
+// nn_match.hip.
+//
+// ONE accumulator chain per row tile: the high part of the src fragment is pre-scaled by 2^11 (exact in fp16 for
+// |x| <= 16, which split4 enforces), so z' = 2^11 (c + ah.bh) + (ah.bl + al.bh) = 2^11 z comes out of six chained MFMAs
+// whose first C operand is 2^11 c, c = -(|b|^2 - d_b) / 2 from LDS: no VALU instruction joins the partial products.
+// Ranking, per accumulator element, exactly four VALU instructions (v_med3_f32, v_cmp_gt_f32, v_cndmask_b32, v_max_f32;
+// inline asm, so no canonicalising v_max x, x and no re-association).  gfx950 overlaps a wave's VALU work with the matrix
+// pipe only marginally (tools/ubench/rank_overlap.hip: clustered, interleaved and role-staggered schedules all land within
+// 7 % of MFMA time + VALU time), so the levers are the instruction count and the exposed latencies: the ranking of step
+// t-1 and the LDS fragment reads of step t+1 are issued between the MFMAs of step t (order pinned with sched_barrier),
+// which takes the ds_read latency off the critical path.
 #ifndef DSIR_SCREEN_WPE
 #define DSIR_SCREEN_WPE 2
 #endif
+#define DSIR_FENCE() __builtin_amdgcn_sched_barrier(0)
+// (z1 >= z2: running top two of z, k1: column of z1)  <-  z at column col
+#define DSIR_RANK(z1, z2, k1, z, col)                                                                                         \
+  asm volatile("v_med3_f32 %1, %0, %1, %3\n\tv_cmp_gt_f32 vcc, %3, %0\n\tv_cndmask_b32 %2, %2, %4, vcc\n\tv_max_f32 %0, %0, %3" \
+               : "+v"(z1), "+v"(z2), "+v"(k1) : "v"(z), "v"(col) : "vcc")
 template <int RT, int NWV>
 __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(DSIR_SCREEN_WPE, DSIR_SCREEN_WPE))) void screen_kernel(const _Float16* __restrict__ Ah, const _Float16* __restrict__ Al,
                                                      const _Float16* __restrict__ Bh, const _Float16* __restrict__ Bl,
@@ -132,10 +147,11 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(DSIR_S
                                                      int2* __restrict__ cand, int32_t* __restrict__ ovf,
                                                      int32_t* __restrict__ rowlist, int ovf_min) {
   constexpr int NP = SBC * 8 / (NWV * 64);          // 16-byte pieces of each tile part per thread
-  static_assert(NP >= 1 && NP * NWV * 64 == SBC * 8 && NWV * 64 % (4 * SBC) == 0, "staging layout");
+  static_assert(NP >= 1 && NP * NWV * 64 == SBC * 8, "staging layout");
+  constexpr int NSB = SBC * 4 / (NWV * 64) > 0 ? SBC * 4 / (NWV * 64) : 1;   // replicated accumulator seeds per thread
+  static_assert(SBC * 4 <= NWV * 64 * NSB, "seed layout");
   __shared__ _Float16 Bs[2][2][SBC * SRS];          // [buffer][high | low part]
-  __shared__ float4 sbs[2][NWV * 16];               // -(|b|^2 - d_b) / 2, replicated: the MFMA accumulators start from it
-                                                    // (one float per thread, no branch in the loop body)
+  __shared__ float4 sbs[2][SBC];                    // 2^11 c, c = -(|b|^2 - d_b) / 2, replicated x4: the first MFMA's C operand
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fq = lane >> 4;
   const int nwg = gridDim.x, id = blockIdx.x;
@@ -154,8 +170,8 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(DSIR_S
   __syncthreads();
   if (s_skip) return;
 
-  // A fragments: lane holds row fr, channels 32 c + 8 fq .. +7
-  h8 ah[RT][2], al[RT][2];
+  // A fragments: lane holds row fr, channels 32 c + 8 fq .. +7; ahs = 2^11 ah (exact: |ah| <= 16)
+  h8 ahs[RT][2], ah[RT][2], al[RT][2];
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
     const int row = min(row0 + rt * 16 + fr, J - 1);
@@ -163,9 +179,11 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(DSIR_S
     for (int c = 0; c < 2; ++c) {
       ah[rt][c] = *reinterpret_cast<const h8*>(Ah + (arow + row) * 64 + 32 * c + 8 * fq);
       al[rt][c] = *reinterpret_cast<const h8*>(Al + (arow + row) * 64 + 32 * c + 8 * fq);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) ahs[rt][c][i] = ah[rt][c][i] * (_Float16)2048.f;
     }
   }
-  // per C element (row 4 fq + r of tile rt, column class fr): the two largest z and the column of the largest
+  // per C element (row 4 fq + r of tile rt, column class fr): the two largest z' and the column of the largest
   float z1[RT][4], z2[RT][4];
   int k1[RT][4];
 #pragma unroll
@@ -175,10 +193,10 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(DSIR_S
 
   const int c_begin = split * cols_per_split;
   const int c_end = min(K, c_begin + cols_per_split);
-  // staging: thread -> 16-byte piece (8 channels) of the tile: column tid >> 3, piece tid & 7
+  // staging: thread -> 16-byte piece (8 channels) of the tile: column f >> 3, piece f & 7
   // two register sets: a tile is fetched two iterations before it is needed (the L2 / MALL latency under load exceeds
   // the time of one tile) and written to the free LDS buffer at the end of the iteration before
-  struct Pre { h8 h[NP], l[NP]; float sb; };
+  struct Pre { h8 h[NP], l[NP]; float sb[NSB]; };
   Pre preA, preB;
   auto gload = [&](Pre& pre, int c0) {
 #pragma unroll
@@ -188,9 +206,13 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(DSIR_S
       pre.h[i] = *reinterpret_cast<const h8*>(Bh + (brow + r) * 64 + 8 * (f & 7));
       pre.l[i] = *reinterpret_cast<const h8*>(Bl + (brow + r) * 64 + 8 * (f & 7));
     }
-    const int col = c0 + ((tid >> 2) & (SBC - 1));
-    const float s = sb[brow + min(col, K - 1)];
-    pre.sb = col < c_end ? -0.5f * (s - kC1 * s) : -INFINITY;   // columns past the range never win
+#pragma unroll
+    for (int i = 0; i < NSB; ++i) {
+      const int f = tid + NWV * 64 * i;
+      const int col = c0 + (f >> 2);
+      const float s = sb[brow + min(col, K - 1)];
+      pre.sb[i] = (col < c_end && f < SBC * 4) ? -1024.f * (s - kC1 * s) : -INFINITY;   // columns past the range never win
+    }
   };
   auto lstore = [&](const Pre& pre, int buf) {
 #pragma unroll
@@ -199,74 +221,80 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(DSIR_S
       *reinterpret_cast<h8*>(&Bs[buf][0][(f >> 3) * SRS + 8 * (f & 7)]) = pre.h[i];
       *reinterpret_cast<h8*>(&Bs[buf][1][(f >> 3) * SRS + 8 * (f & 7)]) = pre.l[i];
     }
-    reinterpret_cast<float*>(sbs[buf])[tid] = pre.sb;
+#pragma unroll
+    for (int i = 0; i < NSB; ++i) {
+      const int f = tid + NWV * 64 * i;
+      if (f < SBC * 4) reinterpret_cast<float*>(sbs[buf])[f] = pre.sb[i];
+    }
   };
-  f32x4 hhP[RT], mxP[RT];
+  // fragments of one 16-column step: lane holds column fr of the step, channels 8 fq .. (+32)
+  struct Frag { h8 bh0, bh1, bl0, bl1; f32x4 cin; };
+  f32x4 zP[RT];
   int colP = 0;
 #pragma unroll
-  for (int rt = 0; rt < RT; ++rt) {
-    hhP[rt] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-    mxP[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-  // ranking of the pending accumulators: independent of the MFMAs of the running step, so the compiler's scheduler is
-  // free to issue it in their shadow
-  auto rank = [&]() {
+  for (int rt = 0; rt < RT; ++rt) zP[rt] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#define DSIR_MFMA(acc, a, b, c) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
+  // one step: the six MFMAs per row tile on `cur`, between them the ranking of the previous step's accumulators (zP) and
+  // the fragment reads of the next step (`nxt`; skipped when !more)
+  auto step = [&](const Frag& cur, Frag& nxt, const _Float16* bhp, const _Float16* blp, const float4* cp, bool more, int col) {
+    f32x4 zN[RT];
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
+    for (int rt = 0; rt < RT; ++rt) DSIR_MFMA(zN[rt], ahs[rt][0], cur.bh0, cur.cin);
+    if (more) { nxt.bh0 = *reinterpret_cast<const h8*>(bhp); const float4 v = *cp; nxt.cin = f32x4{v.x, v.y, v.z, v.w}; }
+    DSIR_FENCE();
+    DSIR_RANK(z1[0][0], z2[0][0], k1[0][0], zP[0][0], colP);
+    if (RT > 1) DSIR_RANK(z1[RT - 1][0], z2[RT - 1][0], k1[RT - 1][0], zP[RT - 1][0], colP);
+    DSIR_FENCE();
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float z = fmaf(mxP[rt][r], 4.8828125e-4f, hhP[rt][r]);
-        z2[rt][r] = __builtin_amdgcn_fmed3f(z1[rt][r], z2[rt][r], z);   // z1 >= z2: the median is the new runner-up
-        k1[rt][r] = z > z1[rt][r] ? colP : k1[rt][r];
-        z1[rt][r] = fmaxf(z1[rt][r], z);
-      }
+    for (int rt = 0; rt < RT; ++rt) DSIR_MFMA(zN[rt], ahs[rt][1], cur.bh1, zN[rt]);
+    if (more) nxt.bl0 = *reinterpret_cast<const h8*>(blp);
+    DSIR_FENCE();
+    DSIR_RANK(z1[0][1], z2[0][1], k1[0][1], zP[0][1], colP);
+    if (RT > 1) DSIR_RANK(z1[RT - 1][1], z2[RT - 1][1], k1[RT - 1][1], zP[RT - 1][1], colP);
+    DSIR_FENCE();
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) DSIR_MFMA(zN[rt], ah[rt][0], cur.bl0, zN[rt]);
+    if (more) nxt.bh1 = *reinterpret_cast<const h8*>(bhp + 32);
+    DSIR_FENCE();
+    DSIR_RANK(z1[0][2], z2[0][2], k1[0][2], zP[0][2], colP);
+    if (RT > 1) DSIR_RANK(z1[RT - 1][2], z2[RT - 1][2], k1[RT - 1][2], zP[RT - 1][2], colP);
+    DSIR_FENCE();
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) DSIR_MFMA(zN[rt], al[rt][0], cur.bh0, zN[rt]);
+    if (more) nxt.bl1 = *reinterpret_cast<const h8*>(blp + 32);
+    DSIR_FENCE();
+    DSIR_RANK(z1[0][3], z2[0][3], k1[0][3], zP[0][3], colP);
+    if (RT > 1) DSIR_RANK(z1[RT - 1][3], z2[RT - 1][3], k1[RT - 1][3], zP[RT - 1][3], colP);
+    DSIR_FENCE();
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) DSIR_MFMA(zN[rt], ah[rt][1], cur.bl1, zN[rt]);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) DSIR_MFMA(zN[rt], al[rt][1], cur.bh1, zN[rt]);
+    DSIR_FENCE();
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) zP[rt] = zN[rt];
+    colP = col;
   };
+  static_assert(RT <= 2, "the ranking slots above cover two row tiles");
   // one tile: ranks into (z1, z2, k1); `pre` holds the tile after it and is refilled with the one two further on
   auto tile = [&](int c0, int buf, Pre& pre) {
     const _Float16* bhp = &Bs[buf][0][fr * SRS + 8 * fq];
     const _Float16* blp = &Bs[buf][1][fr * SRS + 8 * fq];
-    h8 bh0, bh1, bl0, bl1;
-    f32x4 cin;
-    // fragment loads of step t (each register is reloaded for the next step right after its last use)
-    auto ld_bh0 = [&](int t) { bh0 = *reinterpret_cast<const h8*>(bhp + 16 * t * SRS); };
-    auto ld_bh1 = [&](int t) { bh1 = *reinterpret_cast<const h8*>(bhp + 16 * t * SRS + 32); };
-    auto ld_bl0 = [&](int t) { bl0 = *reinterpret_cast<const h8*>(blp + 16 * t * SRS); };
-    auto ld_bl1 = [&](int t) { bl1 = *reinterpret_cast<const h8*>(blp + 16 * t * SRS + 32); };
-    auto ld_cin = [&](int t) { const float4 v = sbs[buf][16 * t + fr]; cin = f32x4{v.x, v.y, v.z, v.w}; };
-    ld_bh0(0); ld_cin(0); ld_bl0(0); ld_bh1(0); ld_bl1(0);
+    const float4* cp = &sbs[buf][fr];
+    Frag fa, fb;
+    fa.bh0 = *reinterpret_cast<const h8*>(bhp); fa.bh1 = *reinterpret_cast<const h8*>(bhp + 32);
+    fa.bl0 = *reinterpret_cast<const h8*>(blp); fa.bl1 = *reinterpret_cast<const h8*>(blp + 32);
+    { const float4 v = *cp; fa.cin = f32x4{v.x, v.y, v.z, v.w}; }
 #pragma unroll
-    for (int t = 0; t < SBC / 16; ++t) {
-      const bool more = t + 1 < SBC / 16;
-      f32x4 hhN[RT], mxN[RT];
-      const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
-#define DSIR_MFMA(acc, a, b, c) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt) DSIR_MFMA(hhN[rt], ah[rt][0], bh0, cin);
-      if (more) ld_cin(t + 1);
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt) DSIR_MFMA(mxN[rt], ah[rt][0], bl0, zero);
-      if (more) ld_bl0(t + 1);
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt) DSIR_MFMA(hhN[rt], ah[rt][1], bh1, hhN[rt]);
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt) DSIR_MFMA(mxN[rt], al[rt][0], bh0, mxN[rt]);
-      if (more) ld_bh0(t + 1);
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt) DSIR_MFMA(mxN[rt], ah[rt][1], bl1, mxN[rt]);
-      if (more) ld_bl1(t + 1);
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt) DSIR_MFMA(mxN[rt], al[rt][1], bh1, mxN[rt]);
-      if (more) ld_bh1(t + 1);
-#undef DSIR_MFMA
-      rank();
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt) { hhP[rt] = hhN[rt]; mxP[rt] = mxN[rt]; }
-      colP = c0 + 16 * t + fr;
+    for (int t = 0; t < SBC / 16; t += 2) {
+      step(fa, fb, bhp + 16 * (t + 1) * SRS, blp + 16 * (t + 1) * SRS, cp + 16 * (t + 1), true, c0 + 16 * t + fr);
+      step(fb, fa, bhp + 16 * (t + 2) * SRS, blp + 16 * (t + 2) * SRS, cp + 16 * (t + 2), t + 2 < SBC / 16, c0 + 16 * (t + 1) + fr);
     }
     lstore(pre, buf ^ 1);
     gload(pre, c0 + 3 * SBC);                         // clamped addresses: harmless past the range
     __syncthreads();
   };
+#undef DSIR_MFMA
   gload(preA, c_begin);
   lstore(preA, 0);
   gload(preA, c_begin + SBC);
@@ -276,7 +304,11 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(DSIR_S
     tile(c0, 0, preA);
     if (c0 + SBC < c_end) tile(c0 + SBC, 1, preB);
   }
-  rank();
+  // the last step's accumulators
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) DSIR_RANK(z1[rt][r], z2[rt][r], k1[rt][r], zP[rt][r], colP);
 
   // T = min over the lanes of (their smallest lower bound + its bound width) >= min_k D(row, k) over this block's
   // columns, hence over all columns.  Every column of the block with lower bound <= T is either some lane's smallest
@@ -289,7 +321,8 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(DSIR_S
       const int rr = min(row, J - 1);
       const float san = sa[arow + rr];
       const float slo = san - kC1 * san - kC0;       // |a|^2 - d_a
-      const float l1 = fmaf(z1[rt][r], -2.f, slo), l2 = fmaf(z2[rt][r], -2.f, slo);
+      // z' = 2^11 z: L = slo - 2 z = slo - 2^-10 z'
+      const float l1 = fmaf(z1[rt][r], -9.765625e-4f, slo), l2 = fmaf(z2[rt][r], -9.765625e-4f, slo);
       const int k = k1[rt][r];
       float u = INFINITY;
       if (k >= 0) u = l1 + kW * (kC1 * (san + sb[brow + k]) + kC0);
@@ -488,7 +521,10 @@ void launch_nn_screen(const float* a, const float* b, const void* ah, const void
                        packed, (int64_t)rows);
   }
   constexpr int RT = DSIR_SCREEN_RT;
-  constexpr int NWV = 8;   // waves per block: 8 x 32 rows share one staged ref tile (the L2 -> LDS fill is the scarce resource)
+#ifndef DSIR_SCREEN_NWV
+#define DSIR_SCREEN_NWV 8
+#endif
+  constexpr int NWV = DSIR_SCREEN_NWV;   // waves per block: 8 x 32 rows share one staged ref tile (the L2 -> LDS fill is the scarce resource)
   const int rows_per_block = NWV * 16 * RT;
   const int rb_count = (J + rows_per_block - 1) / rows_per_block;
   const int64_t base = (int64_t)pairs * rb_count;

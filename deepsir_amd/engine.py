@@ -374,6 +374,30 @@ class Engine:
         self.sync()
         return T, stats
 
+    def pose_finetune(self, xyz_src, xyz_ref, T_init, weights=None, weights_are_logits: bool = False,
+                      quantization_size: float = 1.0, max_iter: int = 1000, break_threshold_ratio: float = 1e-4,
+                      max_break_count: int = 20):
+        """transformation_finetune counterpart for P pairs (reference test.py:159-207, disabled there).
+        xyz_src / xyz_ref [P,m,3] matched points, T_init [P,3,4], weights [P,m] or None
+        -> (T [P,3,4], stats [P,3] f64: iterations, loss, break_count)."""
+        xyz_src, xyz_ref = _chk(xyz_src, torch.float32, "xyz_src"), _chk(xyz_ref, torch.float32, "xyz_ref")
+        T_init = _chk(T_init, torch.float32, "T_init")
+        P, m, three = xyz_src.shape
+        if three != 3 or tuple(xyz_ref.shape) != (P, m, 3) or tuple(T_init.shape) != (P, 3, 4):
+            raise EngineError("pose_finetune: xyz_src / xyz_ref must be [P,m,3] and T_init [P,3,4]")
+        if weights is not None:
+            weights = _chk(weights.reshape(P, -1), torch.float32, "weights")
+            if weights.shape[1] != m:
+                raise EngineError("pose_finetune: weights must be [P,m]")
+        T = self._empty((P, 3, 4))
+        stats = self._empty((P, 3), torch.float64)
+        self._pre()
+        self._call(self.lib.dsir_pose_finetune(self.h, _ptr(xyz_src), _ptr(xyz_ref), _ptr(weights), 1 if weights_are_logits else 0,
+                                               P, m, _ptr(T_init), float(quantization_size), int(max_iter),
+                                               float(break_threshold_ratio), int(max_break_count), _ptr(T), _ptr(stats)))
+        self.sync()
+        return T, stats
+
     def enable_graph(self, on=True):
         """Replay dsir_register through a captured hipGraph (same buffers on every call)."""
         self._call(self.lib.dsir_enable_graph(self.h, 1 if on else 0))

@@ -128,7 +128,7 @@ int dsir_nn_match(dsir_ctx* ctx, const float* desc_src, const float* desc_ref, i
 /* The same arg-min as dsir_nn_match, bit for bit, the way dsir_register computes it: columns are first discarded by an
  * fp16-split MFMA screening with a rigorous error bound, the exact fp32 formula then decides among the survivors
  * (csrc/nn_screen.hip); rows the screening cannot decide are searched by the exhaustive fp32 kernel of dsir_nn_match.
- * Any finite input gives the exact result: components beyond the fp16 range (|x| > 2^15) or not finite switch the whole
+ * Any finite input gives the exact result: components outside the screening's domain (|x| > 16) or not finite switch the whole
  * call to the exhaustive kernel.
  * stats (HOST, optional): [0] = candidate entries emitted by the screening, [1] = rows left to the exhaustive kernel. */
 int dsir_nn_match_screened(dsir_ctx* ctx, const float* desc_src, const float* desc_ref, int pairs, int J, int K,
@@ -239,6 +239,20 @@ int dsir_eval_metrics(dsir_ctx* ctx, const float* pred_T, int64_t pred_stride, c
 int dsir_icp_refine(dsir_ctx* ctx, const float* points_src, const float* points_ref, int pairs, int J, int K, int stride,
                     float max_corr_dist, int max_iter, float rel_fitness, float rel_rmse, const float* T_init,
                     float* T_out, double* stats);
+
+/* Replaces the `use_tune` branch of pose_optimization (test.py:209-239): transformation_finetune (test.py:159-207) with
+ * HighDimSmoothL1Loss (test.py:103-131) over the network's last correspondences, the pose re-parametrised as
+ * network/DGR.py's Transformation (6-D rotation + translation, :60-132) and fitted by Adam (lr 0.1, ExponentialLR 0.999)
+ * until the loss is below 1e-7, max_iter steps are done, or the relative loss change was below break_threshold_ratio
+ * max_break_count times - for P pairs at once, each pair's whole optimisation inside one workgroup.
+ * xyz_src / xyz_ref [P][m][3] MATCHED points (endpoints['pt_src'] and 'pt_ref_new' = dsir_pair_result.pt_ref_new);
+ * weights [P][m] or NULL (unweighted mean); weights_are_logits != 0: sigmoid applied on the fly (perm_matrices[-1]);
+ * T_init / T_out [P][3][4]; stats [P][3] float64 {iterations, loss, break_count} (opt_result) or NULL.
+ * The branch is disabled in the reference (use_tune = False) and test.py / DGR.py cannot be imported offline (open3d):
+ * the rule is restated with the same torch calls in oracle/finetune.py (parity unpinned). */
+int dsir_pose_finetune(dsir_ctx* ctx, const float* xyz_src, const float* xyz_ref, const float* weights, int weights_are_logits,
+                       int pairs, int m, const float* T_init, float quantization_size, int max_iter, float break_threshold_ratio,
+                       int max_break_count, float* T_out, double* stats);
 
 /* Launch-bound small batches: capture the whole dsir_register launch sequence into a hipGraph once per
  * call signature (sizes and buffer addresses) and replay it.  Off by default. */
