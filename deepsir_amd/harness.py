@@ -51,10 +51,18 @@ def inference_align(pairs: Sequence[Dict[str, np.ndarray]], model, num_reg_iter:
             T_opt, _ = model._engine.icp_refine(data["points_src"].float(), data["points_ref"].float(),
                                                 transforms[-1].contiguous(), 2.0 * voxel_size)
             transforms.append(T_opt)
+        elif pose_opt == "tune":
+            # pose_optimization with use_tune (test.py:218-239; off in the reference): Adam fine-tune of the 6-D-rotation
+            # pose on the last iteration's correspondences, weights = sigmoid of its inlier logits, distances in units
+            # of 2 x voxel size (test.py:219, :238)
+            T_opt, _ = model._engine.pose_finetune(endpoints["pt_src"].float(), endpoints["pt_ref_new"].float(),
+                                                   transforms[-1].contiguous(), weights=endpoints["perm_matrices"][-1],
+                                                   weights_are_logits=True, quantization_size=2.0 * voxel_size)
+            transforms.append(T_opt)
         elif pose_opt is None:
             transforms.append(transforms[-1].detach())        # pose_optimization == identity (test.py:215-216, :406-408)
         else:
-            raise ValueError("pose_opt must be None or 'icp' (the Adam fine-tune branch, test.py:159-207, is not built)")
+            raise ValueError("pose_opt must be None, 'icp' or 'tune'")
         T = torch.stack(transforms, dim=1).cpu().numpy()      # [B, n_iter+1, 3, 4]
         preds.append(T)
         gt = data["transform_gt"].cpu().numpy()
