@@ -4,7 +4,7 @@
 //   desc = normalize(mlp_proj(F + g))    64 -> 64, L2 over channels           (F = mlp_feat(feat0): loop invariant, hoisted)
 // Unfused these are six launches whose 32..256-wide intermediates make a round trip through HBM (4.3 kB per point per
 // iteration) and whose K loops are only 1..8 chunks long, so prologue / epilogue dominate.  Here a block owns 128
-// points (4 waves x 2 row tiles of 16) and walks the whole chain:
+// points (4 waves x 2 row tiles of 16; 64 points with one row tile per wave when few clouds are in flight) and walks the whole chain:
 //   * activations never leave the CU: a layer's accumulators (C layout) are transposed through a wave-private LDS tile
 //     into the A fragments (registers) of the next layer; the 256-wide layer is produced 64 columns at a time and
 //     consumed immediately as one K chunk of the following 256 -> 64 layer;
@@ -23,6 +23,7 @@ namespace {
 constexpr int LDW = 66;   // weight tile row (floats): fragment reads (row r, k = 4 s + q) hit banks 2 r + q
 constexpr int LDT = 66;   // transposition tile row
 
+template <int RT>
 __global__ __launch_bounds__(256, 2) void agg_chain_kernel(const AggArgs p) {
   __shared__ float Ws[2][64 * LDW];
   __shared__ float Ts[4][2][16 * LDT];
@@ -30,7 +31,7 @@ __global__ __launch_bounds__(256, 2) void agg_chain_kernel(const AggArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fq = lane >> 4;
   const int cloud = blockIdx.y;
-  const int r0 = blockIdx.x * 128 + 32 * w;      // first row of this wave
+  const int r0 = blockIdx.x * (64 * RT) + 16 * RT * w;      // first row of this wave
 
   // ---- weight chunk schedule
   const int srow = tid >> 4, sk = (tid & 15) * 4;
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(256, 2) void agg_chain_kernel(const AggArgs p) {
 #pragma unroll
     for (int t = 0; t < 2; ++t) { w1[t] = p.W1[(16 * t + fr) * 4 + fq]; b1[t] = p.b1[16 * t + fr]; }
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
+    for (int rt = 0; rt < RT; ++rt) {
       const int row = min(r0 + 16 * rt + fr, p.n - 1);
       const float x = fq < 3 ? p.xyz[cloud * p.xyz_cs + (int64_t)row * 3 + fq] : p.score[(int64_t)cloud * p.n + row];
       const float a = fmaf(x, 1.f, 0.f);
@@ -118,24 +119,24 @@ __global__ __launch_bounds__(256, 2) void agg_chain_kernel(const AggArgs p) {
     }
     __builtin_amdgcn_wave_barrier();
   };
-  auto zero = [&](f32x4 (&acc)[2][4]) {
+  auto zero = [&](f32x4 (&acc)[RT][4]) {
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
       for (int t = 0; t < 4; ++t) acc[rt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
   };
 
   // ---- layer 2: 32 -> 64 (chunk 0), k order of pw_stream<8,...>: lane (r,q) holds channels [8q, 8q+8)
-  float a3[2][16];
+  float a3[RT][16];
   {
-    float a2[2][8];
+    float a2[RT][8];
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
+    for (int rt = 0; rt < RT; ++rt) {
       const float* T = rt ? T1 : T0;
 #pragma unroll
       for (int s = 0; s < 8; ++s) a2[rt][s] = T[fr * LDT + 8 * fq + s];
     }
-    f32x4 acc[2][4];
+    f32x4 acc[RT][4];
     zero(acc);
     const float* Wt = Ws[buf];
 #pragma unroll
@@ -144,12 +145,12 @@ __global__ __launch_bounds__(256, 2) void agg_chain_kernel(const AggArgs p) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) b[t] = Wt[(16 * t + fr) * LDW + 8 * fq + s];
 #pragma unroll
-      for (int rt = 0; rt < 2; ++rt)
+      for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[rt][s], b[t], acc[rt][t], 0, 0, 0);
     }
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
+    for (int rt = 0; rt < RT; ++rt) {
       float* T = rt ? T1 : T0;
       spill_act(T, acc[rt], p.b2, true);
 #pragma unroll
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(256, 2) void agg_chain_kernel(const AggArgs p) {
   }
 
   // one 64-column x 64-channel weight chunk against A fragments in natural order (k = k0 + 4 s + q)
-  auto mma64 = [&](f32x4 (&acc)[2][4], const float (&a0)[16], const float (&a1)[16]) {
+  auto mma64 = [&](f32x4 (&acc)[RT][4], const float (&a0)[16], const float (&a1)[16]) {
     const float* Wt = Ws[buf];
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
@@ -168,8 +169,10 @@ __global__ __launch_bounds__(256, 2) void agg_chain_kernel(const AggArgs p) {
       for (int t = 0; t < 4; ++t) b[t] = Wt[(16 * t + fr) * LDW + 4 * s + fq];
 #pragma unroll
       for (int t = 0; t < 4; ++t) acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s], b[t], acc[0][t], 0, 0, 0);
+      if (RT > 1) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s], b[t], acc[1][t], 0, 0, 0);
+        for (int t = 0; t < 4; ++t) acc[RT - 1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s], b[t], acc[RT - 1][t], 0, 0, 0);
+      }
     }
   };
   auto read_nat = [&](const float* T, float (&a)[16]) {
@@ -178,14 +181,14 @@ __global__ __launch_bounds__(256, 2) void agg_chain_kernel(const AggArgs p) {
   };
 
   // ---- layer 3: 64 -> 128 (chunks 1, 2 = column halves); its output is layer 4's A operand (2 x 16 regs per row tile)
-  float a4[2][2][16];   // [row tile][k half][s]
+  float a4[RT][2][16];   // [row tile][k half][s]
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
-    f32x4 acc[2][4];
+    f32x4 acc[RT][4];
     zero(acc);
-    mma64(acc, a3[0], a3[1]);
+    mma64(acc, a3[0], a3[RT - 1]);
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
+    for (int rt = 0; rt < RT; ++rt) {
       float* T = rt ? T1 : T0;
       spill_act(T, acc[rt], p.b3 + 64 * c, true);
       read_nat(T, a4[rt][c]);
@@ -194,19 +197,19 @@ __global__ __launch_bounds__(256, 2) void agg_chain_kernel(const AggArgs p) {
   }
 
   // ---- layers 4 + 5 interleaved: column chunk j of 128 -> 256 (two K chunks), activated, becomes K chunk j of 256 -> 64
-  f32x4 acc5[2][4];
+  f32x4 acc5[RT][4];
   zero(acc5);
-  float fres[2][4][4];
+  float fres[RT][4][4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    f32x4 acc[2][4];
+    f32x4 acc[RT][4];
     zero(acc);
-    mma64(acc, a4[0][0], a4[1][0]);
+    mma64(acc, a4[0][0], a4[RT - 1][0]);
     next_chunk();
-    mma64(acc, a4[0][1], a4[1][1]);
-    float a5[2][16];
+    mma64(acc, a4[0][1], a4[RT - 1][1]);
+    float a5[RT][16];
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
+    for (int rt = 0; rt < RT; ++rt) {
       float* T = rt ? T1 : T0;
       spill_act(T, acc[rt], p.b4 + 64 * j, true);
       read_nat(T, a5[rt]);
@@ -215,7 +218,7 @@ __global__ __launch_bounds__(256, 2) void agg_chain_kernel(const AggArgs p) {
     if (j == 3) {
       // the residual F rows (C layout) land while the last K chunk of layer 5 runs
 #pragma unroll
-      for (int rt = 0; rt < 2; ++rt)
+      for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = min(r0 + 16 * rt + 4 * fq + r, p.n - 1);
@@ -224,15 +227,15 @@ __global__ __launch_bounds__(256, 2) void agg_chain_kernel(const AggArgs p) {
           for (int t = 0; t < 4; ++t) fres[rt][t][r] = f[16 * t];
         }
     }
-    mma64(acc5, a5[0], a5[1]);
+    mma64(acc5, a5[0], a5[RT - 1]);
     next_chunk();
   }
 
   // ---- layer 5 epilogue (bias, + F) -> layer 6 (mlp_proj, k order of pw_stream<16,...>) -> L2 normalise -> store
   {
-    float a6[2][16];
+    float a6[RT][16];
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
+    for (int rt = 0; rt < RT; ++rt) {
       float* T = rt ? T1 : T0;
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -249,7 +252,7 @@ __global__ __launch_bounds__(256, 2) void agg_chain_kernel(const AggArgs p) {
 #pragma unroll
       for (int s = 0; s < 16; ++s) a6[rt][s] = T[fr * LDT + 16 * fq + s];
     }
-    f32x4 acc[2][4];
+    f32x4 acc[RT][4];
     zero(acc);
     const float* Wt = Ws[buf];
 #pragma unroll
@@ -258,7 +261,7 @@ __global__ __launch_bounds__(256, 2) void agg_chain_kernel(const AggArgs p) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) b[t] = Wt[(16 * t + fr) * LDW + 16 * fq + s];
 #pragma unroll
-      for (int rt = 0; rt < 2; ++rt)
+      for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a6[rt][s], b[t], acc[rt][t], 0, 0, 0);
     }
@@ -267,7 +270,7 @@ __global__ __launch_bounds__(256, 2) void agg_chain_kernel(const AggArgs p) {
     for (int t = 0; t < 4; ++t) bv[t] = p.b6[16 * t + fr];
     float* Y = p.desc + (int64_t)cloud * p.n * 64;
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
+    for (int rt = 0; rt < RT; ++rt) {
       float ss[4] = {0.f, 0.f, 0.f, 0.f};
       float v[4][4];
 #pragma unroll
@@ -296,8 +299,16 @@ __global__ __launch_bounds__(256, 2) void agg_chain_kernel(const AggArgs p) {
 
 bool launch_agg_chain(const AggArgs& a, hipStream_t st) {
   if (a.n <= 0 || a.clouds <= 0) return true;
-  dim3 grid((a.n + 127) / 128, a.clouds);
-  hipLaunchKernelGGL(agg_chain_kernel, grid, dim3(256), 0, st, a);
+  // every point's chain is independent of the blocking, so the rows per workgroup follow the launch size: 128 (two row
+  // tiles per wave, weights re-read once per 128 points) when that already fills the chip, 64 for a few clouds in flight
+  // (batch-1 latency: twice the workgroups, half the chain per wave) - same bits either way
+  if ((int64_t)((a.n + 127) / 128) * a.clouds >= 256) {
+    dim3 grid((a.n + 127) / 128, a.clouds);
+    hipLaunchKernelGGL(agg_chain_kernel<2>, grid, dim3(256), 0, st, a);
+  } else {
+    dim3 grid((a.n + 63) / 64, a.clouds);
+    hipLaunchKernelGGL(agg_chain_kernel<1>, grid, dim3(256), 0, st, a);
+  }
   return true;
 }
 

@@ -487,6 +487,17 @@ void launch_s(const GemmArgs& a, hipStream_t st) {
     blocks = want < most ? want : most;
   }
   if (blocks < 1) blocks = 1;
+  // Epilogues without a cross-workgroup reduction (everything but the GroupNorm statistics) give the same bits under any
+  // tile -> wave assignment, so their grid may follow the launch size: with one or two clouds in flight (batch-1 latency)
+  // a cloud spreads over enough workgroups to reach ~2 per CU; with many clouds nothing changes.
+  if (EPI != EPI_GN) {
+    const int64_t total = (int64_t)blocks * gy * a.clouds;
+    if (total < 512) {
+      const int want = (int)((512 + (int64_t)gy * a.clouds - 1) / ((int64_t)gy * a.clouds)), most = (ntiles + 3) / 4;
+      const int nb = want < most ? want : most;
+      if (nb > blocks) blocks = nb;
+    }
+  }
   GemmArgs b = a;
   b.grid_x = blocks; b.grid_y = gy;
   dim3 grid((unsigned)((int64_t)blocks * gy * a.clouds));

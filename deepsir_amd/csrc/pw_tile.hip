@@ -15,6 +15,7 @@
 // bias + LeakyReLU, linear (+residual), attentive pooling — as in pw_gemm.hip.
 #include "kernels.h"
 #include "device_utils.h"
+#include <cstdlib>
 
 namespace dsir {
 
@@ -346,6 +347,153 @@ __global__ __launch_bounds__(256) void pw_tile_kernel(const GemmArgs p) {
   }
 }
 
+// Small-M variant (per-cloud layers of the deep pyramid levels: M = 312 / 78 / 19 rows at N = 5000): block tile
+// 32 rows x 64 columns, the four waves arranged 2 x 2 (wave = 16 rows x 32 columns), same 32-channel K chunks, same
+// staging, same k order - every output element is the same fmaf chain as in pw_tile_kernel, bit for bit.  A wave's MFMA
+// chain is 4 x shorter (K/2 instead of 2 K for RT = 2), a cloud spreads over 4-8 x more workgroups, and the row padding
+// drops from 64-128 to 32 rows (M = 78: 64 % -> 23 %; M = 19: 237 % -> 68 %).  Price: a weight tile is re-read from L2
+// once per 32 rows.  GroupNorm statistics: fp32 per column tile and wave, fp64 atomics.
+template <int EPI>
+__global__ __launch_bounds__(256) void pw_tile_small_kernel(const GemmArgs p) {
+  constexpr int BM = 32, NTW = 2;
+  __shared__ float As[2][BM * LDS_LD];
+  __shared__ float Ws[2][BN * LDS_LD];
+  __shared__ float s_sc[MAXC];
+  __shared__ float s_sh[MAXC];
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = w & 1, wc = w >> 1;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int cloud = blockIdx.z;
+  const int m0 = blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+
+  for (int c = tid; c < p.Cin; c += 256) {
+    const Seg& s = (c < p.seg[0].C) ? p.seg[0] : p.seg[1];
+    const int lc = (c < p.seg[0].C) ? c : c - p.seg[0].C;
+    float scale = 1.f, shift = 0.f;
+    if (s.gn.stats) {
+      const int g = lc / (s.C / s.gn.groups);
+      const double* st = s.gn.stats + ((int64_t)cloud * s.gn.groups + g) * 2;
+      const double mean = st[0] * s.gn.inv_count;
+      double var = st[1] * s.gn.inv_count - mean * mean;
+      var = var > 0.0 ? var : 0.0;
+      const double rstd = 1.0 / sqrt(var + 1e-5);
+      const double scd = (double)s.gn.gamma[lc] * rstd;
+      scale = (float)scd;
+      shift = (float)((double)s.gn.beta[lc] - mean * scd);
+    }
+    s_sc[c] = scale;
+    s_sh[c] = shift;
+  }
+  // staging: thread -> 4 consecutive channels (tid & 7) of A row (tid >> 3) and of W rows (tid >> 3), (tid >> 3) + 32
+  const int c4 = (tid & 7) * 4;
+  const int sr0 = tid >> 3;
+  const RowOff ro = row_off(p, cloud, min(m0 + sr0, p.M - 1));
+  const float* wrow[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int col = min(n0 + sr0 + 32 * i, p.Cout - 1);
+    wrow[i] = p.W + (int64_t)col * (p.ldw ? p.ldw : p.Cin) + c4;
+  }
+  const int C0 = p.seg[0].C;
+  const int act0 = p.seg[0].act, act1 = p.nseg > 1 ? p.seg[1].act : 0;
+  __syncthreads();
+
+  float4 ra, rw[2];
+  auto gload = [&](int k0) {
+    const int c = k0 + c4;
+    const bool s1 = c >= C0;
+    const float* base = s1 ? p.seg[1].x : p.seg[0].x;
+    ra = *reinterpret_cast<const float4*>(base + (s1 ? ro.o1 : ro.o0) + (s1 ? c - C0 : c));
+#pragma unroll
+    for (int i = 0; i < 2; ++i) rw[i] = *reinterpret_cast<const float4*>(wrow[i] + k0);
+  };
+  auto lstore = [&](int k0, int buf) {
+    const int c = k0 + c4;
+    const float slope = ((c >= C0) ? act1 : act0) ? 0.2f : 1.f;
+    const float4 sc = *reinterpret_cast<const float4*>(&s_sc[c]);
+    const float4 sh = *reinterpret_cast<const float4*>(&s_sh[c]);
+    float4 v = ra;
+    v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y); v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+    v.x = fmaxf(v.x, slope * v.x); v.y = fmaxf(v.y, slope * v.y);
+    v.z = fmaxf(v.z, slope * v.z); v.w = fmaxf(v.w, slope * v.w);
+    float2* d = reinterpret_cast<float2*>(&As[buf][sr0 * LDS_LD + c4]);
+    d[0] = make_float2(v.x, v.y);
+    d[1] = make_float2(v.z, v.w);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float2* dw = reinterpret_cast<float2*>(&Ws[buf][(sr0 + 32 * i) * LDS_LD + c4]);
+      dw[0] = make_float2(rw[i].x, rw[i].y);
+      dw[1] = make_float2(rw[i].z, rw[i].w);
+    }
+  };
+  f32x4 acc[NTW];
+#pragma unroll
+  for (int t = 0; t < NTW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nchunks = p.Cin / BK;
+  gload(0);
+  lstore(0, 0);
+  __syncthreads();
+  int buf = 0;
+  for (int kc = 0; kc < nchunks; ++kc) {
+    const bool more = kc + 1 < nchunks;
+    if (more) gload((kc + 1) * BK);
+    const float* At = As[buf];
+    const float* Wt = Ws[buf];
+#pragma unroll
+    for (int s = 0; s < BK / 4; ++s) {
+      const float a = At[(16 * wr + fr) * LDS_LD + 4 * s + fq];
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) {
+        const float b = Wt[(16 * (NTW * wc + t) + fr) * LDS_LD + 4 * s + fq];
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[t], 0, 0, 0);
+      }
+    }
+    if (more) lstore((kc + 1) * BK, buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+  // ---- epilogue.  C layout: col = lane & 15, row = 4 * (lane >> 4) + reg.
+  const int r0 = m0 + 16 * wr;
+  float* Y = p.Y + cloud * p.y_cloud_stride;
+#pragma unroll
+  for (int t = 0; t < NTW; ++t) {
+    const int col = n0 + 16 * (NTW * wc + t) + fr;
+    const float bv = (p.bias && col < p.Cout) ? p.bias[col] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = r0 + 4 * fq + r;
+      if (row < p.M && col < p.Cout) {
+        float v = acc[t][r] + bv;
+        if (EPI == EPI_LINEAR && p.residual) v += p.residual[cloud * p.res_cloud_stride + (int64_t)row * p.ldres + col];
+        if (EPI == EPI_ACT && v < 0.f) v *= 0.2f;
+        Y[(int64_t)row * p.ldy + col] = v;
+        s1 += v;
+        s2 += v * v;
+      }
+    }
+    if (EPI == EPI_GN) {
+      const int gw = p.Cout / p.groups_out;     // 8, 16, 32 or 64 channels per group
+      const int lw = gw < 16 ? gw : 16;
+      s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
+      s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
+      for (int o = 1; o < lw; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+      if (fq == 0 && (fr % lw) == 0 && r0 < p.M && col < p.Cout) {
+        double* st = p.stats_out + ((int64_t)cloud * p.groups_out + col / gw) * 2;
+        atomicAdd(st, (double)s1);
+        atomicAdd(st + 1, (double)s2);
+      }
+    }
+  }
+}
+
+template <int EPI>
+void launch_small(const GemmArgs& a, hipStream_t st) {
+  dim3 grid((a.M + 31) / 32, (a.Cout + BN - 1) / BN, a.clouds);
+  hipLaunchKernelGGL((pw_tile_small_kernel<EPI>), grid, dim3(256), 0, st, a);
+}
+
 template <int RT, int EPI>
 void launch_t(const GemmArgs& a, hipStream_t st) {
   dim3 grid((a.M + 64 * RT - 1) / (64 * RT), (a.Cout + BN - 1) / BN, a.clouds);
@@ -379,7 +527,16 @@ bool launch_pw_tile(const GemmArgs& a, hipStream_t st) {
   if (!seg_ok(a.seg[0]) || (a.nseg > 1 && (!seg_ok(a.seg[1]) || (a.seg[0].C % 4) != 0))) return false;
   if ((reinterpret_cast<uintptr_t>(a.W) % 16) != 0) return false;
   if (a.epi == EPI_GN && ((a.Cout / a.groups_out) % 8) != 0) return false;
-  // rows per block: a function of M only (batch-invariant tiling); 128-row tiles unless they waste > 25 %
+  // rows per block: a function of M only (batch-invariant tiling)
+  static const int small_m = getenv("DSIR_TILE_SMALL_M") ? atoi(getenv("DSIR_TILE_SMALL_M")) : 320;   // tuning hook; 0 = off
+  if (a.M <= small_m && (a.epi == EPI_GN || a.epi == EPI_ACT || a.epi == EPI_LINEAR)) {
+    switch (a.epi) {
+      case EPI_GN: launch_small<EPI_GN>(a, st); return true;
+      case EPI_ACT: launch_small<EPI_ACT>(a, st); return true;
+      default: launch_small<EPI_LINEAR>(a, st); return true;
+    }
+  }
+  // 128-row tiles unless they waste > 25 %
   const int pad128 = ((a.M + 127) / 128) * 128, pad64 = ((a.M + 63) / 64) * 64;
   if (a.M >= 128 && pad128 * 3 <= pad64 * 4) return launch_e<2>(a, st);
   return launch_e<1>(a, st);
