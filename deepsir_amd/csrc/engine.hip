@@ -31,7 +31,7 @@ struct HostParam {
 };
 
 struct Mlp2dW { const float *W = nullptr, *b = nullptr, *gamma = nullptr, *beta = nullptr; int cin = 0, cout = 0, groups = 0; };
-struct AttW { const float* fc = nullptr; int d = 0; Mlp2dW mlp; };
+struct AttW { const float* fc = nullptr; const float* fc_g = nullptr; int d = 0; Mlp2dW mlp; };   // fc_g: see up_fc_g
 struct BlockW { Mlp2dW mlp1, lfa1, lfa2, mlp2, skip; AttW att1, att2; int d_in = 0, d = 0; };
 struct LinW { const float *W = nullptr, *b = nullptr; int cin = 0, cout = 0; };
 struct RandlaW { Mlp2dW pre; BlockW blk[4]; Mlp2dW mid; Mlp2dW dec[4]; const float* out_w = nullptr; int dec_out = 0; LinW fc[3]; int cin = 0, ncls = 0; };
@@ -257,9 +257,29 @@ LinOff up_lin(dsir_ctx* c, Uploader& u, const std::string& pre, int pos, bool bn
 }
 LinW bind_lin(const float* base, const LinOff& o) { LinW l; l.W = base + o.W; l.b = base + o.b; l.cin = o.cin; l.cout = o.cout; return l; }
 
+// Split attentive pooling (d >= 64): G = W1 f is consumed only by the pooling kernel, where lane (fr, fq) of a block needs
+// the gathered G values of its column in each of the block's four 16-column tiles.  W1 = fc[:, :d/2] is therefore uploaded
+// a second time with its rows permuted so that those four values are adjacent: G' column 64 b + 4 fr + t = the column of
+// tile t, lane fr of block b - one 16-byte gather instead of four 4-byte ones.  Which columns form tile t of block b is
+// the consumer's mapping: pw_stream.hip (d = 64, 128) pairs 32 columns of the gathered half with the matching 32 of the
+// enc half, pw_tile.hip (d = 256) takes 64 consecutive columns.
+size_t up_fc_g(Uploader& u, const HostParam& fc, int d) {
+  if (d < 64) return 0;
+  const int h = d / 2;
+  std::vector<float> w((size_t)d * h);
+  for (int b = 0; b < d / 64; ++b)
+    for (int fr = 0; fr < 16; ++fr)
+      for (int t = 0; t < 4; ++t) {
+        const int pos = 64 * b + 4 * fr + t;
+        const int src = d <= 128 ? (t < 2 ? 32 * b + 16 * t + fr : h + 32 * b + 16 * (t - 2) + fr) : 64 * b + 16 * t + fr;
+        for (int k = 0; k < h; ++k) w[(size_t)pos * h + k] = fc.data[(size_t)src * d + k];
+      }
+  return u.put(w);
+}
+
 struct RandlaOff {
   Mlp2dOff pre, mid, dec[4];
-  struct { Mlp2dOff mlp1, lfa1, lfa2, mlp2, skip, a1m, a2m; size_t fc1, fc2; } blk[4];
+  struct { Mlp2dOff mlp1, lfa1, lfa2, mlp2, skip, a1m, a2m; size_t fc1, fc2, fc1g, fc2g; } blk[4];
   size_t out_w; int dec_out;
   LinOff fc[3];
 };
@@ -271,9 +291,11 @@ RandlaOff up_randla(dsir_ctx* c, Uploader& u, const std::string& pre) {
     r.blk[i].mlp1 = up_mlp2d(c, u, p + ".mlp1");
     r.blk[i].lfa1 = up_mlp2d(c, u, p + ".lfa.mlp1");
     r.blk[i].fc1 = u.put(P(c, p + ".lfa.att_pooling_1.fc.weight").data);
+    r.blk[i].fc1g = up_fc_g(u, P(c, p + ".lfa.att_pooling_1.fc.weight"), c->cfg.d_out[i]);
     r.blk[i].a1m = up_mlp2d(c, u, p + ".lfa.att_pooling_1.mlp");
     r.blk[i].lfa2 = up_mlp2d(c, u, p + ".lfa.mlp2");
     r.blk[i].fc2 = u.put(P(c, p + ".lfa.att_pooling_2.fc.weight").data);
+    r.blk[i].fc2g = up_fc_g(u, P(c, p + ".lfa.att_pooling_2.fc.weight"), c->cfg.d_out[i]);
     r.blk[i].a2m = up_mlp2d(c, u, p + ".lfa.att_pooling_2.mlp");
     r.blk[i].mlp2 = up_mlp2d(c, u, p + ".mlp2");
     r.blk[i].skip = up_mlp2d(c, u, p + ".mlp_skip");
@@ -298,6 +320,8 @@ RandlaW bind_randla(const float* base, const RandlaOff& o, const dsir_cfg& g) {
     b.skip = bind_mlp2d(base, o.blk[i].skip);
     b.att1.fc = base + o.blk[i].fc1; b.att1.d = g.d_out[i]; b.att1.mlp = bind_mlp2d(base, o.blk[i].a1m);
     b.att2.fc = base + o.blk[i].fc2; b.att2.d = g.d_out[i]; b.att2.mlp = bind_mlp2d(base, o.blk[i].a2m);
+    b.att1.fc_g = g.d_out[i] >= 64 ? base + o.blk[i].fc1g : nullptr;
+    b.att2.fc_g = g.d_out[i] >= 64 ? base + o.blk[i].fc2g : nullptr;
     b.d = g.d_out[i]; b.d_in = b.mlp1.cin;
   }
   r.mid = bind_mlp2d(base, o.mid);
@@ -362,13 +386,13 @@ struct Sched {
     y.p = c->ws.get<float>((size_t)clouds * n * w.d);
     y.C = w.d; y.rows = n;
     static const bool no_att2 = getenv("DSIR_NO_ATT2") != nullptr;   // A/B switch
-    if (!no_att2 && w.d >= 64 && f.C * 2 == w.d && enc.C * 2 == w.d) {   // d = 16: the extra gathers cost more than the MFMAs saved
+    if (!no_att2 && w.d >= 64 && w.fc_g && f.C * 2 == w.d && enc.C * 2 == w.d) {   // d = 16: the extra gathers cost more than the MFMAs saved
       // score GEMM split by linearity: fc [gather(f); enc] = gather(W1 f) + W2 enc  (kernels.h, EPI_ATT2).
       // G = W1 f runs on n rows instead of 16 n; the pooling launch contracts only the enc half.
       float* G = c->ws.get<float>((size_t)clouds * n * w.d);
       GemmArgs g;
       g.amode = A_SEGS; g.nseg = 1; g.seg[0] = seg_of(f);
-      g.W = w.fc; g.ldw = w.d; g.bias = nullptr; g.Cin = w.d / 2; g.Cout = w.d; g.M = n; g.clouds = clouds;
+      g.W = w.fc_g; g.ldw = w.d / 2; g.bias = nullptr; g.Cin = w.d / 2; g.Cout = w.d; g.M = n; g.clouds = clouds;   // G in the consumer's column order (up_fc_g)
       g.epi = EPI_LINEAR; g.Y = G; g.y_cloud_stride = (int64_t)n * w.d; g.ldy = w.d;
       launch_pw_gemm(g, st);
       GemmArgs a2;
@@ -376,7 +400,8 @@ struct Sched {
       a2.W = w.fc + w.d / 2; a2.ldw = w.d; a2.bias = nullptr; a2.Cin = w.d / 2; a2.Cout = w.d; a2.M = n * kKnn;
       a2.clouds = clouds; a2.epi = EPI_ATT2; a2.Y = y.p; a2.y_cloud_stride = (int64_t)n * w.d; a2.ldy = w.d;
       a2.g = G; a2.g_cloud_stride = (int64_t)n * w.d; a2.fseg = seg_of(f, neigh, neigh_cs);
-      if (launch_pw_stream(a2, st) || launch_pw_tile(a2, st)) return y;
+      // G's column order is the consumer's (up_fc_g): d <= 128 belongs to pw_stream.hip, d = 256 to pw_tile.hip
+      if (w.d <= 128 ? launch_pw_stream(a2, st) : launch_pw_tile(a2, st)) return y;
     }
     GemmArgs a;
     a.amode = A_SEGS; a.nseg = 2;

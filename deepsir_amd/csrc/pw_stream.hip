@@ -277,10 +277,12 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const GemmArgs p) {
         for (int r = 0; r < 4; ++r) {
           const float* gp = p.g + cloud * p.g_cloud_stride;                 // wave-uniform bases
           const float* fp = p.fseg.x + cloud * p.fseg.cloud_stride;
-          const uint32_t go = 4u * ((uint32_t)gi_all[d][r] * (uint32_t)p.Cout + (uint32_t)fr);
+          // G is stored in this kernel's order (engine.hip, up_fc_g): the block's column of lane fr in tiles 0..3 is one float4
+          const uint32_t go = 4u * ((uint32_t)gi_all[d][r] * (uint32_t)p.Cout + (uint32_t)(n0 + 4 * fr));
           const uint32_t fo = 4u * ((uint32_t)gi_all[d][r] * (uint32_t)p.fseg.ld + (uint32_t)fr);
-#pragma unroll
-          for (int t = 0; t < NT; ++t) gpre_all[d][t][r] = ld_f32(gp + col0_of(t), go);
+          static_assert(EPI != EPI_ATT2 || NT == 4, "one float4 of G per gathered row");
+          const float4 g4 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(gp) + go);
+          gpre_all[d][0][r] = g4.x; gpre_all[d][1 % GN_][r] = g4.y; gpre_all[d][2 % GN_][r] = g4.z; gpre_all[d][3 % GN_][r] = g4.w;
 #pragma unroll
           for (int t = 0; t < NT / 2; ++t) fpre_all[d][t][r] = ld_f32(fp + col0_of(t), fo);
         }

@@ -176,12 +176,14 @@ __global__ __launch_bounds__(256) void pw_tile_kernel(const GemmArgs p) {
       for (int r = 0; r < 4; ++r) {
         const int row = min(m0 + 16 * RT * w + 16 * rt + 4 * fq + r, p.M - 1);
         const int gi = p.fseg.idx[cloud * p.fseg.idx_cloud_stride + row];
-        const float* gp = p.g + cloud * p.g_cloud_stride + (int64_t)gi * p.Cout + n0 + fr;
+        // G is stored in this kernel's order (engine.hip, up_fc_g): lane fr's column in tiles 0..3 of the block is one float4
+        const float4 g4 = *reinterpret_cast<const float4*>(p.g + cloud * p.g_cloud_stride + (int64_t)gi * p.Cout + n0 + 4 * fr);
+        const float gq[4] = {g4.x, g4.y, g4.z, g4.w};
         const float* fp = gath ? p.fseg.x + cloud * p.fseg.cloud_stride + (int64_t)gi * p.fseg.ld + n0 + fr
                                : p.seg[0].x + row_off(p, cloud, row).o0 + (n0 - ch) + fr;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-          gpre[rt][t][r] = gp[16 * t];
+          gpre[rt][t][r] = gq[t];
           fpre[rt][t][r] = fp[16 * t];
         }
       }
