@@ -65,7 +65,7 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pairs", type=int, default=int(os.environ.get("DSIR_BENCH_PAIRS", "256")), help="pairs per step per GPU")
     ap.add_argument("--points", type=int, default=5000)
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("DSIR_BENCH_STREAMS", "4")),
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("DSIR_BENCH_STREAMS", "2")),
                     help="engine streams per GPU; the batch is split across them and registered concurrently")
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--feat-len", type=int, default=3, help="3 = xyz (3DMatch), 4 = xyz + reflectance (KITTI)")

@@ -214,8 +214,8 @@ class KittiOdometryTest:
     3DFeatNet convention), then continue after it; pair (8, 15, 58) dropped.  A sample = both scans cropped
     (3 m < r <= 60 m, -3 m <= z <= 10 m) and voxel-averaged at `voxel_size` with the reflectance as 4th channel, and
     the ground-truth pose: odometry poses through the velodyne calibration, refined by point-to-point ICP (0.2 m,
-    <= 200 iterations, on 0.05 m voxels) and cached as `<root>/icp_opti_pose/<drive>_<t0>_<t1>.npy` - the
-    reference's cache file, so either side can reuse the other's.
+    <= 200 iterations, on 0.05 m voxels) and cached as `<root>/icp_opti_pose_dsir/<drive>_<t0>_<t1>.npy`; the
+    reference's own cache `<root>/icp_opti_pose/` is read when present and never written.
 
     Sizes: `num_points` None = what the reference's test split does (SemanticKITTIPair.__getitem__ with fixed=True,
     apply_augment_V2, data_base.py:271-283): the cloud with fewer voxels is tiled (FixedResampler) to the size of the
@@ -290,7 +290,13 @@ class KittiOdometryTest:
 
     def gt_pose(self, drive: int, t0: int, t1: int, xyz0: np.ndarray, xyz1: np.ndarray) -> np.ndarray:
         key = "%d_%d_%d" % (drive, t0, t1)
-        fn = os.path.join(self.icp_path, key + ".npy")
+        # The reference's own cache (open3d ICP) is READ when present, never written: this engine's refinement is not
+        # pinned against open3d (voxel order, termination bookkeeping), so its poses go to a directory of their own and
+        # neither side's ground truth silently becomes the other's.
+        ref_fn = os.path.join(self.icp_path, key + ".npy")
+        if os.path.exists(ref_fn):
+            return np.load(ref_fn)
+        fn = os.path.join(self.icp_path + "_dsir", key + ".npy")
         if os.path.exists(fn):
             return np.load(fn)
         M = self.odometry_pose(drive, t0, t1)
@@ -306,7 +312,7 @@ class KittiOdometryTest:
         Tp = np.eye(4)
         Tp[:3, :] = T[0].double().cpu().numpy()
         M2 = M @ Tp
-        os.makedirs(self.icp_path, exist_ok=True)
+        os.makedirs(os.path.dirname(fn), exist_ok=True)
         np.save(fn, M2)
         return M2
 

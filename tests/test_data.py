@@ -226,12 +226,18 @@ def test_kitti_test_split_end_to_end(tmp_path):
     M = ds.odometry_pose(10, t0, t1)
     T = item["transform_gt"]
     assert np.abs(T - M[:3]).max() < 0.05
-    fn = os.path.join(root, "icp_opti_pose", f"10_{t0}_{t1}.npy")
-    assert os.path.exists(fn)
+    # written to the engine's OWN cache directory: its ICP is not pinned against open3d, so the reference's cache
+    # (icp_opti_pose/) is never written by this side
+    fn = os.path.join(root, "icp_opti_pose_dsir", f"10_{t0}_{t1}.npy")
+    ref_fn = os.path.join(root, "icp_opti_pose", f"10_{t0}_{t1}.npy")
+    assert os.path.exists(fn) and not os.path.exists(ref_fn)
     np.save(fn, np.eye(4) * 2.0)                      # the cache is authoritative, like the reference's
     assert np.array_equal(ds[0]["transform_gt"], (np.eye(4) * 2.0)[:3].astype(np.float32))
+    os.makedirs(os.path.dirname(ref_fn), exist_ok=True)
+    np.save(ref_fn, np.eye(4) * 3.0)                  # a pose the reference cached wins over ours, and is left alone
+    assert np.array_equal(ds[0]["transform_gt"], (np.eye(4) * 3.0)[:3].astype(np.float32))
     # the pair registers: src moved by T_gt lands on ref (nearest-neighbour distance of the voxel centroids)
-    os.remove(fn)
+    os.remove(fn); os.remove(ref_fn)
     item = ds[0]
     Tg = torch.from_numpy(item["transform_gt"]).to(item["points_src"].device)
     moved = item["points_src"][:, :3] @ Tg[:, :3].T + Tg[:, 3]
