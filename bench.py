@@ -408,7 +408,7 @@ def main():
                        "points_per_cloud": N, "pairs_per_step_per_gpu": P, "pairs_in_flight_per_gpu": P, "streams_per_gpu": S,
                        "num_reg_iter": n_iter, "knn": 16, "world_size": world,
                        "weights": "seeded random state-dict (checkpoint not available)",
-                       "parallelism": f"pair-sharded x{world}, RCCL all_gather of results"},
+                       "parallelism": f"pair-sharded x{world}, {'RCCL' if (dist is None or dist.get_backend() == 'nccl') else dist.get_backend() + ' (rehearsal)'} all_gather of results"},
         }
         # ---- roofline of the dominant kernel
         roof = {"bound": "mfma", "unit": "TFLOP/s"}

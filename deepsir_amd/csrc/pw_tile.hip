@@ -355,9 +355,9 @@ __global__ __launch_bounds__(256) void pw_tile_kernel(const GemmArgs p) {
 // chain is 4 x shorter (K/2 instead of 2 K for RT = 2), a cloud spreads over 4-8 x more workgroups, and the row padding
 // drops from 64-128 to 32 rows (M = 78: 64 % -> 23 %; M = 19: 237 % -> 68 %).  Price: a weight tile is re-read from L2
 // once per 32 rows.  GroupNorm statistics: fp32 per column tile and wave, fp64 atomics.
-template <int EPI>
+template <int RTS, int EPI>
 __global__ __launch_bounds__(256) void pw_tile_small_kernel(const GemmArgs p) {
-  constexpr int BM = 32, NTW = 2;
+  constexpr int BM = 32 * RTS, NTW = 2;         // RTS row tiles per wave: 32- or 64-row blocks
   __shared__ float As[2][BM * LDS_LD];
   __shared__ float Ws[2][BN * LDS_LD];
   __shared__ float s_sc[MAXC];
@@ -387,10 +387,12 @@ __global__ __launch_bounds__(256) void pw_tile_small_kernel(const GemmArgs p) {
     s_sc[c] = scale;
     s_sh[c] = shift;
   }
-  // staging: thread -> 4 consecutive channels (tid & 7) of A row (tid >> 3) and of W rows (tid >> 3), (tid >> 3) + 32
+  // staging: thread -> 4 consecutive channels (tid & 7) of A rows (tid >> 3) + 32 i and of W rows (tid >> 3), (tid >> 3) + 32
   const int c4 = (tid & 7) * 4;
   const int sr0 = tid >> 3;
-  const RowOff ro = row_off(p, cloud, min(m0 + sr0, p.M - 1));
+  RowOff ro[RTS];
+#pragma unroll
+  for (int i = 0; i < RTS; ++i) ro[i] = row_off(p, cloud, min(m0 + sr0 + 32 * i, p.M - 1));
   const float* wrow[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -401,12 +403,13 @@ __global__ __launch_bounds__(256) void pw_tile_small_kernel(const GemmArgs p) {
   const int act0 = p.seg[0].act, act1 = p.nseg > 1 ? p.seg[1].act : 0;
   __syncthreads();
 
-  float4 ra, rw[2];
+  float4 ra[RTS], rw[2];
   auto gload = [&](int k0) {
     const int c = k0 + c4;
     const bool s1 = c >= C0;
     const float* base = s1 ? p.seg[1].x : p.seg[0].x;
-    ra = *reinterpret_cast<const float4*>(base + (s1 ? ro.o1 : ro.o0) + (s1 ? c - C0 : c));
+#pragma unroll
+    for (int i = 0; i < RTS; ++i) ra[i] = *reinterpret_cast<const float4*>(base + (s1 ? ro[i].o1 : ro[i].o0) + (s1 ? c - C0 : c));
 #pragma unroll
     for (int i = 0; i < 2; ++i) rw[i] = *reinterpret_cast<const float4*>(wrow[i] + k0);
   };
@@ -415,13 +418,16 @@ __global__ __launch_bounds__(256) void pw_tile_small_kernel(const GemmArgs p) {
     const float slope = ((c >= C0) ? act1 : act0) ? 0.2f : 1.f;
     const float4 sc = *reinterpret_cast<const float4*>(&s_sc[c]);
     const float4 sh = *reinterpret_cast<const float4*>(&s_sh[c]);
-    float4 v = ra;
-    v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y); v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
-    v.x = fmaxf(v.x, slope * v.x); v.y = fmaxf(v.y, slope * v.y);
-    v.z = fmaxf(v.z, slope * v.z); v.w = fmaxf(v.w, slope * v.w);
-    float2* d = reinterpret_cast<float2*>(&As[buf][sr0 * LDS_LD + c4]);
-    d[0] = make_float2(v.x, v.y);
-    d[1] = make_float2(v.z, v.w);
+#pragma unroll
+    for (int i = 0; i < RTS; ++i) {
+      float4 v = ra[i];
+      v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y); v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+      v.x = fmaxf(v.x, slope * v.x); v.y = fmaxf(v.y, slope * v.y);
+      v.z = fmaxf(v.z, slope * v.z); v.w = fmaxf(v.w, slope * v.w);
+      float2* d = reinterpret_cast<float2*>(&As[buf][(sr0 + 32 * i) * LDS_LD + c4]);
+      d[0] = make_float2(v.x, v.y);
+      d[1] = make_float2(v.z, v.w);
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       float2* dw = reinterpret_cast<float2*>(&Ws[buf][(sr0 + 32 * i) * LDS_LD + c4]);
@@ -429,9 +435,11 @@ __global__ __launch_bounds__(256) void pw_tile_small_kernel(const GemmArgs p) {
       dw[1] = make_float2(rw[i].z, rw[i].w);
     }
   };
-  f32x4 acc[NTW];
+  f32x4 acc[RTS][NTW];
 #pragma unroll
-  for (int t = 0; t < NTW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int rt = 0; rt < RTS; ++rt)
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) acc[rt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int nchunks = p.Cin / BK;
   gload(0);
   lstore(0, 0);
@@ -444,19 +452,21 @@ __global__ __launch_bounds__(256) void pw_tile_small_kernel(const GemmArgs p) {
     const float* Wt = Ws[buf];
 #pragma unroll
     for (int s = 0; s < BK / 4; ++s) {
-      const float a = At[(16 * wr + fr) * LDS_LD + 4 * s + fq];
+      float a[RTS], b[NTW];
 #pragma unroll
-      for (int t = 0; t < NTW; ++t) {
-        const float b = Wt[(16 * (NTW * wc + t) + fr) * LDS_LD + 4 * s + fq];
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[t], 0, 0, 0);
-      }
+      for (int rt = 0; rt < RTS; ++rt) a[rt] = At[(16 * (RTS * wr + rt) + fr) * LDS_LD + 4 * s + fq];
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) b[t] = Wt[(16 * (NTW * wc + t) + fr) * LDS_LD + 4 * s + fq];
+#pragma unroll
+      for (int rt = 0; rt < RTS; ++rt)
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt], b[t], acc[rt][t], 0, 0, 0);
     }
     if (more) lstore((kc + 1) * BK, buf ^ 1);
     __syncthreads();
     buf ^= 1;
   }
   // ---- epilogue.  C layout: col = lane & 15, row = 4 * (lane >> 4) + reg.
-  const int r0 = m0 + 16 * wr;
   float* Y = p.Y + cloud * p.y_cloud_stride;
 #pragma unroll
   for (int t = 0; t < NTW; ++t) {
@@ -464,15 +474,19 @@ __global__ __launch_bounds__(256) void pw_tile_small_kernel(const GemmArgs p) {
     const float bv = (p.bias && col < p.Cout) ? p.bias[col] : 0.f;
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = r0 + 4 * fq + r;
-      if (row < p.M && col < p.Cout) {
-        float v = acc[t][r] + bv;
-        if (EPI == EPI_LINEAR && p.residual) v += p.residual[cloud * p.res_cloud_stride + (int64_t)row * p.ldres + col];
-        if (EPI == EPI_ACT && v < 0.f) v *= 0.2f;
-        Y[(int64_t)row * p.ldy + col] = v;
-        s1 += v;
-        s2 += v * v;
+    for (int rt = 0; rt < RTS; ++rt) {
+      const int r0 = m0 + 16 * (RTS * wr + rt);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = r0 + 4 * fq + r;
+        if (row < p.M && col < p.Cout) {
+          float v = acc[rt][t][r] + bv;
+          if (EPI == EPI_LINEAR && p.residual) v += p.residual[cloud * p.res_cloud_stride + (int64_t)row * p.ldres + col];
+          if (EPI == EPI_ACT && v < 0.f) v *= 0.2f;
+          Y[(int64_t)row * p.ldy + col] = v;
+          s1 += v;
+          s2 += v * v;
+        }
       }
     }
     if (EPI == EPI_GN) {
@@ -481,7 +495,7 @@ __global__ __launch_bounds__(256) void pw_tile_small_kernel(const GemmArgs p) {
       s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
       s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
       for (int o = 1; o < lw; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
-      if (fq == 0 && (fr % lw) == 0 && r0 < p.M && col < p.Cout) {
+      if (fq == 0 && (fr % lw) == 0 && m0 + 16 * RTS * wr < p.M && col < p.Cout) {
         double* st = p.stats_out + ((int64_t)cloud * p.groups_out + col / gw) * 2;
         atomicAdd(st, (double)s1);
         atomicAdd(st + 1, (double)s2);
@@ -490,10 +504,19 @@ __global__ __launch_bounds__(256) void pw_tile_small_kernel(const GemmArgs p) {
   }
 }
 
-template <int EPI>
+template <int RTS, int EPI>
 void launch_small(const GemmArgs& a, hipStream_t st) {
-  dim3 grid((a.M + 31) / 32, (a.Cout + BN - 1) / BN, a.clouds);
-  hipLaunchKernelGGL((pw_tile_small_kernel<EPI>), grid, dim3(256), 0, st, a);
+  dim3 grid((a.M + 32 * RTS - 1) / (32 * RTS), (a.Cout + BN - 1) / BN, a.clouds);
+  hipLaunchKernelGGL((pw_tile_small_kernel<RTS, EPI>), grid, dim3(256), 0, st, a);
+}
+
+template <int RTS>
+bool launch_small_e(const GemmArgs& a, hipStream_t st) {
+  switch (a.epi) {
+    case EPI_GN: launch_small<RTS, EPI_GN>(a, st); return true;
+    case EPI_ACT: launch_small<RTS, EPI_ACT>(a, st); return true;
+    default: launch_small<RTS, EPI_LINEAR>(a, st); return true;
+  }
 }
 
 template <int RT, int EPI>
@@ -532,11 +555,11 @@ bool launch_pw_tile(const GemmArgs& a, hipStream_t st) {
   // rows per block: a function of M only (batch-invariant tiling)
   static const int small_m = getenv("DSIR_TILE_SMALL_M") ? atoi(getenv("DSIR_TILE_SMALL_M")) : 320;   // tuning hook; 0 = off
   if (a.M <= small_m && (a.epi == EPI_GN || a.epi == EPI_ACT || a.epi == EPI_LINEAR)) {
-    switch (a.epi) {
-      case EPI_GN: launch_small<EPI_GN>(a, st); return true;
-      case EPI_ACT: launch_small<EPI_ACT>(a, st); return true;
-      default: launch_small<EPI_LINEAR>(a, st); return true;
-    }
+    // 64-row blocks (two row tiles per wave: W fragments reused twice) when they pad no more than 32-row blocks
+    static const int rt2_min = getenv("DSIR_TILE_SMALL_RT2") ? atoi(getenv("DSIR_TILE_SMALL_RT2")) : 128;   // tuning hook
+    const int p32 = ((a.M + 31) / 32) * 32, p64 = ((a.M + 63) / 64) * 64;
+    if (a.M >= rt2_min && p64 == p32) return launch_small_e<2>(a, st);
+    return launch_small_e<1>(a, st);
   }
   // 128-row tiles unless they waste > 25 %
   const int pad128 = ((a.M + 127) / 128) * 128, pad64 = ((a.M + 63) / 64) * 64;
