@@ -1246,6 +1246,31 @@ int dsir_pose_finetune(dsir_ctx* c, const float* xyz_src, const float* xyz_ref, 
   return post(c);
 }
 
+int dsir_align_loss_backward(dsir_ctx* c, const float* pt_src, const float* pt_ref, const int32_t* idx, const float* logits,
+                             const float* labels, const float* transform_gt, int pairs, int J, int K, int n_iter, int loss_type,
+                             float wt_ptDist_loss, float wt_inlier_loss, float loss_discount_factor, float* transforms,
+                             double* losses, float* grad_logits) {
+  if (!c) return 1;
+  if (!pt_src || !pt_ref || !idx || !logits || !transform_gt || !grad_logits || pairs < 1 || J < 1 || K < 1 || n_iter < 1 ||
+      n_iter > 8 || (loss_type != 0 && loss_type != 1))
+    return fail(c, "dsir_align_loss_backward: bad arguments (n_iter in [1,8], loss_type 0 = mae / 1 = mse)");
+  HIP_OK(c, hipSetDevice(c->device));
+  c->ws.top = 0; c->ws.overflow = false;
+  // correspondences come from the caller: clamped into [0, K) before any gather
+  int32_t* idx_ok = c->ws.get<int32_t>((size_t)n_iter * pairs * J);
+  double* dloss = c->ws.get<double>((size_t)2 * n_iter);
+  if (c->ws.overflow) return fail(c, "workspace too small for dsir_align_loss_backward");
+  launch_copy_idx_clamped(idx, (int64_t)pairs * J, pairs * J, K, n_iter, idx_ok, (int64_t)pairs * J, nullptr, 1, c->stream);
+  if (launch_align_loss(pt_src, pt_ref, idx_ok, logits, labels, transform_gt, pairs, J, K, n_iter, loss_type, wt_ptDist_loss,
+                        wt_inlier_loss, loss_discount_factor, transforms, dloss, grad_logits, c->stream))
+    return fail(c, "dsir_align_loss_backward: launch failed");
+  if (losses) {
+    HIP_OK(c, hipStreamSynchronize(c->stream));
+    HIP_OK(c, hipMemcpy(losses, dloss, sizeof(double) * 2 * n_iter, hipMemcpyDeviceToHost));
+  }
+  return post(c);
+}
+
 int dsir_enable_graph(dsir_ctx* c, int enable) {
   if (!c) return 1;
   c->use_graph = enable != 0;

@@ -226,6 +226,12 @@ void launch_pose_finetune(const float* src, const float* ref, const float* w, in
                           float quant, int max_iter, float break_ratio, int max_break, float* T_out, double* stats,
                           hipStream_t st);
 
+// align_loss.hip — ScanAlignmentLoss and its gradient down to the inlier logits (loss.py:705-851, model.py:22-66, :571-595);
+// losses [n_iter][2] float64 on device (point-distance term, confidence term), summed over pairs; returns 0 on success
+int launch_align_loss(const float* src, const float* ref, const int32_t* idx, const float* logits, const float* labels,
+                      const float* T_gt, int P, int J, int K, int n_iter, int mse, float wt_pt, float wt_in, float discount,
+                      float* T_out, double* losses, float* grad, hipStream_t st);
+
 // pre-processing on ragged batches (preprocess.hip); return 0 on success
 size_t voxel_downsample_scratch_bytes(int64_t total, int clouds);
 int launch_voxel_downsample(const float* pts, const int64_t* offsets_host, int clouds, int stride, float voxel,

@@ -398,6 +398,40 @@ class Engine:
         self.sync()
         return T, stats
 
+    def align_loss_backward(self, pt_src, pt_ref, idx, logits, labels, transform_gt, loss_type: str = "mae",
+                            wt_ptDist_loss: float = 1.0, wt_inlier_loss: float = 1.0, loss_discount_factor: float = 0.5):
+        """ScanAlignmentLoss (reduction='mean') + its gradient down to the inlier logits (include/dsir.h).
+        pt_src [P,J,3], pt_ref [P,K,3], idx [n,P,J] i32, logits [n,P,J], labels [n,P,J] or None, transform_gt [P,3,4]
+        -> dict(losses {mae_i|mse_i, outlier_i, total}, grad_logits [n,P,J], transforms [P,n,3,4])."""
+        pt_src, pt_ref = _chk(pt_src, torch.float32, "pt_src"), _chk(pt_ref, torch.float32, "pt_ref")
+        idx, logits = _chk(idx, torch.int32, "idx"), _chk(logits, torch.float32, "logits")
+        transform_gt = _chk(transform_gt, torch.float32, "transform_gt")
+        if labels is not None:
+            labels = _chk(labels, torch.float32, "labels")
+        n, P, J = logits.shape
+        K = pt_ref.shape[1]
+        if tuple(pt_src.shape) != (P, J, 3) or tuple(idx.shape) != (n, P, J) or tuple(transform_gt.shape) != (P, 3, 4) or \
+                (labels is not None and tuple(labels.shape) != (n, P, J)):
+            raise EngineError("align_loss_backward: inconsistent shapes")
+        lt = {"mae": 0, "mse": 1}[loss_type]
+        T = self._empty((P, n, 3, 4))
+        grad = self._empty((n, P, J))
+        losses = (C.c_double * (2 * n))()
+        self._pre()
+        self._call(self.lib.dsir_align_loss_backward(self.h, _ptr(pt_src), _ptr(pt_ref), _ptr(idx), _ptr(logits), _ptr(labels),
+                                                     _ptr(transform_gt), P, J, K, n, lt, float(wt_ptDist_loss), float(wt_inlier_loss),
+                                                     float(loss_discount_factor), _ptr(T), losses, _ptr(grad)))
+        self.sync()
+        d, total = {}, 0.0
+        for i in range(n):
+            disc = loss_discount_factor ** (n - i - 1)
+            if wt_ptDist_loss > 0:
+                d[f"{loss_type}_{i}"] = losses[2 * i]; total += disc * losses[2 * i]
+            if wt_inlier_loss > 0 and labels is not None:
+                d[f"outlier_{i}"] = losses[2 * i + 1]; total += disc * losses[2 * i + 1]
+        d["total"] = total
+        return {"losses": d, "grad_logits": grad, "transforms": T}
+
     def enable_graph(self, on=True):
         """Replay dsir_register through a captured hipGraph (same buffers on every call)."""
         self._call(self.lib.dsir_enable_graph(self.h, 1 if on else 0))

@@ -254,6 +254,26 @@ int dsir_pose_finetune(dsir_ctx* ctx, const float* xyz_src, const float* xyz_ref
                        int pairs, int m, const float* T_init, float quantization_size, int max_iter, float break_threshold_ratio,
                        int max_break_count, float* T_out, double* stats);
 
+/* ---- the training slice (backward half) ------- */
+
+/* Replaces ScanAlignmentLoss.forward with reduction='mean' (network/loss.py:705-851; defaults of arguments.py:51-61:
+ * loss_type mae, wt_ptDist_loss 1, wt_inlier_loss 1, wt_pose_loss 0, loss_discount_factor 0.5; called at train.py:401)
+ * AND torch autograd's backward of it down to the inlier logits: through se3_torch.concatenate (model.py:595) and the
+ * SVD of compute_rigid_transform_2 (model.py:22-66).  In forward_align_4 the matching runs under no_grad and the src
+ * cloud is moved by R_t.detach(), so d total / d logits is the whole gradient the network receives from this loss: the
+ * input of the inlier RandLA's backward pass (not built).
+ * pt_src [P][J][3], pt_ref [P][K][3] (endpoints['pt_src'/'pt_ref']); idx [n_iter][P][J] i32 (pred_pairs[...,1]);
+ * logits [n_iter][P][J] (perm_matrices); labels [n_iter][P][J] f32 0/1 = find_correct_correspondence(matches, pred_pairs)
+ * (loss.py:723-749, host work in the reference too) or NULL = no confidence term; transform_gt [P][3][4].
+ * loss_type 0 = mae, 1 = mse; wt_ptDist_loss only gates the point-distance term (> 0), as in the reference.
+ * Outputs: transforms [P][n_iter][3][4] cumulative poses replayed from the logits (or NULL); losses = HOST float64
+ * [n_iter][2] {mae_i | mse_i, outlier_i} (total = sum_i discount^(n_iter-1-i) (term_i + outlier_i)) or NULL;
+ * grad_logits [n_iter][P][J] = d total / d logits.  n_iter <= 8. */
+int dsir_align_loss_backward(dsir_ctx* ctx, const float* pt_src, const float* pt_ref, const int32_t* idx, const float* logits,
+                             const float* labels, const float* transform_gt, int pairs, int J, int K, int n_iter, int loss_type,
+                             float wt_ptDist_loss, float wt_inlier_loss, float loss_discount_factor, float* transforms,
+                             double* losses, float* grad_logits);
+
 /* Launch-bound small batches: capture the whole dsir_register launch sequence into a hipGraph once per
  * call signature (sizes and buffer addresses) and replay it.  Off by default. */
 int dsir_enable_graph(dsir_ctx* ctx, int enable);
