@@ -38,3 +38,19 @@ def test_world_size_mismatch_is_an_error():
     """A rank started by someone else's launcher with a different world size than --gpus says must not print a number."""
     r = _run(["--gpus", "4", "--dry-run"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and "launched as 1 ranks" in r.stderr
+
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_two_ranks_with_the_engine_on_one_gpu():
+    """The real multi-rank path on the GPU box: `bench.py --gpus 2` launches itself as two ranks, each with its own
+    engine (both on the one visible device, collectives over gloo because RCCL refuses two ranks on one GPU), disjoint
+    pair shards, result all_gather, MAX-over-ranks timing.  n_gpus counts distinct devices: 1."""
+    r = _run(["--gpus", "2", "--pairs", "16", "--points", "2048", "--steps", "3", "--warmup", "1", "--streams", "1"],
+             {"DSIR_BENCH_BACKEND": "gloo"}, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = _json_line(r.stdout)
+    assert j["n_gpus"] == 1 and j["config"]["world_size"] == 2 and j["value"] > 0 and j["scaling"] == "weak"
+    assert j["config"]["pairs_per_step_per_gpu"] == 16 and "rehearsal" in j["config"]["parallelism"]
