@@ -286,6 +286,115 @@ __global__ __launch_bounds__(KB) void grid_knn_kernel(const float4* __restrict__
   }
 }
 
+// Four lanes per query, for launches too small to fill the chip with one lane per query (one or two clouds in flight:
+// 5000 queries are 79 waves on 1024 SIMDs, and a query's walk over ~27 cells x 8 points is a chain of dependent loads).
+// Lane s of a quad takes the candidates k = b + s, b + s + 4, ... of every cell run, keeps its own sorted top 16 and
+// queue; the filter / termination threshold is the minimum over the quad of the lanes' 16th best - an upper bound of the
+// query's true 16th best (the k-th smallest of a union is at most that of any part), so the walk stays exact, at worst a
+// little longer.  At the end the four sorted lists meet in a 4-way merge by lane 0 of the quad.  Keys are unique
+// (distance bits << 32 | index), so the 16 smallest keys - hence the output - are the one-lane kernel's, bit for bit.
+constexpr int KB4 = 64;      // threads per block = 16 queries
+__global__ __launch_bounds__(KB4) void grid_knn4_kernel(const float4* __restrict__ sorted, const int* __restrict__ starts,
+                                                        const GridParams* __restrict__ gp, int max_cells, int n,
+                                                        int32_t* __restrict__ out, int64_t ocs) {
+  __shared__ float qd[QCAP][KB4];
+  __shared__ int qi[QCAP][KB4];
+  __shared__ unsigned long long mk[KB4][kKnn + 1];      // the quads' lists for the merge (+1: bank spread)
+  const int cloud = blockIdx.y;
+  const int tid = threadIdx.x, sub = tid & 3;
+  const int t = blockIdx.x * (KB4 / 4) + (tid >> 2);
+  const bool live = t < n;
+  const GridParams g = gp[cloud];
+  const float4* S = sorted + (int64_t)cloud * n;
+  const int* ST = starts + (int64_t)cloud * (max_cells + 1);
+  const float4 q = S[live ? t : n - 1];
+  const int qidx = __float_as_int(q.w);
+  const int cx = cell_coord(q.x, g.ox, g.inv_h, g.gx);
+  const int cy = cell_coord(q.y, g.oy, g.inv_h, g.gy);
+  const int cz = cell_coord(q.z, g.oz, g.inv_h, g.gz);
+  TopLex top;
+  top.init();
+  float thr = INFINITY;
+  int nq = 0;
+  auto quad_min = [&](float v) { v = fminf(v, __shfl_xor(v, 1)); return fminf(v, __shfl_xor(v, 2)); };
+  auto flush = [&]() {
+#pragma unroll 1
+    for (int c = 0; c < QCAP; ++c)
+      if (c < nq) top.insert(qd[c][tid], qi[c][tid]);
+    nq = 0;
+    thr = quad_min(top.worst());
+  };
+  auto scan = [&](int b, int e) {
+    for (int kb = b; kb < e; kb += 16) {                  // trip count uniform over the quad (its lanes shuffle in flush())
+      const int k = kb + sub;
+      float4 sv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) sv[u] = S[min(k + 4 * u, n - 1)];
+      if (__any(nq > QCAP - 4)) flush();
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float d = sqdist3(q.x, q.y, q.z, sv[u].x, sv[u].y, sv[u].z);
+        if (k + 4 * u < e && d <= thr) { qd[nq][tid] = d; qi[nq][tid] = __float_as_int(sv[u].w); ++nq; }
+      }
+    }
+  };
+  const int rmax = live ? max(max(max(cx, g.gx - 1 - cx), max(cy, g.gy - 1 - cy)), max(cz, g.gz - 1 - cz)) : -1;
+  for (int r = 0; r <= rmax; ++r) {
+    const int z0 = max(cz - r, 0), z1 = min(cz + r, g.gz - 1);
+    const int y0 = max(cy - r, 0), y1 = min(cy + r, g.gy - 1);
+    const int x0 = max(cx - r, 0), x1 = min(cx + r, g.gx - 1);
+    const int ny = y1 - y0 + 1, nrows = (z1 - z0 + 1) * ny;
+    auto bounds = [&](int j, int& b0, int& e0, int& b1, int& e1) {
+      const int z = z0 + j / ny, y = y0 + j % ny;
+      const bool face = (z == cz - r) || (z == cz + r) || (y == cy - r) || (y == cy + r);
+      const int rowbase = (z * g.gy + y) * g.gx;
+      b0 = e0 = b1 = e1 = 0;
+      if (face) { b0 = ST[rowbase + x0]; e0 = ST[rowbase + x1 + 1]; }
+      else {
+        if (cx - r >= 0) { b0 = ST[rowbase + cx - r]; e0 = ST[rowbase + cx - r + 1]; }
+        if (cx + r <= g.gx - 1) { b1 = ST[rowbase + cx + r]; e1 = ST[rowbase + cx + r + 1]; }
+      }
+    };
+    int b0, e0, b1, e1;
+    if (nrows > 0) bounds(0, b0, e0, b1, e1);
+    for (int j = 0; j < nrows; ++j) {
+      int nb0 = 0, ne0 = 0, nb1 = 0, ne1 = 0;
+      if (j + 1 < nrows) bounds(j + 1, nb0, ne0, nb1, ne1);
+      scan(b0, e0);
+      scan(b1, e1);
+      b0 = nb0; e0 = ne0; b1 = nb1; e1 = ne1;
+    }
+    flush();
+    float bound = INFINITY;
+    if (cx - r > 0) bound = fminf(bound, q.x - (g.ox + (float)(cx - r) * g.h));
+    if (cx + r < g.gx - 1) bound = fminf(bound, (g.ox + (float)(cx + r + 1) * g.h) - q.x);
+    if (cy - r > 0) bound = fminf(bound, q.y - (g.oy + (float)(cy - r) * g.h));
+    if (cy + r < g.gy - 1) bound = fminf(bound, (g.oy + (float)(cy + r + 1) * g.h) - q.y);
+    if (cz - r > 0) bound = fminf(bound, q.z - (g.oz + (float)(cz - r) * g.h));
+    if (cz + r < g.gz - 1) bound = fminf(bound, (g.oz + (float)(cz + r + 1) * g.h) - q.z);
+    if (bound == INFINITY) break;
+    bound -= 1e-4f * g.h;
+    if (bound > 0.f && thr < bound * bound * 0.9999f) break;      // thr = quad minimum of the 16th bests (set by flush)
+  }
+  // 4-way merge of the quad's sorted lists
+#pragma unroll
+  for (int k = 0; k < kKnn; ++k) mk[tid][k] = top.k[k];
+  __builtin_amdgcn_wave_barrier();
+  if (live && sub == 0) {
+    int h0 = 0, h1 = 0, h2 = 0, h3 = 0;
+    int32_t* o = out + cloud * ocs + (int64_t)qidx * kKnn;
+    const unsigned long long sentinel = 0x7f8000007fffffffull;
+    for (int k = 0; k < kKnn; ++k) {
+      const unsigned long long a0 = h0 < kKnn ? mk[tid][h0] : ~0ull, a1 = h1 < kKnn ? mk[tid + 1][h1] : ~0ull;
+      const unsigned long long a2 = h2 < kKnn ? mk[tid + 2][h2] : ~0ull, a3 = h3 < kKnn ? mk[tid + 3][h3] : ~0ull;
+      const unsigned long long m01 = a0 < a1 ? a0 : a1, m23 = a2 < a3 ? a2 : a3, m = m01 < m23 ? m01 : m23;
+      if (m == a0) ++h0; else if (m == a1) ++h1; else if (m == a2) ++h2; else ++h3;
+      const int i = (int)(unsigned)(m & 0xffffffffull);
+      o[k] = (m == sentinel || i == 0x7fffffff) ? qidx : i;
+    }
+  }
+}
+
 }  // namespace
 
 size_t knn_grid_scratch_bytes(int clouds, int n) {
@@ -317,7 +426,11 @@ void launch_knn16_grid(const float* pts, int64_t cs, int stride, int n, int clou
   hipLaunchKernelGGL(grid_count_kernel, dim3(gx, clouds), dim3(256), 0, st, pts, cs, stride, n, gp, max_cells, cell_of, counts);
   hipLaunchKernelGGL(grid_scan_kernel, dim3(clouds), dim3(1024), 0, st, counts, max_cells, gp, starts, cursor);
   hipLaunchKernelGGL(grid_scatter_kernel, dim3(gx, clouds), dim3(256), 0, st, pts, cs, stride, n, cell_of, max_cells, cursor, sorted);
-  hipLaunchKernelGGL(grid_knn_kernel, dim3((n + KB - 1) / KB, clouds), dim3(KB), 0, st, sorted, starts, gp, max_cells, n, out, ocs);
+  // one lane per query when that fills the chip (1024 SIMDs), four lanes per query for a few clouds in flight; same bits
+  if ((int64_t)((n + KB - 1) / KB) * clouds >= 1024)
+    hipLaunchKernelGGL(grid_knn_kernel, dim3((n + KB - 1) / KB, clouds), dim3(KB), 0, st, sorted, starts, gp, max_cells, n, out, ocs);
+  else
+    hipLaunchKernelGGL(grid_knn4_kernel, dim3((n + KB4 / 4 - 1) / (KB4 / 4), clouds), dim3(KB4), 0, st, sorted, starts, gp, max_cells, n, out, ocs);
 }
 
 }  // namespace dsir
