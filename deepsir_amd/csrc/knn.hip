@@ -125,6 +125,50 @@ __global__ __launch_bounds__(QB * NW) void knn16_kernel(const float* __restrict_
   }
 }
 
+// One WAVE per query, for the small pyramid levels when few clouds are in flight (312 and 78 points per cloud at N = 5000:
+// with one lane per query that is 5 and 2 workgroups per cloud, each lane walking the whole support through a sorted
+// insertion).  Lane l holds the keys (distance bits << 32 | index) of support points l, l + 64, ...; the 16 smallest keys
+// of the wave are extracted by 16 rounds of a wave-wide minimum (keys are unique, so each round removes exactly one).
+// Same keys, same order as Top16 / oracle/knn.py: distance, then lower index - bit-identical output.
+constexpr int WQ_MAX = 16;    // support points per lane: n <= 1024
+__global__ __launch_bounds__(256) void knn16_wave_kernel(const float* __restrict__ pts, int64_t cs, int stride, int n,
+                                                         int32_t* __restrict__ out, int64_t ocs) {
+  const int lane = threadIdx.x & 63;
+  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int cloud = blockIdx.y;
+  if (q >= n) return;                                  // wave-uniform
+  const float* P = pts + cloud * cs;
+  const float qx = P[(int64_t)q * stride], qy = P[(int64_t)q * stride + 1], qz = P[(int64_t)q * stride + 2];
+  unsigned long long key[WQ_MAX];
+#pragma unroll
+  for (int i = 0; i < WQ_MAX; ++i) {
+    const int j = lane + 64 * i;
+    key[i] = ~0ull;
+    if (j < n) {
+      float4 s;
+      s.x = P[(int64_t)j * stride]; s.y = P[(int64_t)j * stride + 1]; s.z = P[(int64_t)j * stride + 2]; s.w = 0.f;
+      const float d = sqdist(qx, qy, qz, s);
+      if (d == d && d < INFINITY) key[i] = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)j;   // finite, >= 0: bits are monotone
+    }
+  }
+  int mine = -1;                                        // lane t keeps the t-th neighbour
+  for (int t = 0; t < kKnn; ++t) {
+    unsigned long long m = key[0];
+#pragma unroll
+    for (int i = 1; i < WQ_MAX; ++i) m = key[i] < m ? key[i] : m;
+    unsigned long long w = m;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned long long v = __shfl_xor(w, o);
+      w = v < w ? v : w;
+    }
+    if (lane == t) mine = w == ~0ull ? q : (int)(unsigned)(w & 0xffffffffull);   // fewer than 16 finite distances: the query itself
+#pragma unroll
+    for (int i = 0; i < WQ_MAX; ++i) key[i] = key[i] == w ? ~0ull : key[i];      // unique keys: removes exactly the winner
+  }
+  if (lane < kKnn) out[cloud * ocs + (int64_t)q * kKnn + lane] = mine;
+}
+
 // nearest support point (support = first n_support points) of every query point
 __global__ __launch_bounds__(QB * NW) void nn1_kernel(const float* __restrict__ pts, int64_t cs, int stride, int n_query,
                                                       int n_support, int32_t* __restrict__ out, int64_t ocs) {
@@ -173,6 +217,11 @@ __global__ __launch_bounds__(QB * NW) void nn1_kernel(const float* __restrict__ 
 }  // namespace
 
 void launch_knn16(const float* pts, int64_t cs, int stride, int n, int clouds, int32_t* out, int64_t ocs, hipStream_t st) {
+  // small level, few clouds: one wave per query (same bits); otherwise one lane per query
+  if (n <= 64 * WQ_MAX && (int64_t)clouds * n <= 4096) {
+    hipLaunchKernelGGL(knn16_wave_kernel, dim3((n + 3) / 4, clouds), dim3(256), 0, st, pts, cs, stride, n, out, ocs);
+    return;
+  }
   dim3 grid((n + QB - 1) / QB, clouds);
   hipLaunchKernelGGL(knn16_kernel, grid, dim3(QB * NW), 0, st, pts, cs, stride, n, out, ocs);
 }
