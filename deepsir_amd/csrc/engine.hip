@@ -362,7 +362,7 @@ struct Sched {
     a.amode = A_SEGS; a.nseg = s1 ? 2 : 1; a.seg[0] = s0; if (s1) a.seg[1] = *s1;
     a.W = w.W; a.bias = w.b; a.Cin = w.cin; a.Cout = w.cout; a.M = M; a.clouds = clouds; a.epi = EPI_GN;
     a.Y = y.p; a.y_cloud_stride = (int64_t)M * w.cout; a.ldy = w.cout; a.stats_out = st_out; a.groups_out = w.groups;
-    launch_pw_gemm(a, st);
+    if (!c->ws.overflow) launch_pw_gemm(a, st);   // an exhausted arena hands out its base: nothing may run on it
     return y;
   }
   Act mlp2d_lse(const Mlp2dW& w, const float* xyz, int64_t xyz_cs, const int32_t* neigh, int64_t neigh_cs, int n,
@@ -377,7 +377,7 @@ struct Sched {
     a.amode = A_LSE; a.xyz = xyz; a.xyz_cloud_stride = xyz_cs; a.neigh = neigh; a.neigh_cloud_stride = neigh_cs;
     a.W = w.W; a.bias = w.b; a.Cin = 10; a.Cout = w.cout; a.M = M; a.clouds = clouds; a.epi = EPI_GN;
     a.Y = y.p; a.y_cloud_stride = (int64_t)M * w.cout; a.ldy = w.cout; a.stats_out = st_out; a.groups_out = w.groups;
-    launch_pw_gemm(a, st);
+    if (!c->ws.overflow) launch_pw_gemm(a, st);   // an exhausted arena hands out its base: nothing may run on it
     return y;
   }
   // Att_pooling up to (not including) its MLP2D: softmax_k(fc [gather(f); enc]) . [gather(f); enc]
@@ -394,6 +394,7 @@ struct Sched {
       g.amode = A_SEGS; g.nseg = 1; g.seg[0] = seg_of(f);
       g.W = w.fc_g; g.ldw = w.d / 2; g.bias = nullptr; g.Cin = w.d / 2; g.Cout = w.d; g.M = n; g.clouds = clouds;   // G in the consumer's column order (up_fc_g)
       g.epi = EPI_LINEAR; g.Y = G; g.y_cloud_stride = (int64_t)n * w.d; g.ldy = w.d;
+      if (c->ws.overflow) return y;
       launch_pw_gemm(g, st);
       GemmArgs a2;
       a2.amode = A_SEGS; a2.nseg = 1; a2.seg[0] = seg_of(enc);
@@ -409,7 +410,7 @@ struct Sched {
     a.seg[1] = seg_of(enc);
     a.W = w.fc; a.bias = nullptr; a.Cin = w.d; a.Cout = w.d; a.M = n * kKnn; a.clouds = clouds; a.epi = EPI_ATT;
     a.Y = y.p; a.y_cloud_stride = (int64_t)n * w.d; a.ldy = w.d;
-    launch_pw_gemm(a, st);
+    if (!c->ws.overflow) launch_pw_gemm(a, st);   // an exhausted arena hands out its base: nothing may run on it
     return y;
   }
   Act linear(const LinW& w, const Seg& s0, const Seg* s1, int M, int epi, float* out = nullptr,
@@ -422,7 +423,7 @@ struct Sched {
     a.W = w.W; a.bias = w.b; a.Cin = w.cin; a.Cout = w.cout; a.M = M; a.clouds = clouds; a.epi = epi;
     a.Y = y.p; a.y_cloud_stride = (int64_t)M * w.cout; a.ldy = w.cout;
     a.residual = residual; a.res_cloud_stride = (int64_t)M * w.cout; a.ldres = w.cout;
-    launch_pw_gemm(a, st);
+    if (!c->ws.overflow) launch_pw_gemm(a, st);   // an exhausted arena hands out its base: nothing may run on it
     return y;
   }
 };
@@ -489,9 +490,10 @@ int randla_forward(dsir_ctx* c, const RandlaW& w, const Seg& in0, const Seg* in1
     Act samp;
     samp.C = enc_out.C; samp.rows = py.nl[l + 1];
     samp.p = c->ws.get<float>((size_t)py.clouds * samp.rows * samp.C);
+    if (l == 0) enc_out.p = c->ws.get<float>((size_t)py.clouds * n * enc_out.C);
+    if (c->ws.overflow) return fail(c, "workspace exhausted in randla_forward (raise max_points / max_pairs)");
     if (l == 0) {
       // the level-0 block output is also the decoder's last skip connection: materialise it
-      enc_out.p = c->ws.get<float>((size_t)py.clouds * n * enc_out.C);
       launch_residual_combine(mainb.p, mainb.gn, skipb.p, skipb.gn, enc_out.C, n, py.clouds, enc_out.p, st);
       launch_gather_max(enc_out.p, (int64_t)n * enc_out.C, py.sub + (int64_t)py.soff[l] * kKnn, sub_cs, samp.C, samp.rows,
                         py.clouds, samp.p, st);
@@ -521,6 +523,7 @@ int randla_forward(dsir_ctx* c, const RandlaW& w, const Seg& in0, const Seg* in1
     h.in = Sched::seg_of(x);
     h.W1 = w.out_w; h.W2 = w.fc[0].W; h.b2 = w.fc[0].b; h.W3 = w.fc[1].W; h.b3 = w.fc[1].b; h.W4 = w.fc[2].W; h.b4 = w.fc[2].b;
     h.ncls = w.ncls; h.M = n0; h.clouds = py.clouds; h.feat_out = feat_out; h.logits_out = logits_out;
+    if (c->ws.overflow) return fail(c, "workspace exhausted in randla_forward (raise max_points / max_pairs)");
     fused = launch_head_mlp(h, st);
   }
   LinW ow; ow.W = w.out_w; ow.b = nullptr; ow.cin = w.dec_out; ow.cout = g.out_feat_dim;
