@@ -135,9 +135,20 @@ __global__ __launch_bounds__(256) void split_norm_kernel(const float* __restrict
 #endif
 #define DSIR_FENCE() __builtin_amdgcn_sched_barrier(0)
 // (z1 >= z2: running top two of z, k1: column of z1)  <-  z at column col
+// DSIR_ABL_*: timing-only ablation builds (tools/ab_screen.sh; WRONG results, never part of libdsir.so): one VALU
+// instruction per element instead of the ranking, no LDS fragment reads after a tile's first step, no tile staging / barrier.
+#ifdef DSIR_ABL_NORANK
+#define DSIR_RANK(z1, z2, k1, z, col) asm volatile("v_max_f32 %0, %0, %1" : "+v"(z1) : "v"(z))
+#else
 #define DSIR_RANK(z1, z2, k1, z, col)                                                                                         \
   asm volatile("v_med3_f32 %1, %0, %1, %3\n\tv_cmp_gt_f32 vcc, %3, %0\n\tv_cndmask_b32 %2, %2, %4, vcc\n\tv_max_f32 %0, %0, %3" \
                : "+v"(z1), "+v"(z2), "+v"(k1) : "v"(z), "v"(col) : "vcc")
+#endif
+#ifdef DSIR_ABL_NOLDS
+#define DSIR_MORE(x) false
+#else
+#define DSIR_MORE(x) (x)
+#endif
 template <int RT, int NWV>
 __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(DSIR_SCREEN_WPE, DSIR_SCREEN_WPE))) void screen_kernel(const _Float16* __restrict__ Ah, const _Float16* __restrict__ Al,
                                                      const _Float16* __restrict__ Bh, const _Float16* __restrict__ Bl,
@@ -287,12 +298,14 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(DSIR_S
     { const float4 v = *cp; fa.cin = f32x4{v.x, v.y, v.z, v.w}; }
 #pragma unroll
     for (int t = 0; t < SBC / 16; t += 2) {
-      step(fa, fb, bhp + 16 * (t + 1) * SRS, blp + 16 * (t + 1) * SRS, cp + 16 * (t + 1), true, c0 + 16 * t + fr);
-      step(fb, fa, bhp + 16 * (t + 2) * SRS, blp + 16 * (t + 2) * SRS, cp + 16 * (t + 2), t + 2 < SBC / 16, c0 + 16 * (t + 1) + fr);
+      step(fa, fb, bhp + 16 * (t + 1) * SRS, blp + 16 * (t + 1) * SRS, cp + 16 * (t + 1), DSIR_MORE(true), c0 + 16 * t + fr);
+      step(fb, fa, bhp + 16 * (t + 2) * SRS, blp + 16 * (t + 2) * SRS, cp + 16 * (t + 2), DSIR_MORE(t + 2 < SBC / 16), c0 + 16 * (t + 1) + fr);
     }
+#ifndef DSIR_ABL_NOSTAGE
     lstore(pre, buf ^ 1);
     gload(pre, c0 + 3 * SBC);                         // clamped addresses: harmless past the range
     __syncthreads();
+#endif
   };
 #undef DSIR_MFMA
   gload(preA, c_begin);
