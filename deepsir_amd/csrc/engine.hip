@@ -381,7 +381,9 @@ struct Sched {
     return y;
   }
   // Att_pooling up to (not including) its MLP2D: softmax_k(fc [gather(f); enc]) . [gather(f); enc]
-  Act att(const AttW& w, const Act& f, const Act& enc, const int32_t* neigh, int64_t neigh_cs, int n) {
+  // s2 / s2_mode: optional cache of the enc half of the scores (kernels.h, GemmArgs::s2)
+  Act att(const AttW& w, const Act& f, const Act& enc, const int32_t* neigh, int64_t neigh_cs, int n, float* s2 = nullptr,
+          int s2_mode = 0) {
     Act y;
     y.p = c->ws.get<float>((size_t)clouds * n * w.d);
     y.C = w.d; y.rows = n;
@@ -401,6 +403,7 @@ struct Sched {
       a2.W = w.fc + w.d / 2; a2.ldw = w.d; a2.bias = nullptr; a2.Cin = w.d / 2; a2.Cout = w.d; a2.M = n * kKnn;
       a2.clouds = clouds; a2.epi = EPI_ATT2; a2.Y = y.p; a2.y_cloud_stride = (int64_t)n * w.d; a2.ldy = w.d;
       a2.g = G; a2.g_cloud_stride = (int64_t)n * w.d; a2.fseg = seg_of(f, neigh, neigh_cs);
+      a2.s2 = s2; a2.s2_mode = s2 ? s2_mode : 0; a2.s2_cloud_stride = (int64_t)n * kKnn * w.d;
       // G's column order is the consumer's (up_fc_g): d <= 128 belongs to pw_stream.hip, d = 256 to pw_tile.hip
       if (w.d <= 128 ? launch_pw_stream(a2, st) : launch_pw_tile(a2, st)) return y;
     }
@@ -442,6 +445,7 @@ Seg plain_seg(const float* x, int64_t cloud_stride, int C, int ld, const int32_t
 // storage and re-used afterwards: same kernels, same inputs, same bits (SURVEY §7.2 loop invariants).
 struct EncCache {
   bool valid = false;
+  float* s2_buf[DSIR_MAX_LEVELS][2] = {};   // enc half of the attention scores (W2 enc / W2 enc2) of the split levels (d >= 64)
   float* enc_buf[DSIR_MAX_LEVELS] = {};
   float* enc2_buf[DSIR_MAX_LEVELS] = {};
   double* enc_stats[DSIR_MAX_LEVELS] = {};
@@ -475,13 +479,14 @@ int randla_forward(dsir_ctx* c, const RandlaW& w, const Seg& in0, const Seg* in1
     Act enc = reuse ? cache->enc[l]
                     : s.mlp2d_lse(b.lfa1, xyz_l, xyz_cs, nb_l, neigh_cs, n, cache ? cache->enc_buf[l] : nullptr,
                                   cache ? cache->enc_stats[l] : nullptr);
-    Act agg = s.att(b.att1, f, enc, nb_l, neigh_cs, n);
+    const int s2_mode = reuse ? 2 : 1;      // iteration 0 stores the pyramid-only half of the scores, later iterations load it
+    Act agg = s.att(b.att1, f, enc, nb_l, neigh_cs, n, cache ? cache->s2_buf[l][0] : nullptr, s2_mode);
     Act a1 = s.mlp2d(b.att1.mlp, Sched::seg_of(agg), nullptr, n, true);
     Act enc2 = reuse ? cache->enc2[l]
                      : s.mlp2d(b.lfa2, Sched::seg_of(enc), nullptr, n * kKnn, true, cache ? cache->enc2_buf[l] : nullptr,
                                cache ? cache->enc2_stats[l] : nullptr);
     if (cache && !reuse) { cache->enc[l] = enc; cache->enc2[l] = enc2; }
-    Act agg2 = s.att(b.att2, a1, enc2, nb_l, neigh_cs, n);
+    Act agg2 = s.att(b.att2, a1, enc2, nb_l, neigh_cs, n, cache ? cache->s2_buf[l][1] : nullptr, s2_mode);
     Act a2 = s.mlp2d(b.att2.mlp, Sched::seg_of(agg2), nullptr, n, true);
     Act mainb = s.mlp2d(b.mlp2, Sched::seg_of(a2), nullptr, n, false);
     Act skipb = s.mlp2d(b.skip, xin, nullptr, n, false);
@@ -669,6 +674,16 @@ int dsir_create(int device, const dsir_cfg* cfg, dsir_ctx** out) {
   const size_t clouds = (size_t)2 * cfg->max_pairs;
   const size_t per_cloud = (size_t)cfg->max_points * 2560 * sizeof(float) + ((size_t)1 << 22);
   c->ws.cap = clouds * per_cloud + ((size_t)64 << 20);
+  if (cfg->pipeline == DSIR_PIPELINE_ALIGN) {
+    // per pair: the inlier model's cached enc halves of the attention scores (EncCache::s2_buf), 2 x n_l x 16 x d_l floats
+    size_t s2 = 0;
+    int nl = cfg->max_points;
+    for (int l = 0; l < cfg->num_layers; ++l) {
+      if (cfg->d_out[l] >= 64) s2 += (size_t)2 * nl * kKnn * cfg->d_out[l] * sizeof(float) + 512;
+      nl /= cfg->sub_sampling_ratio[l];
+    }
+    c->ws.cap += (size_t)cfg->max_pairs * s2;
+  }
   if (hipMalloc((void**)&c->ws.base, c->ws.cap) != hipSuccess) {
     const size_t cap = c->ws.cap;
     hipStreamDestroy(c->stream);
@@ -1045,6 +1060,11 @@ static int register_enqueue(dsir_ctx* c, const dsir_pair_batch* in, int n_iter, 
       const size_t rows = (size_t)P * ps.nl[l] * kKnn, ch = (size_t)g.d_out[l] / 2;
       enc_cache.enc_buf[l] = ws.get<float>(rows * ch);
       enc_cache.enc2_buf[l] = ws.get<float>(rows * ch);
+      static const bool no_s2 = getenv("DSIR_NO_S2") != nullptr;   // A/B switch: recompute the enc half of the scores every iteration
+      if (g.d_out[l] >= 64 && !no_s2) {
+        enc_cache.s2_buf[l][0] = ws.get<float>(rows * (size_t)g.d_out[l]);
+        enc_cache.s2_buf[l][1] = ws.get<float>(rows * (size_t)g.d_out[l]);
+      }
       nstats += 2 * (size_t)P * 16;
     }
     double* cst = ws.get<double>(nstats);

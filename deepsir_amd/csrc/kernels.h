@@ -55,6 +55,13 @@ struct GemmArgs {
   const float* g = nullptr;
   int64_t g_cloud_stride = 0;
   Seg fseg = {};                // f [clouds][n][Cout/2] with its lazy GroupNorm; fseg.idx = neighbour index of every A row
+  // EPI_ATT2 only, optional: the enc half of the scores (W2 enc, the launch's own contraction) kept across launches.  In the
+  // inlier model it depends on the pyramid and the weights alone, so iteration 0 stores the accumulators
+  // (s2_mode 1) and the later iterations load them instead of contracting (s2_mode 2): same values, bit for bit.
+  // Layout [clouds][M/16][Cout/16][64 lanes][4]: the MFMA C fragments as they sit in registers.
+  float* s2 = nullptr;
+  int64_t s2_cloud_stride = 0;
+  int s2_mode = 0;
   int M = 0;                    // rows per cloud
   int clouds = 1;
   int epi = EPI_GN;

@@ -52,7 +52,7 @@ __device__ __forceinline__ int src_row(const Seg& s, int cloud, int row) {
   return s.idx ? s.idx[cloud * s.idx_cloud_stride + row] : row;
 }
 
-template <int KQ, int NT, int EPI, int MODE>
+template <int KQ, int NT, int EPI, int MODE, int SC = 0>   // SC: GemmArgs::s2_mode (EPI_ATT2 only)
 __global__ __launch_bounds__(256) void pw_stream_kernel(const GemmArgs p) {
   constexpr int BN = NT * 16;
   constexpr int CP = KQ * 4;  // padded Cin
@@ -301,12 +301,25 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const GemmArgs p) {
     const int rbase = tile * 16 + 4 * fq;   // C layout: col = lane & 15, row = 4 * (lane >> 4) + reg
 
     f32x4 acc[NT];
+    // cached enc-half scores: C fragments of tile `tile`, column tiles n0/16 .. n0/16 + NT
+    float4* s2p = (SC != 0) ? reinterpret_cast<float4*>(p.s2 + cloud * p.s2_cloud_stride) +
+                                  ((int64_t)tile * (p.Cout >> 4) + (n0 >> 4)) * 64 + lane
+                            : nullptr;
+    if (SC == 2) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int t = 0; t < NT; ++t) { const float4 v = s2p[t * 64]; acc[t] = f32x4{v.x, v.y, v.z, v.w}; }
+    } else {
 #pragma unroll
-    for (int s = 0; s < KQ; ++s)
+      for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.v[s], wf[t][s], acc[t], 0, 0, 0);
+      for (int s = 0; s < KQ; ++s)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.v[s], wf[t][s], acc[t], 0, 0, 0);
+      if (SC == 1) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) s2p[t * 64] = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+      }
+    }
 
     if (EPI == EPI_GN) {
       float* Y = p.Y + cloud * p.y_cloud_stride;
@@ -472,7 +485,7 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const GemmArgs p) {
   }
 }
 
-template <int KQ, int NT, int EPI, int MODE>
+template <int KQ, int NT, int EPI, int MODE, int SC = 0>
 void launch_s(const GemmArgs& a, hipStream_t st) {
   const int ntiles = (a.M + 15) / 16;
   const int gy = (a.Cout + NT * 16 - 1) / (NT * 16);
@@ -503,7 +516,7 @@ void launch_s(const GemmArgs& a, hipStream_t st) {
   GemmArgs b = a;
   b.grid_x = blocks; b.grid_y = gy;
   dim3 grid((unsigned)((int64_t)blocks * gy * a.clouds));
-  hipLaunchKernelGGL((pw_stream_kernel<KQ, NT, EPI, MODE>), grid, dim3(256), 0, st, b);
+  hipLaunchKernelGGL((pw_stream_kernel<KQ, NT, EPI, MODE, SC>), grid, dim3(256), 0, st, b);
 }
 
 template <int KQ, int NT, int MODE>
@@ -555,8 +568,19 @@ bool launch_pw_stream(const GemmArgs& a, hipStream_t st) {
     }
     if (a.epi == EPI_ATT2) {   // A = enc (Cin = d/2), Cout = d
       if (a.nseg != 1 || a.Cout != 2 * a.Cin || !a.g || !a.fseg.idx) return false;
-      if (KQ == 8) { launch_s<8, 4, EPI_ATT2, S_VEC>(a, st); return true; }     // d = 64
-      if (KQ == 16) { launch_s<16, 4, EPI_ATT2, S_VEC>(a, st); return true; }   // d = 128 (two column blocks)
+      const int sc = a.s2 ? a.s2_mode : 0;
+      if (KQ == 8) {                                                            // d = 64
+        if (sc == 1) launch_s<8, 4, EPI_ATT2, S_VEC, 1>(a, st);
+        else if (sc == 2) launch_s<8, 4, EPI_ATT2, S_VEC, 2>(a, st);
+        else launch_s<8, 4, EPI_ATT2, S_VEC>(a, st);
+        return true;
+      }
+      if (KQ == 16) {                                                           // d = 128 (two column blocks)
+        if (sc == 1) launch_s<16, 4, EPI_ATT2, S_VEC, 1>(a, st);
+        else if (sc == 2) launch_s<16, 4, EPI_ATT2, S_VEC, 2>(a, st);
+        else launch_s<16, 4, EPI_ATT2, S_VEC>(a, st);
+        return true;
+      }
       return false;
     }
     switch (KQ) {

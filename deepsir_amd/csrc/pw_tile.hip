@@ -45,7 +45,7 @@ __device__ __forceinline__ RowOff row_off(const GemmArgs& p, int cloud, int row)
   return r;
 }
 
-template <int RT, int EPI>
+template <int RT, int EPI, int SC = 0>   // SC: GemmArgs::s2_mode (EPI_ATT2 only)
 __global__ __launch_bounds__(256) void pw_tile_kernel(const GemmArgs p) {
   constexpr int BM = 64 * RT;
   constexpr int AV = BM / 32;     // float4 A loads per thread per chunk (BM*32/4/256)
@@ -190,10 +190,26 @@ __global__ __launch_bounds__(256) void pw_tile_kernel(const GemmArgs p) {
     }
   }
 
-  const int nchunks = p.Cin / BK;
-  gload(0);
-  lstore(0, 0);
-  __syncthreads();
+  // cached enc-half scores (kernels.h, GemmArgs::s2): C fragments of row tile (r0 >> 4) + rt, column tiles n0/16 .. +NT
+  float4* s2p = (SC != 0) ? reinterpret_cast<float4*>(p.s2 + cloud * p.s2_cloud_stride) +
+                                ((int64_t)((m0 + 16 * RT * w) >> 4) * (p.Cout >> 4) + (n0 >> 4)) * 64 + lane
+                          : nullptr;
+  const int nchunks = SC == 2 ? 0 : p.Cin / BK;      // loaded scores: no contraction, no staging
+  if (SC == 2) {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      const bool live = m0 + 16 * RT * w + 16 * rt < p.M;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const float4 v = live ? s2p[((int64_t)rt * (p.Cout >> 4) + t) * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+        acc[rt][t] = f32x4{v.x, v.y, v.z, v.w};
+      }
+    }
+  } else {
+    gload(0);
+    lstore(0, 0);
+    __syncthreads();
+  }
   int buf = 0;
   for (int kc = 0; kc < nchunks; ++kc) {
     const bool more = kc + 1 < nchunks;
@@ -217,6 +233,15 @@ __global__ __launch_bounds__(256) void pw_tile_kernel(const GemmArgs p) {
     buf ^= 1;
   }
 
+  if (SC == 1) {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+      if (m0 + 16 * RT * w + 16 * rt < p.M) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+          s2p[((int64_t)rt * (p.Cout >> 4) + t) * 64] = make_float4(acc[rt][t][0], acc[rt][t][1], acc[rt][t][2], acc[rt][t][3]);
+      }
+  }
   // ---- epilogues.  C layout: col = lane & 15, row = 4 * (lane >> 4) + reg.
   const int r0 = m0 + 16 * RT * w;
   float bv[NT];
@@ -519,10 +544,10 @@ bool launch_small_e(const GemmArgs& a, hipStream_t st) {
   }
 }
 
-template <int RT, int EPI>
+template <int RT, int EPI, int SC = 0>
 void launch_t(const GemmArgs& a, hipStream_t st) {
   dim3 grid((a.M + 64 * RT - 1) / (64 * RT), (a.Cout + BN - 1) / BN, a.clouds);
-  hipLaunchKernelGGL((pw_tile_kernel<RT, EPI>), grid, dim3(256), 0, st, a);
+  hipLaunchKernelGGL((pw_tile_kernel<RT, EPI, SC>), grid, dim3(256), 0, st, a);
 }
 
 template <int RT>
@@ -534,7 +559,9 @@ bool launch_e(const GemmArgs& a, hipStream_t st) {
     case EPI_ATT: launch_t<RT, EPI_ATT>(a, st); return true;
     case EPI_ATT2:
       if (a.nseg != 1 || a.Cout != 2 * a.Cin || a.Cin > 128 || !a.g || !a.fseg.idx) return false;
-      launch_t<RT, EPI_ATT2>(a, st);
+      if (a.s2 && a.s2_mode == 1) launch_t<RT, EPI_ATT2, 1>(a, st);
+      else if (a.s2 && a.s2_mode == 2) launch_t<RT, EPI_ATT2, 2>(a, st);
+      else launch_t<RT, EPI_ATT2>(a, st);
       return true;
     default: return false;
   }

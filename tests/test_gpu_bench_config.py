@@ -202,3 +202,23 @@ def test_graph_replay_after_weight_reload():
         assert torch.equal(second[k], want[k]), k
     assert not torch.equal(T0, want["transforms"])
     eng.close(); fresh.close()
+
+
+def test_hoisted_loop_invariants_are_bit_identical(tmp_path):
+    """The loop invariants hoisted out of the registration iterations - the inlier model's position-encoding layers and the
+    enc half of its attention scores (EncCache, csrc/engine.hip) - change nothing: recomputing them every iteration
+    (DSIR_NO_HOIST), or only the score halves (DSIR_NO_S2), gives the same bits.  Switches are read once per process."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for name, extra in (("hoisted", {}), ("no_s2", {"DSIR_NO_S2": "1"}), ("no_hoist", {"DSIR_NO_HOIST": "1"})):
+        out = str(tmp_path / f"{name}.npz")
+        env = {k: v for k, v in os.environ.items() if k not in ("DSIR_NO_S2", "DSIR_NO_HOIST")}
+        env.update(extra)
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "register_dump.py"), out, "3", "5000", "4"], env=env,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[name] = np.load(out)
+    for other in ("no_s2", "no_hoist"):
+        for k in ("idx", "logits", "transforms"):
+            assert np.array_equal(outs["hoisted"][k], outs[other][k]), f"{k} differs between hoisted and {other}"
