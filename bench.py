@@ -417,7 +417,7 @@ def main():
             if screened:
                 ex = screen_flops(P_launch, N, N)
                 roof.update({
-                    "kernel": "screen_kernel<2,8> (csrc/nn_screen.hip): fp16-split MFMA screening of the 64-channel descriptor arg-min "
+                    "kernel": "screen_kernel<4,8> (csrc/nn_screen.hip): fp16-split MFMA screening of the 64-channel descriptor arg-min "
                               "under a rigorous bound; the exact fp32 decision among the survivors follows in exact_pick_kernel / nn_match_kernel",
                     "dtype": "f16 in, f32 accumulate (v_mfma_f32_16x16x32_f16)",
                     "achieved": round(ex / (k_ms / 1e3) / 1e12, 3), "peak": PEAK_F16_MFMA_TFLOPS,

@@ -5,7 +5,7 @@
 // chip (fp32: 1/16 of fp16).  Only the ARG-MIN matters, so the contraction is first done approximately where a rigorous
 // error bound lets almost every column be discarded, and the exact fp32 formula is evaluated only for the survivors:
 //
-//   split   x = xh + 2^-11 xl + r,  xh = fp16(x) (flushed to 0 below 2^-14), xl = fp16((x - xh) 2^11)
+//   split   x = xh + 2^-11 xl + r,  xh = fp16(x) (flushed to 0 below 2^-14), xl = fp16((x - xh) 2^11); stored: 2^11 xh, xl
 //   S = |a|^2 + |b|^2 - 2 (ah.bh + 2^-11 (ah.bl + al.bh))     |S - D| <= d = 2^-15 (|a|^2 + |b|^2) + 2^-20
 //   screen  ONE pass of fp16 MFMAs (v_mfma_f32_16x16x32_f16, fp32 accumulate; 3/16 of the fp32 MFMA time).  Every lane
 //           keeps, for each of its rows, the two smallest lower bounds L = S - d among the columns it sees (its class:
@@ -24,13 +24,14 @@
 //           approximate value.
 //
 // Error budget, in units of M = |a|^2 + |b|^2 (|a||b| <= M/2): representation 2^-22 per element (3 2^-22 M with the
-// dropped al.bl term); fp32 accumulation: the kernel forms z' = 2^11 (c + ah.bh) + ah.bl + al.bh in ONE chain of six
-// MFMAs (192 exact fp16 products + the seed), pessimistically one fp32 rounding per addition relative to the sum of the
-// magnitudes 2^11 (|a||b| + |b|^2 / 2) <= 2^11 M: 198 2^-24 M on z, 2^-15.4 M after the factor 2; the reference's own
+// dropped al.bl term); fp32 accumulation: both high parts are stored pre-scaled by 2^11 (exact) and the kernel forms
+// z' = 2^22 (c + ah.bh) + 2^11 (ah.bl + al.bh) = 2^22 z in ONE chain of six MFMAs (192 exact fp16 products + the seed;
+// a pure power-of-two scaling: the roundings are those of the unscaled sum), pessimistically one fp32 rounding per
+// addition relative to the sum of the magnitudes (|a||b| + |b|^2 / 2) <= M: 198 2^-24 M on z, 2^-15.4 M after the factor 2; the reference's own
 // fmaf chain 64 * 2^-24 * 2 |a||b| <= 2^-18 M; final roundings 2^-22 M: 2.8e-5 M against 2^-15 M = 3.05e-5 M (measured on
 // unit descriptors: < 1e-6 against 6e-5).  Elements below 2^-25 lose their low part
 // (fp16 underflow): <= 2^-25 per element, 2^-21 (|a| + |b|) <= 2^-21 (1 + M/2) on the distance: the constant term 2^-20.
-// Elements with |x| > 16 (the 2^11 pre-scaling of the high part must stay inside fp16) or not finite: split16_kernel
+// Elements with |x| > 16 (the 2^11 pre-scaling of the high part must stay inside fp16: 2^15 < 65504) or not finite: split16_kernel
 // raises a flag and every pair is searched exhaustively (the engine's descriptors are L2-normalised, model.py:232-233,
 // and never take that path).
 #include <hip/hip_fp16.h>
@@ -56,7 +57,10 @@ constexpr int SBC = DSIR_SCREEN_BC;   // ref columns per LDS tile
 #define DSIR_SCREEN_SRS 80
 #endif
 #ifndef DSIR_SCREEN_RT
-#define DSIR_SCREEN_RT 2
+#define DSIR_SCREEN_RT 0      // row tiles per wave: 0 = chosen per launch (launch_nn_screen), 2 / 4 = forced
+#endif
+#ifndef DSIR_SCREEN_NWV
+#define DSIR_SCREEN_NWV 8
 #endif
 constexpr int SRS = DSIR_SCREEN_SRS;     // halfs per LDS row: 64 + 16 pad (160 B; measured 1 % faster than the 144 B of a minimal pad)
 constexpr int CAP = 16;     // entries kept per row; more => the row goes to the exhaustive kernel
@@ -83,7 +87,7 @@ __device__ __forceinline__ void split4(const float4 v, h4& h, h4& l, int32_t* __
   for (int k = 0; k < 4; ++k) {
     _Float16 t = (_Float16)f[k];
     if (fabsf((float)t) < 6.103515625e-05f) t = (_Float16)0.f;          // no fp16 subnormals in the high part
-    h[k] = t;
+    h[k] = t * (_Float16)2048.f;                                         // exact: |t| <= 16 and t is 0 or normal
     l[k] = (_Float16)((f[k] - (float)t) * 2048.0f);
   }
 }
@@ -117,13 +121,16 @@ __global__ __launch_bounds__(256) void split_norm_kernel(const float* __restrict
   if (l == 0) sq[row] = s;
 }
 
-// Block = NWV waves, wave w owns RT row tiles of 16 src rows whose fp16 fragments stay in registers; ref tiles of SBC
-// columns stream through double-buffered LDS (fetched two tiles ahead through registers).  XCD-aware work mapping as in
-// nn_match.hip.
+// Block = NWV waves, wave w owns RT row tiles of 16 src rows whose fp16 fragments stay in registers (RT = 4: two operand
+// sets of 8 registers per tile - 64 -, 224 VGPRs in all, two waves per SIMD); ref tiles of SBC columns stream through
+// double-buffered LDS (fetched two tiles ahead through registers).  XCD-aware work mapping as in nn_match.hip.
 //
-// ONE accumulator chain per row tile: the high part of the src fragment is pre-scaled by 2^11 (exact in fp16 for
-// |x| <= 16, which split4 enforces), so z' = 2^11 (c + ah.bh) + (ah.bl + al.bh) = 2^11 z comes out of six chained MFMAs
-// whose first C operand is 2^11 c, c = -(|b|^2 - d_b) / 2 from LDS: no VALU instruction joins the partial products.
+// ONE accumulator chain per row tile: with BOTH high parts pre-scaled by 2^11 (exact in fp16 for |x| <= 16, which split4
+// enforces) the three partial products carry the same factor, z' = 2^22 (c + ah.bh + 2^-11 (ah.bl + al.bh)), and come out
+// of six chained MFMAs whose first C operand is 2^22 c, c = -(|b|^2 - d_b) / 2 from LDS: no VALU instruction joins the
+// partial products, and the src side needs two operand sets (round 2 started with three: ah, 2^11 ah, al), which is
+// what lets a wave hold four row tiles: every ref fragment read from LDS then feeds four MFMA chains instead of two and a
+// staged tile serves 512 rows instead of 256 (1.243 -> 1.097 ms per 128-pair launch).
 // Ranking, per accumulator element, exactly four VALU instructions (v_med3_f32, v_cmp_gt_f32, v_cndmask_b32, v_max_f32;
 // inline asm, so no canonicalising v_max x, x and no re-association).  gfx950 overlaps a wave's VALU work with the matrix
 // pipe only marginally (tools/ubench/rank_overlap.hip: clustered, interleaved and role-staggered schedules all land within
@@ -181,8 +188,8 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(DSIR_S
   __syncthreads();
   if (s_skip) return;
 
-  // A fragments: lane holds row fr, channels 32 c + 8 fq .. +7; ahs = 2^11 ah (exact: |ah| <= 16)
-  h8 ahs[RT][2], ah[RT][2], al[RT][2];
+  // A fragments: lane holds row fr, channels 32 c + 8 fq .. +7; ah = 2^11 x (high part), al = 2^11 x (low part)
+  h8 ah[RT][2], al[RT][2];
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
     const int row = min(row0 + rt * 16 + fr, J - 1);
@@ -190,8 +197,6 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(DSIR_S
     for (int c = 0; c < 2; ++c) {
       ah[rt][c] = *reinterpret_cast<const h8*>(Ah + (arow + row) * 64 + 32 * c + 8 * fq);
       al[rt][c] = *reinterpret_cast<const h8*>(Al + (arow + row) * 64 + 32 * c + 8 * fq);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) ahs[rt][c][i] = ah[rt][c][i] * (_Float16)2048.f;
     }
   }
   // per C element (row 4 fq + r of tile rt, column class fr): the two largest z' and the column of the largest
@@ -222,7 +227,7 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(DSIR_S
       const int f = tid + NWV * 64 * i;
       const int col = c0 + (f >> 2);
       const float s = sb[brow + min(col, K - 1)];
-      pre.sb[i] = (col < c_end && f < SBC * 4) ? -1024.f * (s - kC1 * s) : -INFINITY;   // columns past the range never win
+      pre.sb[i] = (col < c_end && f < SBC * 4) ? -2097152.f * (s - kC1 * s) : -INFINITY;   // columns past the range never win
     }
   };
   auto lstore = [&](const Pre& pre, int buf) {
@@ -249,44 +254,36 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(DSIR_S
   // the fragment reads of the next step (`nxt`; skipped when !more)
   auto step = [&](const Frag& cur, Frag& nxt, const _Float16* bhp, const _Float16* blp, const float4* cp, bool more, int col) {
     f32x4 zN[RT];
+#define DSIR_RANK_ALL(r)                                                                          \
+    DSIR_FENCE();                                                                                 \
+    _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) DSIR_RANK(z1[rt][r], z2[rt][r], k1[rt][r], zP[rt][r], colP); \
+    DSIR_FENCE()
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) DSIR_MFMA(zN[rt], ahs[rt][0], cur.bh0, cur.cin);
+    for (int rt = 0; rt < RT; ++rt) DSIR_MFMA(zN[rt], ah[rt][0], cur.bh0, cur.cin);
     if (more) { nxt.bh0 = *reinterpret_cast<const h8*>(bhp); const float4 v = *cp; nxt.cin = f32x4{v.x, v.y, v.z, v.w}; }
-    DSIR_FENCE();
-    DSIR_RANK(z1[0][0], z2[0][0], k1[0][0], zP[0][0], colP);
-    if (RT > 1) DSIR_RANK(z1[RT - 1][0], z2[RT - 1][0], k1[RT - 1][0], zP[RT - 1][0], colP);
-    DSIR_FENCE();
+    DSIR_RANK_ALL(0);
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) DSIR_MFMA(zN[rt], ahs[rt][1], cur.bh1, zN[rt]);
+    for (int rt = 0; rt < RT; ++rt) DSIR_MFMA(zN[rt], ah[rt][1], cur.bh1, zN[rt]);
     if (more) nxt.bl0 = *reinterpret_cast<const h8*>(blp);
-    DSIR_FENCE();
-    DSIR_RANK(z1[0][1], z2[0][1], k1[0][1], zP[0][1], colP);
-    if (RT > 1) DSIR_RANK(z1[RT - 1][1], z2[RT - 1][1], k1[RT - 1][1], zP[RT - 1][1], colP);
-    DSIR_FENCE();
+    DSIR_RANK_ALL(1);
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) DSIR_MFMA(zN[rt], ah[rt][0], cur.bl0, zN[rt]);
     if (more) nxt.bh1 = *reinterpret_cast<const h8*>(bhp + 32);
-    DSIR_FENCE();
-    DSIR_RANK(z1[0][2], z2[0][2], k1[0][2], zP[0][2], colP);
-    if (RT > 1) DSIR_RANK(z1[RT - 1][2], z2[RT - 1][2], k1[RT - 1][2], zP[RT - 1][2], colP);
-    DSIR_FENCE();
+    DSIR_RANK_ALL(2);
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) DSIR_MFMA(zN[rt], al[rt][0], cur.bh0, zN[rt]);
     if (more) nxt.bl1 = *reinterpret_cast<const h8*>(blp + 32);
-    DSIR_FENCE();
-    DSIR_RANK(z1[0][3], z2[0][3], k1[0][3], zP[0][3], colP);
-    if (RT > 1) DSIR_RANK(z1[RT - 1][3], z2[RT - 1][3], k1[RT - 1][3], zP[RT - 1][3], colP);
-    DSIR_FENCE();
+    DSIR_RANK_ALL(3);
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) DSIR_MFMA(zN[rt], ah[rt][1], cur.bl1, zN[rt]);
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) DSIR_MFMA(zN[rt], al[rt][1], cur.bh1, zN[rt]);
+#undef DSIR_RANK_ALL
     DSIR_FENCE();
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) zP[rt] = zN[rt];
     colP = col;
   };
-  static_assert(RT <= 2, "the ranking slots above cover two row tiles");
   // one tile: ranks into (z1, z2, k1); `pre` holds the tile after it and is refilled with the one two further on
   auto tile = [&](int c0, int buf, Pre& pre) {
     const _Float16* bhp = &Bs[buf][0][fr * SRS + 8 * fq];
@@ -334,8 +331,8 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(DSIR_S
       const int rr = min(row, J - 1);
       const float san = sa[arow + rr];
       const float slo = san - kC1 * san - kC0;       // |a|^2 - d_a
-      // z' = 2^11 z: L = slo - 2 z = slo - 2^-10 z'
-      const float l1 = fmaf(z1[rt][r], -9.765625e-4f, slo), l2 = fmaf(z2[rt][r], -9.765625e-4f, slo);
+      // z' = 2^22 z: L = slo - 2 z = slo - 2^-21 z'
+      const float l1 = fmaf(z1[rt][r], -4.76837158203125e-7f, slo), l2 = fmaf(z2[rt][r], -4.76837158203125e-7f, slo);
       const int k = k1[rt][r];
       float u = INFINITY;
       if (k >= 0) u = l1 + kW * (kC1 * (san + sb[brow + k]) + kC0);
@@ -533,11 +530,12 @@ void launch_nn_screen(const float* a, const float* b, const void* ah, const void
     hipLaunchKernelGGL(screen_reset_kernel, dim3(blocks), dim3(256), 0, st, ovf, pairs, ovf_min, keep_gate ? 1 : 0, bad, umin, cnt,
                        packed, (int64_t)rows);
   }
-  constexpr int RT = DSIR_SCREEN_RT;
-#ifndef DSIR_SCREEN_NWV
-#define DSIR_SCREEN_NWV 8
-#endif
-  constexpr int NWV = DSIR_SCREEN_NWV;   // waves per block: 8 x 32 rows share one staged ref tile (the L2 -> LDS fill is the scarce resource)
+  constexpr int NWV = DSIR_SCREEN_NWV;   // waves per block: they share one staged ref tile (the L2 -> LDS fill is the scarce resource)
+  // row tiles per wave: four (512-row blocks: every ref fragment read from LDS feeds four MFMA chains, -12 % kernel time
+  // at J = 5000) unless the padding of J to whole blocks costs more than that
+  static const int force_rt = getenv("DSIR_SCREEN_RT") ? atoi(getenv("DSIR_SCREEN_RT")) : DSIR_SCREEN_RT;   // A/B hook
+  auto padded = [&](int rt) { const int64_t r = NWV * 16 * rt; return ((J + r - 1) / r) * r; };
+  const int RT = force_rt == 2 || force_rt == 4 ? force_rt : (0.88 * (double)padded(4) <= (double)padded(2) ? 4 : 2);
   const int rows_per_block = NWV * 16 * RT;
   const int rb_count = (J + rows_per_block - 1) / rows_per_block;
   const int64_t base = (int64_t)pairs * rb_count;
@@ -561,8 +559,12 @@ void launch_nn_screen(const float* a, const float* b, const void* ah, const void
   const _Float16 *Ah = reinterpret_cast<const _Float16*>(ah), *Al = reinterpret_cast<const _Float16*>(al);
   const _Float16 *Bh = reinterpret_cast<const _Float16*>(bh), *Bl = reinterpret_cast<const _Float16*>(bl);
   if (evk0) (void)hipEventRecord(evk0, st);
-  hipLaunchKernelGGL((screen_kernel<RT, NWV>), grid, dim3(NWV * 64), 0, st, Ah, Al, Bh, Bl, sa, sb, J, K, cols, rb_count, splits, umin,
-                     cnt, cand, ovf, rowlist, ovf_min);
+  if (RT == 4)
+    hipLaunchKernelGGL((screen_kernel<4, NWV>), grid, dim3(NWV * 64), 0, st, Ah, Al, Bh, Bl, sa, sb, J, K, cols, rb_count, splits, umin,
+                       cnt, cand, ovf, rowlist, ovf_min);
+  else
+    hipLaunchKernelGGL((screen_kernel<2, NWV>), grid, dim3(NWV * 64), 0, st, Ah, Al, Bh, Bl, sa, sb, J, K, cols, rb_count, splits, umin,
+                       cnt, cand, ovf, rowlist, ovf_min);
   if (evk1) (void)hipEventRecord(evk1, st);
   hipLaunchKernelGGL(exact_pick_kernel, dim3((J + 255) / 256, pairs), dim3(256), 0, st, a, b, sa, sb, J, K, umin, cnt, cand, ovf,
                      ovf_min, rowlist, idx);
