@@ -553,6 +553,8 @@ void launch_nn_screen(const float* a, const float* b, const void* ah, const void
     eff *= (double)tiles / (double)(tiles_per * nsp);
     if (eff > best_eff + 1e-9) { best_eff = eff; splits = sp; }
   }
+  static const int force_splits = getenv("DSIR_SCREEN_SPLITS") ? atoi(getenv("DSIR_SCREEN_SPLITS")) : 0;   // tuning hook
+  if (force_splits > 0) splits = force_splits < tiles ? force_splits : tiles;
   const int cols = ((tiles + splits - 1) / splits) * SBC;
   splits = (K + cols - 1) / cols;
   const dim3 grid((unsigned)((int64_t)rb_count * splits * pairs));

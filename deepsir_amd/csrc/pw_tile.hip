@@ -428,24 +428,29 @@ __global__ __launch_bounds__(256) void pw_tile_small_kernel(const GemmArgs p) {
   const int act0 = p.seg[0].act, act1 = p.nseg > 1 ? p.seg[1].act : 0;
   __syncthreads();
 
-  float4 ra[RTS], rw[2];
-  auto gload = [&](int k0) {
+  // two register sets: a chunk is fetched two iterations before it is stored to LDS (a chunk's 8 MFMA steps hide only a
+  // fraction of one L2 round trip; with a single launch on the chip - batch 1 - the K loop runs at load latency)
+  struct Pre { float4 a[RTS], w[2]; };
+  Pre preA, preB;
+  const int nchunks = p.Cin / BK;
+  auto gload = [&](Pre& pre, int kc) {
+    const int k0 = min(kc, nchunks - 1) * BK;    // clamped: a fetch past the end is harmless and never stored
     const int c = k0 + c4;
     const bool s1 = c >= C0;
     const float* base = s1 ? p.seg[1].x : p.seg[0].x;
 #pragma unroll
-    for (int i = 0; i < RTS; ++i) ra[i] = *reinterpret_cast<const float4*>(base + (s1 ? ro[i].o1 : ro[i].o0) + (s1 ? c - C0 : c));
+    for (int i = 0; i < RTS; ++i) pre.a[i] = *reinterpret_cast<const float4*>(base + (s1 ? ro[i].o1 : ro[i].o0) + (s1 ? c - C0 : c));
 #pragma unroll
-    for (int i = 0; i < 2; ++i) rw[i] = *reinterpret_cast<const float4*>(wrow[i] + k0);
+    for (int i = 0; i < 2; ++i) pre.w[i] = *reinterpret_cast<const float4*>(wrow[i] + k0);
   };
-  auto lstore = [&](int k0, int buf) {
+  auto lstore = [&](const Pre& pre, int k0, int buf) {
     const int c = k0 + c4;
     const float slope = ((c >= C0) ? act1 : act0) ? 0.2f : 1.f;
     const float4 sc = *reinterpret_cast<const float4*>(&s_sc[c]);
     const float4 sh = *reinterpret_cast<const float4*>(&s_sh[c]);
 #pragma unroll
     for (int i = 0; i < RTS; ++i) {
-      float4 v = ra[i];
+      float4 v = pre.a[i];
       v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y); v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
       v.x = fmaxf(v.x, slope * v.x); v.y = fmaxf(v.y, slope * v.y);
       v.z = fmaxf(v.z, slope * v.z); v.w = fmaxf(v.w, slope * v.w);
@@ -456,8 +461,8 @@ __global__ __launch_bounds__(256) void pw_tile_small_kernel(const GemmArgs p) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       float2* dw = reinterpret_cast<float2*>(&Ws[buf][(sr0 + 32 * i) * LDS_LD + c4]);
-      dw[0] = make_float2(rw[i].x, rw[i].y);
-      dw[1] = make_float2(rw[i].z, rw[i].w);
+      dw[0] = make_float2(pre.w[i].x, pre.w[i].y);
+      dw[1] = make_float2(pre.w[i].z, pre.w[i].w);
     }
   };
   f32x4 acc[RTS][NTW];
@@ -465,14 +470,8 @@ __global__ __launch_bounds__(256) void pw_tile_small_kernel(const GemmArgs p) {
   for (int rt = 0; rt < RTS; ++rt)
 #pragma unroll
     for (int t = 0; t < NTW; ++t) acc[rt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int nchunks = p.Cin / BK;
-  gload(0);
-  lstore(0, 0);
-  __syncthreads();
-  int buf = 0;
-  for (int kc = 0; kc < nchunks; ++kc) {
-    const bool more = kc + 1 < nchunks;
-    if (more) gload((kc + 1) * BK);
+  // chunk kc from LDS buffer `buf`; `pre` holds chunk kc + 1 (stored to the other buffer) and is refilled with kc + 3
+  auto chunk = [&](int kc, int buf, Pre& pre) {
     const float* At = As[buf];
     const float* Wt = Ws[buf];
 #pragma unroll
@@ -487,9 +486,20 @@ __global__ __launch_bounds__(256) void pw_tile_small_kernel(const GemmArgs p) {
 #pragma unroll
         for (int t = 0; t < NTW; ++t) acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt], b[t], acc[rt][t], 0, 0, 0);
     }
-    if (more) lstore((kc + 1) * BK, buf ^ 1);
+    if (kc + 1 < nchunks) {
+      lstore(pre, (kc + 1) * BK, buf ^ 1);
+      gload(pre, kc + 3);
+    }
     __syncthreads();
-    buf ^= 1;
+  };
+  gload(preA, 0);
+  lstore(preA, 0, 0);
+  gload(preA, 1);
+  gload(preB, 2);
+  __syncthreads();
+  for (int kc = 0; kc < nchunks; kc += 2) {
+    chunk(kc, 0, preA);
+    if (kc + 1 < nchunks) chunk(kc + 1, 1, preB);
   }
   // ---- epilogue.  C layout: col = lane & 15, row = 4 * (lane >> 4) + reg.
   float* Y = p.Y + cloud * p.y_cloud_stride;
