@@ -9,8 +9,8 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 ROOT = os.path.dirname(PKG)
-SOURCES = ["engine.hip", "pw_gemm.hip", "pw_stream.hip", "pw_tile.hip", "head_mlp.hip", "agg_chain.hip", "select.hip", "misc.hip", "knn.hip", "knn_grid.hip", "score.hip", "nn_match.hip", "nn_screen.hip", "kabsch.hip", "icp.hip", "finetune.hip", "align_loss.hip", "metrics.hip", "preprocess.hip"]
-HEADERS = ["kernels.h", "device_utils.h", "svd3.h", os.path.join(ROOT, "include", "dsir.h")]
+SOURCES = ["engine.hip", "pw_gemm.hip", "pw_stream.hip", "pw_tile.hip", "head_mlp.hip", "agg_chain.hip", "select.hip", "misc.hip", "knn.hip", "knn_grid.hip", "score.hip", "nn_match.hip", "nn_screen.hip", "kabsch.hip", "icp.hip", "finetune.hip", "align_loss.hip", "train_ops.hip", "metrics.hip", "preprocess.hip"]
+HEADERS = ["kernels.h", "device_utils.h", "svd3.h", os.path.join(ROOT, "include", "dsir.h"), os.path.join(ROOT, "include", "dsir_train.h")]
 OUT = os.path.join(PKG, "libdsir.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"),
          "-I" + HERE, "-Wall", "-Wno-unused-function", "-Wno-unused-value"]
@@ -53,7 +53,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     # the plain C++ host over the C ABI (examples/cabi_register.cpp): links against libdsir.so only
     ex_src = os.path.join(ROOT, "examples", "cabi_register.cpp")
     ex_bin = os.path.join(ROOT, "examples", "cabi_register")
-    if os.path.exists(ex_src) and (force or not _newer(ex_bin, [ex_src, OUT, os.path.join(ROOT, "include", "dsir.h")])):
+    if os.path.exists(ex_src) and (force or not _newer(ex_bin, [ex_src, OUT, os.path.join(ROOT, "include", "dsir.h"), os.path.join(ROOT, "include", "dsir_train.h")])):
         run([hipcc, "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), ex_src, "-o", ex_bin,
              "-L" + PKG, "-ldsir", "-Wl,-rpath," + PKG, "-Wl,-rpath,$ORIGIN/../deepsir_amd"])
     return OUT

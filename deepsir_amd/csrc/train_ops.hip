@@ -1,0 +1,590 @@
+// Training operators (include/dsir_train.h): forward-with-saved-activations and backward of the ATen calls RandLA.forward
+// makes (reference network/RandLANet.py:140-230, :311-408), point-major fp32.  The inference engine (engine.hip) fuses and
+// never materialises most of these tensors; a training step needs them all, so this path is layer by layer: one
+// exact-fp32 MFMA GEMM for every 1x1 convolution (forward, d input, d weight), and row-streaming kernels around it.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <cmath>
+
+#include "device_utils.h"
+#include "dsir_train.h"
+
+namespace dsir {
+namespace {
+
+constexpr int TB = 64;        // GEMM tile: 64 rows x 64 columns
+constexpr int TK = 16;        // K chunk
+constexpr int TLD = TK + 2;   // LDS row (floats): fragment reads (row r, k = 4 s + q) hit banks 2 r + q
+
+// Y[r][n] = beta Y[r][n] + bias[n] + sum_k X[r][k] W[n wn + k wk]; block = 4 waves, wave w owns rows 16 w .. 16 w + 15
+__global__ __launch_bounds__(256) void t_gemm_kernel(const float* __restrict__ X, int ldx, const float* __restrict__ W, int wn, int wk,
+                                                     const float* __restrict__ bias, float* __restrict__ Y, int ldy, int64_t rows,
+                                                     int K, int N, float beta) {
+  __shared__ float Xs[TB * TLD];
+  __shared__ float Ws[TB * TLD];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int64_t m0 = (int64_t)blockIdx.x * TB;
+  const int n0 = blockIdx.y * TB;
+  const int sr = tid >> 2, sk = (tid & 3) * 4;          // staging: row / column sr, four consecutive k
+  const int64_t xr = m0 + sr;
+  const int wc = n0 + sr;
+  f32x4 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < K; k0 += TK) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = k0 + sk + u;
+      Xs[sr * TLD + sk + u] = (xr < rows && k < K) ? X[xr * ldx + k] : 0.f;
+      Ws[sr * TLD + sk + u] = (wc < N && k < K) ? W[(int64_t)wc * wn + (int64_t)k * wk] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < TK / 4; ++s) {
+      const float a = Xs[(16 * w + fr) * TLD + 4 * s + fq];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Ws[(16 * t + fr) * TLD + 4 * s + fq], acc[t], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int n = n0 + 16 * t + fr;
+    if (n >= N) continue;
+    const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t row = m0 + 16 * w + 4 * fq + r;
+      if (row < rows) {
+        float v = acc[t][r] + bv;
+        if (beta != 0.f) v += beta * Y[row * ldy + n];
+        Y[row * ldy + n] = v;
+      }
+    }
+  }
+}
+
+// partial[split][n][k'] = sum over the split's rows of dY[r][n] X'[r][k'], X' = [X, 1] when the bias column is wanted
+constexpr int DLD = TB + 16;   // LDS row of the transposed-use tiles: (k-row q, column fr) -> banks 16 q + fr
+__global__ __launch_bounds__(256) void t_gemm_dw_kernel(const float* __restrict__ dY, int ldy, const float* __restrict__ X, int ldx,
+                                                        int64_t rows, int64_t rows_per_split, int N, int K, int Kp,
+                                                        float* __restrict__ partial) {
+  __shared__ float As[TK * DLD];
+  __shared__ float Bs[TK * DLD];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int n0 = blockIdx.x * TB, k0 = blockIdx.y * TB;
+  const int64_t r_begin = (int64_t)blockIdx.z * rows_per_split;
+  const int64_t r_end = min(rows, r_begin + rows_per_split);
+  const int sr = tid >> 4, sc = (tid & 15) * 4;         // staging: row sr of the chunk, four consecutive columns
+  f32x4 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int64_t r0 = r_begin; r0 < r_end; r0 += TK) {
+    const int64_t r = r0 + sr;
+    const bool rin = r < r_end;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int n = n0 + sc + u, k = k0 + sc + u;
+      As[sr * DLD + sc + u] = (rin && n < N) ? dY[r * ldy + n] : 0.f;
+      Bs[sr * DLD + sc + u] = !rin ? 0.f : (k < K ? X[r * ldx + k] : (k == K && Kp > K ? 1.f : 0.f));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < TK / 4; ++s) {
+      const float a = As[(4 * s + fq) * DLD + 16 * w + fr];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Bs[(4 * s + fq) * DLD + 16 * t + fr], acc[t], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  float* P = partial + (int64_t)blockIdx.z * N * Kp;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int k = k0 + 16 * t + fr;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + 16 * w + 4 * fq + r;
+      if (n < N && k < Kp) P[(int64_t)n * Kp + k] = acc[t][r];
+    }
+  }
+}
+
+__global__ void t_gemm_dw_reduce_kernel(const float* __restrict__ partial, int splits, int N, int K, int Kp, float* __restrict__ dW,
+                                        float* __restrict__ db) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (int64_t)N * Kp) return;
+  const int n = (int)(e / Kp), k = (int)(e % Kp);
+  float s = 0.f;
+  for (int i = 0; i < splits; ++i) s += partial[(int64_t)i * N * Kp + e];
+  if (k < K) dW[(int64_t)n * K + k] += s;
+  else if (db) db[n] += s;
+}
+
+// ---- GroupNorm / BatchNorm(train) -------------------------------------------------------------------------------------
+// one block per (cloud, group): mean and 1 / sqrt(var + eps) over M rows x gw channels, fp64 accumulation
+__global__ __launch_bounds__(256) void t_gn_stats_kernel(const float* __restrict__ Y, int M, int C, int groups, float* __restrict__ stats) {
+  const int cloud = blockIdx.y, g = blockIdx.x, gw = C / groups;
+  const float* base = Y + (int64_t)cloud * M * C + g * gw;
+  double s1 = 0.0, s2 = 0.0;
+  const int64_t total = (int64_t)M * gw;
+  for (int64_t e = threadIdx.x; e < total; e += 256) {
+    const float v = base[(e / gw) * C + (e % gw)];
+    s1 += v; s2 += (double)v * v;
+  }
+  s1 = wave_sum(s1); s2 = wave_sum(s2);
+  __shared__ double sh[2][4];
+  if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = s1; sh[1][threadIdx.x >> 6] = s2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double a = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3], b = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+    const double mean = a / (double)total;
+    double var = b / (double)total - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    stats[((int64_t)cloud * groups + g) * 2] = (float)mean;
+    stats[((int64_t)cloud * groups + g) * 2 + 1] = (float)(1.0 / sqrt(var + 1e-5));
+  }
+}
+
+__global__ void t_gn_apply_kernel(const float* __restrict__ Y, const float* __restrict__ stats, int M, int C, int groups,
+                                  const float* __restrict__ gamma, const float* __restrict__ beta, int act, float* __restrict__ out,
+                                  int64_t total) {
+  const int gw = C / groups;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(e % C);
+    const int64_t cloud = e / ((int64_t)M * C);
+    const float* st = stats + (cloud * groups + c / gw) * 2;
+    float v = (Y[e] - st[0]) * st[1] * gamma[c] + beta[c];
+    if (act && !(v > 0.f)) v *= 0.2f;
+    out[e] = v;
+  }
+}
+
+// per (cloud, channel): s1 = sum_r g, s2 = sum_r g xhat, g = dOut * slope(v); block = 32 channels x 8 row lanes
+__global__ __launch_bounds__(256) void t_gn_bwd_sums_kernel(const float* __restrict__ dOut, const float* __restrict__ Y,
+                                                            const float* __restrict__ stats, int M, int C, int groups,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta, int act,
+                                                            float* __restrict__ sums) {
+  const int cloud = blockIdx.y;
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), ry = threadIdx.x >> 5;
+  const int gw = C / groups;
+  double s1 = 0.0, s2 = 0.0;
+  if (c < C) {
+    const float* st = stats + ((int64_t)cloud * groups + c / gw) * 2;
+    const float mean = st[0], rstd = st[1], ga = gamma[c], be = beta[c];
+    for (int r = ry; r < M; r += 8) {
+      const int64_t e = ((int64_t)cloud * M + r) * C + c;
+      const float xh = (Y[e] - mean) * rstd;
+      float g = dOut[e];
+      if (act && !(xh * ga + be > 0.f)) g *= 0.2f;
+      s1 += g; s2 += (double)g * xh;
+    }
+  }
+  __shared__ double sh[2][8][32];
+  sh[0][ry][threadIdx.x & 31] = s1; sh[1][ry][threadIdx.x & 31] = s2;
+  __syncthreads();
+  if (ry == 0 && c < C) {
+    double a = 0.0, b = 0.0;
+    for (int i = 0; i < 8; ++i) { a += sh[0][i][threadIdx.x]; b += sh[1][i][threadIdx.x]; }
+    sums[((int64_t)cloud * C + c) * 2] = (float)a;
+    sums[((int64_t)cloud * C + c) * 2 + 1] = (float)b;
+  }
+}
+
+// dY = rstd (gamma g - mean_group(gamma g) - xhat mean_group(gamma g xhat)); one block per (row range, cloud)
+__global__ __launch_bounds__(256) void t_gn_bwd_apply_kernel(const float* __restrict__ dOut, const float* __restrict__ Y,
+                                                             const float* __restrict__ stats, const float* __restrict__ sums, int M,
+                                                             int C, int groups, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, int act, float* __restrict__ dY,
+                                                             int rows_per_block) {
+  extern __shared__ float gm[];   // [groups][2]: mean(gamma g), mean(gamma g xhat)
+  const int cloud = blockIdx.y, gw = C / groups;
+  for (int g = threadIdx.x; g < groups; g += 256) {
+    double a = 0.0, b = 0.0;
+    for (int c = g * gw; c < (g + 1) * gw; ++c) {
+      a += (double)gamma[c] * sums[((int64_t)cloud * C + c) * 2];
+      b += (double)gamma[c] * sums[((int64_t)cloud * C + c) * 2 + 1];
+    }
+    const double inv = 1.0 / ((double)M * gw);
+    gm[2 * g] = (float)(a * inv); gm[2 * g + 1] = (float)(b * inv);
+  }
+  __syncthreads();
+  const int r0 = blockIdx.x * rows_per_block;
+  const int64_t n = (int64_t)min(rows_per_block, M - r0) * C;
+  const int64_t base = ((int64_t)cloud * M + r0) * C;
+  for (int64_t i = threadIdx.x; i < n; i += 256) {
+    const int64_t e = base + i;
+    const int c = (int)(e % C), g = c / gw;
+    const float* st = stats + ((int64_t)cloud * groups + g) * 2;
+    const float xh = (Y[e] - st[0]) * st[1];
+    float d = dOut[e];
+    if (act && !(xh * gamma[c] + beta[c] > 0.f)) d *= 0.2f;
+    dY[e] = st[1] * (gamma[c] * d - gm[2 * g] - xh * gm[2 * g + 1]);
+  }
+}
+
+__global__ void t_gn_bwd_params_kernel(const float* __restrict__ sums, int clouds, int C, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float a = 0.f, b = 0.f;
+  for (int i = 0; i < clouds; ++i) { a += sums[((int64_t)i * C + c) * 2]; b += sums[((int64_t)i * C + c) * 2 + 1]; }
+  dbeta[c] += a;
+  dgamma[c] += b;
+}
+
+// ---- gathers ----------------------------------------------------------------------------------------------------------
+__global__ void t_gather_kernel(const float* __restrict__ X, int n, int C, const int32_t* __restrict__ idx, int m, float* __restrict__ Y,
+                                int ldy, int col_off, int64_t total) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(e % C);
+    const int64_t j = e / C;                 // cloud * m + j
+    const int64_t cloud = j / m;
+    int i = idx[j];
+    i = i < 0 ? 0 : (i >= n ? n - 1 : i);
+    Y[j * ldy + col_off + c] = X[(cloud * n + i) * C + c];
+  }
+}
+
+__global__ void t_scatter_add_kernel(const float* __restrict__ dY, int ldy, int col_off, const int32_t* __restrict__ idx, int m,
+                                     float* __restrict__ dX, int n, int C, int64_t total) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(e % C);
+    const int64_t j = e / C;
+    const int64_t cloud = j / m;
+    int i = idx[j];
+    i = i < 0 ? 0 : (i >= n ? n - 1 : i);
+    atomicAdd(dX + (cloud * n + i) * C + c, dY[j * ldy + col_off + c]);
+  }
+}
+
+__global__ void t_relpos_kernel(const float* __restrict__ xyz, const int32_t* __restrict__ idx, int n, int k, float* __restrict__ out,
+                                int64_t total) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = e / k;                 // cloud * n + i
+    const int64_t cloud = p / n;
+    int j = idx[e];
+    j = j < 0 ? 0 : (j >= n ? n - 1 : j);
+    const float* pi = xyz + p * 3;
+    const float* pj = xyz + (cloud * n + j) * 3;
+    const float dx = pj[0] - pi[0], dy = pj[1] - pi[1], dz = pj[2] - pi[2];
+    float* o = out + e * 10;
+    o[0] = sqrtf(dx * dx + dy * dy + dz * dz);
+    o[1] = dx; o[2] = dy; o[3] = dz;
+    o[4] = pi[0]; o[5] = pi[1]; o[6] = pi[2];
+    o[7] = pj[0]; o[8] = pj[1]; o[9] = pj[2];
+  }
+}
+
+// the inlier model's input of one registration iteration (model.py:571-573 with :587): [T x_src ; x_ref[idx]]
+__global__ void t_inlier_input_kernel(const float* __restrict__ xs, const float* __restrict__ xr, const int32_t* __restrict__ idx,
+                                      const float* __restrict__ T, int t_stride, int J, int K, float* __restrict__ out, int64_t total) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t pair = e / J;
+    const float* p = xs + e * 3;
+    float x = p[0], y = p[1], z = p[2];
+    if (T) {
+      const float* t = T + pair * t_stride;
+      const float a = t[0] * x + t[1] * y + t[2] * z + t[3];
+      const float b = t[4] * x + t[5] * y + t[6] * z + t[7];
+      const float c = t[8] * x + t[9] * y + t[10] * z + t[11];
+      x = a; y = b; z = c;
+    }
+    int i = idx[e];
+    i = i < 0 ? 0 : (i >= K ? K - 1 : i);
+    const float* q = xr + (pair * K + i) * 3;
+    float* o = out + e * 6;
+    o[0] = x; o[1] = y; o[2] = z; o[3] = q[0]; o[4] = q[1]; o[5] = q[2];
+  }
+}
+
+// ---- attentive pooling ------------------------------------------------------------------------------------------------
+__global__ void t_attpool_fwd_kernel(const float* __restrict__ cat, float* __restrict__ S, int k, int C, float* __restrict__ out,
+                                     int64_t total) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(e % C);
+    const int64_t p = e / C;
+    const int64_t b = p * k * C + c;
+    float mx = -INFINITY;
+    for (int t = 0; t < k; ++t) mx = fmaxf(mx, S[b + (int64_t)t * C]);
+    float se = 0.f;
+    for (int t = 0; t < k; ++t) se += expf(S[b + (int64_t)t * C] - mx);
+    const float inv = 1.f / se;
+    float o = 0.f;
+    for (int t = 0; t < k; ++t) {
+      const float a = expf(S[b + (int64_t)t * C] - mx) * inv;
+      S[b + (int64_t)t * C] = a;
+      o += a * cat[b + (int64_t)t * C];
+    }
+    out[e] = o;
+  }
+}
+
+__global__ void t_attpool_bwd_kernel(const float* __restrict__ dOut, const float* __restrict__ cat, const float* __restrict__ A, int k,
+                                     int C, float* __restrict__ dCat, float* __restrict__ dS, int64_t total) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(e % C);
+    const int64_t p = e / C;
+    const int64_t b = p * k * C + c;
+    const float g = dOut[e];
+    float dot = 0.f;
+    for (int t = 0; t < k; ++t) dot += A[b + (int64_t)t * C] * cat[b + (int64_t)t * C];
+    dot *= g;                                // sum_t a_t (cat_t g)
+    for (int t = 0; t < k; ++t) {
+      const float a = A[b + (int64_t)t * C];
+      dCat[b + (int64_t)t * C] = a * g;
+      dS[b + (int64_t)t * C] = a * (cat[b + (int64_t)t * C] * g - dot);
+    }
+  }
+}
+
+// ---- pooling / element-wise ---------------------------------------------------------------------------------------------
+__global__ void t_maxpool_fwd_kernel(const float* __restrict__ X, int n, int C, const int32_t* __restrict__ pool, int m, int k,
+                                     float* __restrict__ out, int32_t* __restrict__ arg, int64_t total) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(e % C);
+    const int64_t j = e / C;                 // cloud * m + j
+    const int64_t cloud = j / m;
+    float best = -INFINITY;
+    int bi = 0;
+    for (int t = 0; t < k; ++t) {
+      int i = pool[j * k + t];
+      i = i < 0 ? 0 : (i >= n ? n - 1 : i);
+      const float v = X[(cloud * n + i) * C + c];
+      if (t == 0 || v > best) { best = v; bi = i; }
+    }
+    out[e] = best;
+    arg[e] = bi;
+  }
+}
+
+__global__ void t_maxpool_bwd_kernel(const float* __restrict__ dOut, const int32_t* __restrict__ arg, int m, int C, float* __restrict__ dX,
+                                     int n, int64_t total) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(e % C);
+    const int64_t cloud = (e / C) / m;
+    atomicAdd(dX + (cloud * n + arg[e]) * C + c, dOut[e]);
+  }
+}
+
+__global__ void t_add_leaky_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t n, float* __restrict__ out) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    float v = a[e] + b[e];
+    if (!(v > 0.f)) v *= 0.2f;
+    out[e] = v;
+  }
+}
+__global__ void t_add_leaky_bwd_kernel(const float* __restrict__ dOut, const float* __restrict__ out, int64_t n, float* __restrict__ d) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
+    d[e] = out[e] > 0.f ? dOut[e] : 0.2f * dOut[e];
+}
+__global__ void t_mul_mask_kernel(const float* __restrict__ x, const uint8_t* __restrict__ mask, float scale, int64_t n,
+                                  float* __restrict__ y) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
+    y[e] = mask[e] ? x[e] * scale : 0.f;
+}
+__global__ void t_axpy_kernel(float a, const float* __restrict__ x, int64_t n, float* __restrict__ y) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) y[e] += a * x[e];
+}
+__global__ void t_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                              int64_t n, float b1, float b2, float eps, float step_size, float inv_sqrt_bc2) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    const float gi = g[e];
+    const float mi = b1 * m[e] + (1.f - b1) * gi;
+    const float vi = b2 * v[e] + (1.f - b2) * gi * gi;
+    m[e] = mi; v[e] = vi;
+    p[e] -= step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+  }
+}
+
+// running statistics of nn.BatchNorm1d in training mode: running = (1 - momentum) running + momentum batch, the variance
+// unbiased (M / (M - 1)); stats [C][2] = {mean, rstd} of dsir_t_gn_fwd with groups = C
+__global__ void t_bn_running_kernel(const float* __restrict__ stats, int C, double M, float momentum, float* __restrict__ rmean,
+                                    float* __restrict__ rvar) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double mean = stats[2 * c], rstd = stats[2 * c + 1];
+  const double var = fmax(1.0 / (rstd * rstd) - 1e-5, 0.0) * (M > 1.0 ? M / (M - 1.0) : 1.0);
+  rmean[c] = (float)((1.0 - momentum) * rmean[c] + momentum * mean);
+  rvar[c] = (float)((1.0 - momentum) * rvar[c] + momentum * var);
+}
+
+inline unsigned grid1(int64_t n) { const int64_t g = (n + 255) / 256; return (unsigned)(g < 1 ? 1 : (g > 8192 ? 8192 : g)); }
+inline int done() { return (int)hipGetLastError(); }
+
+struct DwPlan { int splits; int64_t rows_per_split; int Kp; };
+inline DwPlan dw_plan(int64_t rows, int N, int K, bool bias) {
+  DwPlan p;
+  p.Kp = K + (bias ? 1 : 0);
+  const int64_t tiles = (int64_t)((N + TB - 1) / TB) * ((p.Kp + TB - 1) / TB);
+  int64_t sp = (rows + 511) / 512;                       // >= 512 rows per split
+  const int64_t cap = tiles >= 2048 ? 1 : 2048 / tiles;   // ~ 2048 workgroups in all
+  sp = sp > cap ? cap : sp;
+  sp = sp < 1 ? 1 : sp;
+  p.rows_per_split = (((rows + sp - 1) / sp) + TK - 1) / TK * TK;
+  p.splits = (int)((rows + p.rows_per_split - 1) / p.rows_per_split);
+  if (p.splits < 1) p.splits = 1;
+  return p;
+}
+
+}  // namespace
+}  // namespace dsir
+
+using namespace dsir;
+
+extern "C" {
+
+int dsir_t_gemm(void* stream, const float* X, int ldx, const float* W, int wn, int wk, const float* bias, float* Y, int ldy,
+                int64_t rows, int K, int N, float beta) {
+  if (!X || !W || !Y || rows < 1 || K < 1 || N < 1) return (int)hipErrorInvalidValue;
+  const dim3 grid((unsigned)((rows + TB - 1) / TB), (unsigned)((N + TB - 1) / TB));
+  hipLaunchKernelGGL(t_gemm_kernel, grid, dim3(256), 0, (hipStream_t)stream, X, ldx, W, wn, wk, bias, Y, ldy, rows, K, N, beta);
+  return done();
+}
+
+size_t dsir_t_gemm_dw_scratch(int64_t rows, int N, int K) {
+  const DwPlan p = dw_plan(rows, N, K, true);
+  return (size_t)p.splits * N * p.Kp * sizeof(float);
+}
+
+int dsir_t_gemm_dw(void* stream, const float* dY, int ldy, const float* X, int ldx, int64_t rows, int N, int K, float* dW, float* db,
+                   void* scratch) {
+  if (!dY || !X || !dW || !scratch || rows < 1 || K < 1 || N < 1) return (int)hipErrorInvalidValue;
+  const DwPlan p = dw_plan(rows, N, K, db != nullptr);
+  float* partial = reinterpret_cast<float*>(scratch);
+  const dim3 grid((unsigned)((N + TB - 1) / TB), (unsigned)((p.Kp + TB - 1) / TB), (unsigned)p.splits);
+  hipLaunchKernelGGL(t_gemm_dw_kernel, grid, dim3(256), 0, (hipStream_t)stream, dY, ldy, X, ldx, rows, p.rows_per_split, N, K, p.Kp,
+                     partial);
+  hipLaunchKernelGGL(t_gemm_dw_reduce_kernel, dim3(grid1((int64_t)N * p.Kp)), dim3(256), 0, (hipStream_t)stream, partial, p.splits, N, K,
+                     p.Kp, dW, db);
+  return done();
+}
+
+int dsir_t_gn_fwd(void* stream, const float* Y, int clouds, int M, int C, int groups, const float* gamma, const float* beta, int act,
+                  float* out, float* stats) {
+  if (!Y || !gamma || !beta || !out || !stats || clouds < 1 || M < 1 || C < 1 || groups < 1 || C % groups) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(t_gn_stats_kernel, dim3(groups, clouds), dim3(256), 0, (hipStream_t)stream, Y, M, C, groups, stats);
+  const int64_t total = (int64_t)clouds * M * C;
+  hipLaunchKernelGGL(t_gn_apply_kernel, dim3(grid1(total)), dim3(256), 0, (hipStream_t)stream, Y, stats, M, C, groups, gamma, beta, act, out,
+                     total);
+  return done();
+}
+
+int dsir_t_gn_bwd(void* stream, const float* dOut, const float* Y, const float* stats, int clouds, int M, int C, int groups,
+                  const float* gamma, const float* beta, int act, float* dY, float* dgamma, float* dbeta, float* scratch) {
+  if (!dOut || !Y || !stats || !gamma || !beta || !dY || !dgamma || !dbeta || !scratch || clouds < 1 || M < 1 || C < 1 || groups < 1 ||
+      C % groups || groups > 4096)
+    return (int)hipErrorInvalidValue;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(t_gn_bwd_sums_kernel, dim3((C + 31) / 32, clouds), dim3(256), 0, st, dOut, Y, stats, M, C, groups, gamma, beta, act,
+                     scratch);
+  int rpb = (int)(((int64_t)16384 + C - 1) / C);         // ~ 16 k elements per block
+  rpb = rpb < 1 ? 1 : rpb;
+  hipLaunchKernelGGL(t_gn_bwd_apply_kernel, dim3((M + rpb - 1) / rpb, clouds), dim3(256), (size_t)groups * 2 * sizeof(float), st, dOut, Y,
+                     stats, scratch, M, C, groups, gamma, beta, act, dY, rpb);
+  hipLaunchKernelGGL(t_gn_bwd_params_kernel, dim3((C + 255) / 256), dim3(256), 0, st, scratch, clouds, C, dgamma, dbeta);
+  return done();
+}
+
+int dsir_t_gather(void* stream, const float* X, int n, int C, const int32_t* idx, int m, int clouds, float* Y, int ldy, int col_off) {
+  if (!X || !idx || !Y || n < 1 || C < 1 || m < 1 || clouds < 1) return (int)hipErrorInvalidValue;
+  const int64_t total = (int64_t)clouds * m * C;
+  hipLaunchKernelGGL(t_gather_kernel, dim3(grid1(total)), dim3(256), 0, (hipStream_t)stream, X, n, C, idx, m, Y, ldy, col_off, total);
+  return done();
+}
+
+int dsir_t_scatter_add(void* stream, const float* dY, int ldy, int col_off, const int32_t* idx, int m, int clouds, float* dX, int n,
+                       int C) {
+  if (!dY || !idx || !dX || n < 1 || C < 1 || m < 1 || clouds < 1) return (int)hipErrorInvalidValue;
+  const int64_t total = (int64_t)clouds * m * C;
+  hipLaunchKernelGGL(t_scatter_add_kernel, dim3(grid1(total)), dim3(256), 0, (hipStream_t)stream, dY, ldy, col_off, idx, m, dX, n, C, total);
+  return done();
+}
+
+int dsir_t_relpos(void* stream, const float* xyz, const int32_t* idx, int n, int k, int clouds, float* out) {
+  if (!xyz || !idx || !out || n < 1 || k < 1 || clouds < 1) return (int)hipErrorInvalidValue;
+  const int64_t total = (int64_t)clouds * n * k;
+  hipLaunchKernelGGL(t_relpos_kernel, dim3(grid1(total)), dim3(256), 0, (hipStream_t)stream, xyz, idx, n, k, out, total);
+  return done();
+}
+
+int dsir_t_inlier_input(void* stream, const float* xyz_src, const float* xyz_ref, const int32_t* idx, const float* T, int t_stride,
+                        int pairs, int J, int K, float* out) {
+  if (!xyz_src || !xyz_ref || !idx || !out || pairs < 1 || J < 1 || K < 1) return (int)hipErrorInvalidValue;
+  const int64_t total = (int64_t)pairs * J;
+  hipLaunchKernelGGL(t_inlier_input_kernel, dim3(grid1(total)), dim3(256), 0, (hipStream_t)stream, xyz_src, xyz_ref, idx, T, t_stride, J, K,
+                     out, total);
+  return done();
+}
+
+int dsir_t_attpool_fwd(void* stream, const float* cat, float* S, int64_t points, int k, int C, float* out) {
+  if (!cat || !S || !out || points < 1 || k < 1 || C < 1) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(t_attpool_fwd_kernel, dim3(grid1(points * C)), dim3(256), 0, (hipStream_t)stream, cat, S, k, C, out, points * C);
+  return done();
+}
+
+int dsir_t_attpool_bwd(void* stream, const float* dOut, const float* cat, const float* A, int64_t points, int k, int C, float* dCat,
+                       float* dS) {
+  if (!dOut || !cat || !A || !dCat || !dS || points < 1 || k < 1 || C < 1) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(t_attpool_bwd_kernel, dim3(grid1(points * C)), dim3(256), 0, (hipStream_t)stream, dOut, cat, A, k, C, dCat, dS,
+                     points * C);
+  return done();
+}
+
+int dsir_t_maxpool_fwd(void* stream, const float* X, int n, int C, const int32_t* pool, int m, int k, int clouds, float* out,
+                       int32_t* arg) {
+  if (!X || !pool || !out || !arg || n < 1 || C < 1 || m < 1 || k < 1 || clouds < 1) return (int)hipErrorInvalidValue;
+  const int64_t total = (int64_t)clouds * m * C;
+  hipLaunchKernelGGL(t_maxpool_fwd_kernel, dim3(grid1(total)), dim3(256), 0, (hipStream_t)stream, X, n, C, pool, m, k, out, arg, total);
+  return done();
+}
+
+int dsir_t_maxpool_bwd(void* stream, const float* dOut, const int32_t* arg, int m, int C, int clouds, float* dX, int n) {
+  if (!dOut || !arg || !dX || n < 1 || C < 1 || m < 1 || clouds < 1) return (int)hipErrorInvalidValue;
+  const int64_t total = (int64_t)clouds * m * C;
+  hipLaunchKernelGGL(t_maxpool_bwd_kernel, dim3(grid1(total)), dim3(256), 0, (hipStream_t)stream, dOut, arg, m, C, dX, n, total);
+  return done();
+}
+
+int dsir_t_bn_running(void* stream, const float* stats, int C, int64_t M, float momentum, float* running_mean, float* running_var) {
+  if (!stats || !running_mean || !running_var || C < 1 || M < 1) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(t_bn_running_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats, C, (double)M, momentum,
+                     running_mean, running_var);
+  return done();
+}
+
+int dsir_t_add_leaky_fwd(void* stream, const float* a, const float* b, int64_t n, float* out) {
+  if (!a || !b || !out || n < 1) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(t_add_leaky_fwd_kernel, dim3(grid1(n)), dim3(256), 0, (hipStream_t)stream, a, b, n, out);
+  return done();
+}
+
+int dsir_t_add_leaky_bwd(void* stream, const float* dOut, const float* out, int64_t n, float* d) {
+  if (!dOut || !out || !d || n < 1) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(t_add_leaky_bwd_kernel, dim3(grid1(n)), dim3(256), 0, (hipStream_t)stream, dOut, out, n, d);
+  return done();
+}
+
+int dsir_t_mul_mask(void* stream, const float* x, const uint8_t* mask, float scale, int64_t n, float* y) {
+  if (!x || !mask || !y || n < 1) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(t_mul_mask_kernel, dim3(grid1(n)), dim3(256), 0, (hipStream_t)stream, x, mask, scale, n, y);
+  return done();
+}
+
+int dsir_t_axpy(void* stream, float a, const float* x, int64_t n, float* y) {
+  if (!x || !y || n < 1) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(t_axpy_kernel, dim3(grid1(n)), dim3(256), 0, (hipStream_t)stream, a, x, n, y);
+  return done();
+}
+
+int dsir_t_adam(void* stream, float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
+                int step) {
+  if (!p || !g || !m || !v || n < 1 || step < 1) return (int)hipErrorInvalidValue;
+  const double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
+  hipLaunchKernelGGL(t_adam_kernel, dim3(grid1(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, b1, b2, eps, (float)(lr / bc1),
+                     (float)(1.0 / sqrt(bc2)));
+  return done();
+}
+
+}  // extern "C"

@@ -1,0 +1,479 @@
+"""Training step of the inlier model on the device (the backward half of the `align` pipeline).
+
+The reference trains with torch autograd (train.py:379-448): ``Network.forward`` -> ``ScanAlignmentLoss`` ->
+``loss.backward()`` -> ``optim.Adam.step()``.  In ``forward_align_4`` the matching runs under ``no_grad`` and the src cloud is
+moved by ``R_t.detach()`` (network/model.py:556-588), so the alignment loss reaches exactly one sub-network: the inlier
+``RandLA`` (network/RandLANet.py:233-372), through its logits.  This module is that sub-network's training pass without
+autograd: ``RandlaTrainer.forward`` runs the layers in the reference's module order and keeps what the backward needs,
+``backward`` walks them in reverse from d loss / d logits (``Engine.align_loss_backward``) to every parameter, and
+``adam_step`` applies ``torch.optim.Adam``'s update rule.  Every tensor operation is a HIP kernel behind the C ABI of
+``include/dsir_train.h``; torch is used for device memory (allocation, views, copies into concatenation buffers) only.
+
+Layout: point-major ``[clouds][points][C]`` fp32, indices int32 - as everywhere in this package.  Parameters and
+gradients are keyed by the reference's state-dict names (deepsir_amd/arch.py).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from .arch import NetConfig, level_sizes, randla_specs
+
+K_NN = 16
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+class _Ops:
+    """The C ABI of include/dsir_train.h on torch device tensors (memory only) and torch's current HIP stream."""
+
+    def __init__(self, device: torch.device):
+        if device.type != "cuda":
+            raise RuntimeError("deepsir_amd.train needs a GPU: the training operators are HIP kernels, there is no CPU path")
+        self.lib = _lib.load()
+        self.device = device
+        self._scratch: Optional[torch.Tensor] = None
+
+    @property
+    def stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _ok(self, rc: int, what: str) -> None:
+        if rc != 0:
+            raise RuntimeError(f"{what} failed (hipError {rc})")
+
+    def scratch(self, nbytes: int) -> torch.Tensor:
+        if self._scratch is None or self._scratch.numel() * 4 < nbytes:
+            self._scratch = torch.empty((nbytes + 3) // 4 + 1024, dtype=torch.float32, device=self.device)
+        return self._scratch
+
+    def empty(self, *shape, dtype=torch.float32) -> torch.Tensor:
+        return torch.empty(*shape, dtype=dtype, device=self.device)
+
+    # ---- 1x1 convolutions
+    def conv(self, x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+        """x [rows][Cin] (contiguous), w [Cout][Cin...] -> [rows][Cout]."""
+        rows, cin = x.shape[0], x.shape[1]
+        cout = w.shape[0]
+        y = self.empty(rows, cout)
+        self._ok(self.lib.dsir_t_gemm(self.stream, _ptr(x), cin, _ptr(w), cin, 1, _ptr(bias), _ptr(y), cout, rows, cin, cout, 0.0),
+                 "dsir_t_gemm")
+        return y
+
+    def conv_dx(self, dy: torch.Tensor, w: torch.Tensor, into: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """dX = dY W; `into` (contiguous [rows][Cin]): accumulate."""
+        rows, cout = dy.shape
+        cin = w.numel() // cout
+        dx = into if into is not None else self.empty(rows, cin)
+        self._ok(self.lib.dsir_t_gemm(self.stream, _ptr(dy), cout, _ptr(w), 1, cin, None, _ptr(dx), cin, rows, cout, cin,
+                                      1.0 if into is not None else 0.0), "dsir_t_gemm (dX)")
+        return dx
+
+    def conv_dw(self, dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, db: Optional[torch.Tensor]) -> None:
+        rows, cout = dy.shape
+        cin = x.shape[1]
+        sc = self.scratch(self.lib.dsir_t_gemm_dw_scratch(rows, cout, cin))
+        self._ok(self.lib.dsir_t_gemm_dw(self.stream, _ptr(dy), cout, _ptr(x), cin, rows, cout, cin, _ptr(dw), _ptr(db), _ptr(sc)),
+                 "dsir_t_gemm_dw")
+
+    # ---- normalisation
+    def gn_fwd(self, y: torch.Tensor, clouds: int, groups: int, gamma, beta, act: bool):
+        C_ = y.shape[1]
+        M = y.shape[0] // clouds
+        out = self.empty(y.shape[0], C_)
+        stats = self.empty(clouds, groups, 2)
+        self._ok(self.lib.dsir_t_gn_fwd(self.stream, _ptr(y), clouds, M, C_, groups, _ptr(gamma), _ptr(beta), int(act), _ptr(out),
+                                        _ptr(stats)), "dsir_t_gn_fwd")
+        return out, stats
+
+    def gn_bwd(self, dout, y, stats, clouds, groups, gamma, beta, act, dgamma, dbeta) -> torch.Tensor:
+        C_ = y.shape[1]
+        M = y.shape[0] // clouds
+        dy = self.empty(y.shape[0], C_)
+        sc = self.scratch(clouds * C_ * 2 * 4)
+        self._ok(self.lib.dsir_t_gn_bwd(self.stream, _ptr(dout), _ptr(y), _ptr(stats), clouds, M, C_, groups, _ptr(gamma), _ptr(beta),
+                                        int(act), _ptr(dy), _ptr(dgamma), _ptr(dbeta), _ptr(sc)), "dsir_t_gn_bwd")
+        return dy
+
+    # ---- gathers
+    def gather(self, x: torch.Tensor, idx: torch.Tensor, out: torch.Tensor, col_off: int) -> None:
+        """x [clouds][n][C], idx [clouds][m] -> out[clouds * m][col_off : col_off + C] (out's row length = its ld)."""
+        clouds, n, C_ = x.shape
+        m = idx.shape[1]
+        self._ok(self.lib.dsir_t_gather(self.stream, _ptr(x), n, C_, _ptr(idx), m, clouds, _ptr(out), out.shape[-1], col_off),
+                 "dsir_t_gather")
+
+    def scatter_add(self, dy: torch.Tensor, col_off: int, C_: int, idx: torch.Tensor, n: int) -> torch.Tensor:
+        clouds, m = idx.shape
+        dx = torch.zeros(clouds, n, C_, dtype=torch.float32, device=self.device)
+        self._ok(self.lib.dsir_t_scatter_add(self.stream, _ptr(dy), dy.shape[-1], col_off, _ptr(idx), m, clouds, _ptr(dx), n, C_),
+                 "dsir_t_scatter_add")
+        return dx
+
+    def relpos(self, xyz: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+        clouds, n, k = idx.shape
+        out = self.empty(clouds * n * k, 10)
+        self._ok(self.lib.dsir_t_relpos(self.stream, _ptr(xyz), _ptr(idx), n, k, clouds, _ptr(out)), "dsir_t_relpos")
+        return out
+
+    def attpool_fwd(self, cat: torch.Tensor, scores: torch.Tensor, points: int) -> torch.Tensor:
+        C_ = cat.shape[1]
+        out = self.empty(points, C_)
+        self._ok(self.lib.dsir_t_attpool_fwd(self.stream, _ptr(cat), _ptr(scores), points, K_NN, C_, _ptr(out)), "dsir_t_attpool_fwd")
+        return out
+
+    def attpool_bwd(self, dout, cat, att, points):
+        C_ = cat.shape[1]
+        dcat, ds = self.empty(cat.shape[0], C_), self.empty(cat.shape[0], C_)
+        self._ok(self.lib.dsir_t_attpool_bwd(self.stream, _ptr(dout), _ptr(cat), _ptr(att), points, K_NN, C_, _ptr(dcat), _ptr(ds)),
+                 "dsir_t_attpool_bwd")
+        return dcat, ds
+
+    def maxpool_fwd(self, x: torch.Tensor, pool: torch.Tensor):
+        clouds, n, C_ = x.shape
+        m, k = pool.shape[1], pool.shape[2]
+        out = self.empty(clouds, m, C_)
+        arg = self.empty(clouds, m, C_, dtype=torch.int32)
+        self._ok(self.lib.dsir_t_maxpool_fwd(self.stream, _ptr(x), n, C_, _ptr(pool), m, k, clouds, _ptr(out), _ptr(arg)),
+                 "dsir_t_maxpool_fwd")
+        return out, arg
+
+    def maxpool_bwd(self, dout: torch.Tensor, arg: torch.Tensor, n: int) -> torch.Tensor:
+        clouds, m, C_ = arg.shape
+        dx = torch.zeros(clouds, n, C_, dtype=torch.float32, device=self.device)
+        self._ok(self.lib.dsir_t_maxpool_bwd(self.stream, _ptr(dout), _ptr(arg), m, C_, clouds, _ptr(dx), n), "dsir_t_maxpool_bwd")
+        return dx
+
+    def add_leaky_fwd(self, a, b):
+        out = torch.empty_like(a)
+        self._ok(self.lib.dsir_t_add_leaky_fwd(self.stream, _ptr(a), _ptr(b), a.numel(), _ptr(out)), "dsir_t_add_leaky_fwd")
+        return out
+
+    def add_leaky_bwd(self, dout, out):
+        d = torch.empty_like(out)
+        self._ok(self.lib.dsir_t_add_leaky_bwd(self.stream, _ptr(dout), _ptr(out), out.numel(), _ptr(d)), "dsir_t_add_leaky_bwd")
+        return d
+
+    def mul_mask(self, x, mask, scale):
+        y = torch.empty_like(x)
+        self._ok(self.lib.dsir_t_mul_mask(self.stream, _ptr(x), _ptr(mask), scale, x.numel(), _ptr(y)), "dsir_t_mul_mask")
+        return y
+
+    def axpy(self, a: float, x: torch.Tensor, y: torch.Tensor) -> None:
+        self._ok(self.lib.dsir_t_axpy(self.stream, a, _ptr(x), x.numel(), _ptr(y)), "dsir_t_axpy")
+
+    def acc(self, dst: Optional[torch.Tensor], src: torch.Tensor) -> torch.Tensor:
+        """dst += src (dst None: a private copy of src)."""
+        src = src.contiguous()
+        if dst is None:
+            return src.clone()
+        self.axpy(1.0, src, dst)
+        return dst
+
+    def inlier_input(self, xyz_src, xyz_ref, idx, T: Optional[torch.Tensor]) -> torch.Tensor:
+        """[P][J][6] = [T x_src ; x_ref[idx]]; T [P][..][3][4] view of one iteration (row stride taken from it) or None."""
+        P, J, _ = xyz_src.shape
+        out = self.empty(P, J, 6)
+        self._ok(self.lib.dsir_t_inlier_input(self.stream, _ptr(xyz_src), _ptr(xyz_ref), _ptr(idx), _ptr(T), 0 if T is None else T.stride(0),
+                                              P, J, xyz_ref.shape[1], _ptr(out)), "dsir_t_inlier_input")
+        return out
+
+
+class _Layer:
+    """What the backward of one conv (+ norm) needs."""
+    __slots__ = ("name", "x", "y", "stats", "clouds", "groups", "act", "norm")
+
+
+class RandlaTape:
+    def __init__(self):
+        self.layers: Dict[str, _Layer] = {}
+        self.blocks: List[dict] = []
+        self.misc: dict = {}
+
+
+class RandlaTrainer:
+    """One ``RandLA`` (network/RandLANet.py:233-372) with its parameters, gradients and Adam state on the device.
+
+    ``state_dict``: the reference's keys under ``prefix`` (others are ignored).  ``feat_in`` / ``num_classes``: 6 / 1 for the
+    inlier model (network/model.py:181-191)."""
+
+    def __init__(self, cfg: NetConfig, state_dict: Dict[str, "np.ndarray | torch.Tensor"], prefix: str = "inlier_model", feat_in: int = 6,
+                 num_classes: int = 1, device: "str | torch.device" = "cuda:0"):
+        self.cfg, self.prefix, self.feat_in, self.num_classes = cfg, prefix, feat_in, num_classes
+        self.device = torch.device(device)
+        self.ops = _Ops(self.device)
+        self.params: Dict[str, torch.Tensor] = {}
+        self.buffers: Dict[str, torch.Tensor] = {}
+        for spec in randla_specs(prefix, feat_in, num_classes, cfg):
+            if spec.kind == "bn_count":
+                continue
+            if spec.name not in state_dict:
+                raise KeyError(f"state_dict lacks {spec.name}")
+            v = state_dict[spec.name]
+            t = (v.detach().cpu() if isinstance(v, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(v))).float()
+            if tuple(t.shape) != tuple(spec.shape):
+                raise ValueError(f"{spec.name}: shape {tuple(t.shape)} != {tuple(spec.shape)}")
+            t = t.reshape(t.shape[0], -1).contiguous() if t.dim() > 1 else t.contiguous()
+            (self.buffers if spec.kind in ("bn_mean", "bn_var") else self.params)[spec.name] = t.to(self.device)
+        self.grads = {k: torch.zeros_like(v) for k, v in self.params.items()}
+        self.adam_m = {k: torch.zeros_like(v) for k, v in self.params.items()}
+        self.adam_v = {k: torch.zeros_like(v) for k, v in self.params.items()}
+        self.step_count = 0
+
+    # ------------------------------------------------------------------ bookkeeping
+    def zero_grad(self) -> None:
+        for g in self.grads.values():
+            g.zero_()
+
+    def state_dict(self) -> Dict[str, np.ndarray]:
+        """Parameters and BatchNorm running statistics in the reference's shapes (host)."""
+        shapes = {s.name: s.shape for s in randla_specs(self.prefix, self.feat_in, self.num_classes, self.cfg)}
+        out = {}
+        for k, v in list(self.params.items()) + list(self.buffers.items()):
+            out[k] = v.detach().cpu().numpy().reshape(shapes[k])
+        return out
+
+    def grad_dict(self) -> Dict[str, np.ndarray]:
+        shapes = {s.name: s.shape for s in randla_specs(self.prefix, self.feat_in, self.num_classes, self.cfg)}
+        return {k: v.detach().cpu().numpy().reshape(shapes[k]) for k, v in self.grads.items()}
+
+    def adam_step(self, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8) -> None:
+        """torch.optim.Adam.step (train.py:323, :446)."""
+        self.step_count += 1
+        o = self.ops
+        for k, p in self.params.items():
+            o._ok(o.lib.dsir_t_adam(o.stream, _ptr(p), _ptr(self.grads[k]), _ptr(self.adam_m[k]), _ptr(self.adam_v[k]), p.numel(), lr,
+                                    betas[0], betas[1], eps, self.step_count), "dsir_t_adam")
+
+    # ------------------------------------------------------------------ layers
+    def _mlp2d(self, tape: RandlaTape, name: str, x: torch.Tensor, clouds: int, act: bool = True) -> torch.Tensor:
+        """MLP2D (RandLANet.py:58-107): conv 1x1 + GroupNorm(4 | 8) [+ LeakyReLU]; x [clouds * M][Cin]."""
+        w = self.params[name + ".conv.weight"]
+        L = _Layer()
+        L.name, L.x, L.clouds, L.act, L.norm = name, x, clouds, act, "gn"
+        L.groups = 8 if w.shape[0] >= 64 else 4
+        L.y = self.ops.conv(x, w, self.params[name + ".conv.bias"])
+        out, L.stats = self.ops.gn_fwd(L.y, clouds, L.groups, self.params[name + ".norm.weight"], self.params[name + ".norm.bias"], act)
+        tape.layers[name] = L
+        return out
+
+    def _mlp2d_bwd(self, tape: RandlaTape, name: str, dout: torch.Tensor, need_dx: bool = True) -> Optional[torch.Tensor]:
+        L = tape.layers[name]
+        w = self.params[name + ".conv.weight"]
+        dy = self.ops.gn_bwd(dout, L.y, L.stats, L.clouds, L.groups, self.params[name + ".norm.weight"], self.params[name + ".norm.bias"],
+                             L.act, self.grads[name + ".norm.weight"], self.grads[name + ".norm.bias"])
+        self.ops.conv_dw(dy, L.x, self.grads[name + ".conv.weight"], self.grads[name + ".conv.bias"])
+        return self.ops.conv_dx(dy, w) if need_dx else None
+
+    def _att(self, tape: RandlaTape, name: str, cat: torch.Tensor, clouds: int, n: int) -> torch.Tensor:
+        """Att_pooling (RandLANet.py:140-157); cat [clouds * n * 16][d]."""
+        scores = self.ops.conv(cat, self.params[name + ".fc.weight"], None)
+        pooled = self.ops.attpool_fwd(cat, scores, clouds * n)           # scores become the softmax in place
+        tape.misc[name] = (cat, scores)
+        return self._mlp2d(tape, name + ".mlp", pooled, clouds)
+
+    def _att_bwd(self, tape: RandlaTape, name: str, dout: torch.Tensor, clouds: int, n: int) -> torch.Tensor:
+        cat, att = tape.misc[name]
+        dpooled = self._mlp2d_bwd(tape, name + ".mlp", dout)
+        dcat, ds = self.ops.attpool_bwd(dpooled, cat, att, clouds * n)
+        self.ops.conv_dw(ds, cat, self.grads[name + ".fc.weight"], None)
+        return self.ops.conv_dx(ds, self.params[name + ".fc.weight"], into=dcat)
+
+    def _res_block(self, tape: RandlaTape, p: str, feat: torch.Tensor, xyz: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+        """Dilated_res_block + Building_block (RandLANet.py:160-230); feat [clouds][n][Cin] -> [clouds][n][2 d]."""
+        clouds, n, cin = feat.shape
+        d = self.params[p + ".mlp2.conv.weight"].shape[1]
+        h = d // 2
+        flat_idx = idx.reshape(clouds, n * K_NN)
+        f = self._mlp2d(tape, p + ".mlp1", feat.reshape(clouds * n, cin), clouds)                    # [clouds n][h]
+        enc = self._mlp2d(tape, p + ".lfa.mlp1", self.ops.relpos(xyz, idx), clouds)                 # [clouds n 16][h]
+        cat1 = self.ops.empty(clouds * n * K_NN, d)
+        self.ops.gather(f.reshape(clouds, n, h), flat_idx, cat1, 0)
+        cat1[:, h:] = enc
+        agg1 = self._att(tape, p + ".lfa.att_pooling_1", cat1, clouds, n)                           # [clouds n][h]
+        enc2 = self._mlp2d(tape, p + ".lfa.mlp2", enc, clouds)
+        cat2 = self.ops.empty(clouds * n * K_NN, d)
+        self.ops.gather(agg1.reshape(clouds, n, h), flat_idx, cat2, 0)
+        cat2[:, h:] = enc2
+        agg2 = self._att(tape, p + ".lfa.att_pooling_2", cat2, clouds, n)                           # [clouds n][d]
+        main = self._mlp2d(tape, p + ".mlp2", agg2, clouds, act=False)
+        skip = self._mlp2d(tape, p + ".mlp_skip", feat.reshape(clouds * n, cin), clouds, act=False)
+        out = self.ops.add_leaky_fwd(main, skip)
+        tape.misc[p] = (out, flat_idx, clouds, n, h, d, cin)
+        return out.reshape(clouds, n, 2 * d)
+
+    def _res_block_bwd(self, tape: RandlaTape, p: str, dout: torch.Tensor, need_dx: bool = True) -> Optional[torch.Tensor]:
+        out, flat_idx, clouds, n, h, d, cin = tape.misc[p]
+        o = self.ops
+        dsum = o.add_leaky_bwd(dout.reshape(clouds * n, 2 * d), out)
+        dfeat = self._mlp2d_bwd(tape, p + ".mlp_skip", dsum, need_dx)
+        dagg2 = self._mlp2d_bwd(tape, p + ".mlp2", dsum)
+        dcat2 = self._att_bwd(tape, p + ".lfa.att_pooling_2", dagg2, clouds, n)
+        dagg1 = o.scatter_add(dcat2, 0, h, flat_idx, n)                                               # [clouds][n][h]
+        denc = self._mlp2d_bwd(tape, p + ".lfa.mlp2", dcat2[:, h:].contiguous())                      # w.r.t. enc
+        dcat1 = self._att_bwd(tape, p + ".lfa.att_pooling_1", dagg1.reshape(clouds * n, h), clouds, n)
+        df = o.scatter_add(dcat1, 0, h, flat_idx, n)
+        o.axpy(1.0, dcat1[:, h:].contiguous(), denc)
+        self._mlp2d_bwd(tape, p + ".lfa.mlp1", denc, need_dx=False)                                   # its input is data
+        d1 = self._mlp2d_bwd(tape, p + ".mlp1", df.reshape(clouds * n, h), need_dx)
+        if not need_dx:
+            return None
+        o.axpy(1.0, d1, dfeat)
+        return dfeat.reshape(clouds, n, cin)
+
+    # ------------------------------------------------------------------ the network
+    def forward(self, features: torch.Tensor, xyz_multi: torch.Tensor, neigh_idx: torch.Tensor, sub_idx: torch.Tensor,
+                interp_idx: torch.Tensor, dropout_mask: Optional[torch.Tensor] = None, update_running_stats: bool = True):
+        """RandLA.forward in TRAINING mode (RandLANet.py:311-372; train.py:379 ``my_model.train()``): GroupNorm as always,
+        the two BatchNorm1d of ``fc_label`` on batch statistics (running statistics updated with momentum 0.1), Dropout(0.5)
+        with ``dropout_mask`` ([clouds][N][64] uint8 keep flags; None = keep everything, i.e. dropout off).
+        features [clouds][N][feat_in]; pyramids as ``Engine.knn_pyramid`` returns them (int32).
+        -> logits [clouds][N][num_classes], tape."""
+        o = self.ops
+        pf = self.prefix
+        clouds, N, cin = features.shape
+        L = len(self.cfg.d_out)
+        n = level_sizes(N, self.cfg.sub_sampling_ratio)
+        off = np.concatenate([[0], np.cumsum(n[:L])]).astype(int)
+        soff = np.concatenate([[0], np.cumsum(n[1:L + 1])]).astype(int)
+        tape = RandlaTape()
+        x = self._mlp2d(tape, pf + ".mlp_pre", features.reshape(clouds * N, cin).contiguous(), clouds).reshape(clouds, N, -1)
+        skips: List[torch.Tensor] = []
+        args: List[torch.Tensor] = []
+        for l in range(L):
+            a, b = off[l], off[l + 1]
+            enc = self._res_block(tape, f"{pf}.dilated_res_blocks.{l}", x, xyz_multi[:, a:b].contiguous(), neigh_idx[:, a:b].contiguous())
+            x, arg = o.maxpool_fwd(enc, sub_idx[:, soff[l]:soff[l + 1]].contiguous())                  # random_sample (:374-391)
+            args.append(arg)
+            if l == 0:
+                skips.append(enc)
+            skips.append(x)
+        m = n[L]
+        x = self._mlp2d(tape, pf + ".mlp_mid", skips[-1].reshape(clouds * m, -1), clouds).reshape(clouds, m, -1)
+        dec = []
+        for j in range(L):
+            a, b = off[L - j - 1], off[L - j]
+            ii = interp_idx[:, a:b, 0].contiguous()
+            sk = skips[-j - 2]
+            cs, cu = sk.shape[2], x.shape[2]
+            cat = o.empty(clouds * (b - a), cs + cu)
+            cat[:, :cs] = sk.reshape(clouds * (b - a), cs)
+            o.gather(x, ii, cat, cs)                                                                    # nearest_interpolation (:393-408)
+            dec.append((ii, cs, cu, x.shape[1]))
+            x = self._mlp2d(tape, f"{pf}.decoder_blocks.{j}", cat, clouds).reshape(clouds, b - a, -1)
+        xf = x.reshape(clouds * N, -1)
+        feat = o.conv(xf, self.params[pf + ".mlp_out.weight"], None)
+        h = o.mul_mask(feat, dropout_mask.reshape(-1).contiguous(), 2.0) if dropout_mask is not None else feat
+        # fc_label: Conv1d + BatchNorm1d (batch statistics) + LeakyReLU, twice, then Conv1d (RandLANet.py:34-55, :272-273)
+        fc = []
+        pos = 0
+        for i in range(3):
+            w, bias = self.params[f"{pf}.fc_label.{pos}.weight"], self.params[f"{pf}.fc_label.{pos}.bias"]
+            y = o.conv(h, w, bias)
+            if i < 2:
+                g, be = self.params[f"{pf}.fc_label.{pos + 1}.weight"], self.params[f"{pf}.fc_label.{pos + 1}.bias"]
+                out, stats = o.gn_fwd(y, 1, w.shape[0], g, be, True)
+                if update_running_stats:
+                    o._ok(o.lib.dsir_t_bn_running(o.stream, _ptr(stats), w.shape[0], y.shape[0], 0.1,
+                                                  _ptr(self.buffers[f"{pf}.fc_label.{pos + 1}.running_mean"]),
+                                                  _ptr(self.buffers[f"{pf}.fc_label.{pos + 1}.running_var"])), "dsir_t_bn_running")
+                fc.append((pos, h, y, stats))
+                h = out
+                pos += 3
+            else:
+                fc.append((pos, h, None, None))
+                h = y
+        tape.misc["net"] = dict(clouds=clouds, N=N, n=n, skips_shapes=[s.shape for s in skips], args=args, dec=dec, xf=xf, fc=fc,
+                                mask=dropout_mask, L=L)
+        return h.reshape(clouds, N, self.num_classes), tape
+
+    def backward(self, tape: RandlaTape, dlogits: torch.Tensor) -> None:
+        """Accumulates d loss / d parameter into ``self.grads`` (call ``zero_grad`` between steps, not between the
+        registration iterations of one step: their gradients add up, as autograd's do)."""
+        o = self.ops
+        pf = self.prefix
+        net = tape.misc["net"]
+        clouds, N, n, L = net["clouds"], net["N"], net["n"], net["L"]
+        d = dlogits.reshape(clouds * N, self.num_classes).contiguous().float()
+        for pos, hin, y, stats in reversed(net["fc"]):
+            w = self.params[f"{pf}.fc_label.{pos}.weight"]
+            if y is not None:
+                g, be = self.params[f"{pf}.fc_label.{pos + 1}.weight"], self.params[f"{pf}.fc_label.{pos + 1}.bias"]
+                d = o.gn_bwd(d, y, stats, 1, w.shape[0], g, be, True, self.grads[f"{pf}.fc_label.{pos + 1}.weight"],
+                             self.grads[f"{pf}.fc_label.{pos + 1}.bias"])
+            o.conv_dw(d, hin, self.grads[f"{pf}.fc_label.{pos}.weight"], self.grads[f"{pf}.fc_label.{pos}.bias"])
+            d = o.conv_dx(d, w)
+        if net["mask"] is not None:
+            d = o.mul_mask(d, net["mask"].reshape(-1).contiguous(), 2.0)
+        o.conv_dw(d, net["xf"], self.grads[pf + ".mlp_out.weight"], None)
+        dx = o.conv_dx(d, self.params[pf + ".mlp_out.weight"])                                        # [clouds N][C]
+        shapes = net["skips_shapes"]
+        dskips: List[Optional[torch.Tensor]] = [None] * len(shapes)
+        for j in reversed(range(L)):
+            ii, cs, cu, n_prev = net["dec"][j]
+            dcat = self._mlp2d_bwd(tape, f"{pf}.decoder_blocks.{j}", dx)
+            k = len(shapes) - j - 2
+            dskips[k] = o.acc(dskips[k], dcat[:, :cs]).reshape(shapes[k])
+            dx = o.scatter_add(dcat, cs, cu, ii, n_prev).reshape(clouds * n_prev, cu)
+        dmid = self._mlp2d_bwd(tape, pf + ".mlp_mid", dx).reshape(shapes[-1])
+        dskips[-1] = o.acc(dskips[-1], dmid).reshape(shapes[-1])
+        for l in reversed(range(L)):
+            denc = o.maxpool_bwd(dskips[l + 1].contiguous(), net["args"][l], n[l])                   # [clouds][n_l][2 d_l]
+            if l == 0 and dskips[0] is not None:
+                o.axpy(1.0, dskips[0].contiguous(), denc)
+            dfeat = self._res_block_bwd(tape, f"{pf}.dilated_res_blocks.{l}", denc, need_dx=True)
+            if l > 0:
+                dskips[l] = o.acc(dskips[l], dfeat).reshape(shapes[l])
+            else:
+                self._mlp2d_bwd(tape, pf + ".mlp_pre", dfeat.reshape(clouds * N, -1), need_dx=False)
+
+
+def train_step_align(engine, trainer: RandlaTrainer, batch: dict, result: dict, transform_gt: np.ndarray,
+                     labels: Optional[np.ndarray] = None, lr: float = 1e-3, dropout_seed: Optional[int] = None,
+                     loss_kwargs: Optional[dict] = None, apply: bool = True) -> dict:
+    """One optimisation step of the `align` pipeline on the inlier model (train.py:396-448).
+
+    ``batch``: the device tensors of one ``Engine.register`` call (points_src [P][N][C], the src pyramid
+    src_xyz / src_neigh / src_sub / src_interp, points_ref); ``result``: what that call returned (idx [n_iter][P][N],
+    transforms [P][n_iter][3][4]) - the no_grad half of ``forward_align_4`` (matching, ``R_t.detach()``), taken from the
+    inference engine.  Per iteration the inlier model's input cat(xyz_src_i, xyz_ref[idx_i]) (model.py:571-573) is rebuilt
+    from them, run forward in training mode, the alignment loss and its gradient w.r.t. the logits come from
+    ``Engine.align_loss_backward``, and the gradients of all iterations are accumulated before ONE Adam step - skipped,
+    like the reference's (train.py:437-446), when a gradient is NaN or a pose was degenerate."""
+    dev = trainer.device
+    xyz_s = batch["points_src"][:, :, :3].contiguous()
+    xyz_r = batch["points_ref"][:, :, :3].contiguous()
+    idx = result["idx"]
+    T = result["transforms"]
+    n_iter, P, N = idx.shape
+    trainer.zero_grad()
+    logits, tapes = [], []
+    gen = torch.Generator(device="cpu")
+    if dropout_seed is not None:
+        gen.manual_seed(int(dropout_seed))
+    for it in range(n_iter):
+        # the src cloud moved by the previous cumulative pose (model.py:587; R_t.detach()) next to its correspondences
+        cat = trainer.ops.inlier_input(xyz_s, xyz_r, idx[it], None if it == 0 else T[:, it - 1])
+        mask = None
+        if dropout_seed is not None:
+            mask = (torch.rand(P, N, trainer.cfg.out_feat_dim, generator=gen) >= 0.5).to(torch.uint8).to(dev)
+        lg, tape = trainer.forward(cat, batch["src_xyz"], batch["src_neigh"], batch["src_sub"], batch["src_interp"], mask)
+        logits.append(lg.reshape(P, N))
+        tapes.append(tape)
+    lg_all = torch.stack(logits).contiguous()
+    out = engine.align_loss_backward(xyz_s, xyz_r, idx, lg_all, labels, transform_gt, **(loss_kwargs or {}))
+    g = out["grad_logits"]
+    for it in range(n_iter):
+        trainer.backward(tapes[it], g[it])
+    bad = any(bool(torch.isnan(v).any()) for v in trainer.grads.values())
+    if apply and not bad:
+        trainer.adam_step(lr)
+    out["logits"] = lg_all
+    out["skipped"] = bad
+    return out

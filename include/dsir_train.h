@@ -1,0 +1,97 @@
+/*
+ * dsir_train.h — C ABI of the training operators (libdsir.so), SURVEY.md section 8(f) rank 4: the backward half.
+ *
+ * The reference trains with torch autograd (train.py:396-448): every operator below is the forward or the backward of
+ * one ATen call that RandLA.forward (network/RandLANet.py:311-372) makes, so that the inlier model's training step
+ * (forward with saved activations, backward from d loss / d logits - dsir_align_loss_backward - to every parameter,
+ * Adam) runs on the device without autograd.  deepsir_amd/train.py strings them together in the reference's module
+ * order; this header is what a non-Python host would bind.
+ *
+ * Conventions: device pointers, fp32, POINT-MAJOR rows ([rows][channels], leading dimension `ld` in floats), int32
+ * indices; `stream` is a hipStream_t (NULL = default stream); calls are asynchronous; return 0 or a hipError_t.
+ * Reductions are deterministic (fixed partition, fixed order) except the two scatter-adds, which use fp32 atomics
+ * exactly like ATen's index/gather backward on a GPU.
+ */
+#ifndef DSIR_TRAIN_H
+#define DSIR_TRAIN_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* nn.Conv2d 1x1 / nn.Conv1d / nn.Linear (RandLANet.py:77-88, :148, :270, :41): Y[r][n] = beta Y[r][n] + bias[n] +
+ * sum_k X[r][k] W[n wn + k wk].  Forward: W = weight [Cout][Cin], wn = Cin, wk = 1.  Backward w.r.t. the input
+ * (dX = dY W): X = dY, wn = 1, wk = Cin, N = Cin, K = Cout; beta = 1 accumulates into an existing gradient.
+ * Exact-fp32 MFMA (v_mfma_f32_16x16x4_f32), k ascending. */
+int dsir_t_gemm(void* stream, const float* X, int ldx, const float* W, int wn, int wk, const float* bias, float* Y, int ldy,
+                int64_t rows, int K, int N, float beta);
+
+/* Backward of the same call w.r.t. weight and bias: dW[n][k] += sum_r dY[r][n] X[r][k], db[n] += sum_r dY[r][n]
+ * (db may be NULL).  scratch: dsir_t_gemm_dw_scratch(rows, N, K) bytes. */
+size_t dsir_t_gemm_dw_scratch(int64_t rows, int N, int K);
+int dsir_t_gemm_dw(void* stream, const float* dY, int ldy, const float* X, int ldx, int64_t rows, int N, int K, float* dW,
+                   float* db, void* scratch);
+
+/* nn.GroupNorm(groups, C) (+ LeakyReLU 0.2 when act) over one cloud's [M][C] block (RandLANet.py:90-107), also
+ * nn.BatchNorm1d in training mode (clouds = 1, M = all rows, groups = C; RandLANet.py:44): biased variance, eps 1e-5.
+ * stats [clouds][groups][2] = {mean, rstd} are kept for the backward. */
+int dsir_t_gn_fwd(void* stream, const float* Y, int clouds, int M, int C, int groups, const float* gamma, const float* beta,
+                  int act, float* out, float* stats);
+/* dY (may alias dOut) = d loss / d Y; dgamma / dbeta accumulate.  scratch: clouds * C * 2 floats. */
+int dsir_t_gn_bwd(void* stream, const float* dOut, const float* Y, const float* stats, int clouds, int M, int C, int groups,
+                  const float* gamma, const float* beta, int act, float* dY, float* dgamma, float* dbeta, float* scratch);
+
+/* The running statistics nn.BatchNorm1d keeps in training mode (momentum 0.1, unbiased variance); stats = dsir_t_gn_fwd's
+ * with groups = C over M rows. */
+int dsir_t_bn_running(void* stream, const float* stats, int C, int64_t M, float momentum, float* running_mean, float* running_var);
+
+/* gather_neighbour_V2 / nearest_interpolation (network/tools.py:197-221, RandLANet.py:393-408):
+ * Y[cloud][j][col_off + c] = X[cloud][idx[cloud][j]][c], j < m, c < C; X [clouds][n][C]; backward = scatter-add. */
+int dsir_t_gather(void* stream, const float* X, int n, int C, const int32_t* idx, int m, int clouds, float* Y, int ldy, int col_off);
+int dsir_t_scatter_add(void* stream, const float* dY, int ldy, int col_off, const int32_t* idx, int m, int clouds, float* dX,
+                       int n, int C);
+
+/* Building_block.relative_pos_encoding (RandLANet.py:197-212): out[cloud][i k + j][10] = {|pj - pi|, pj - pi, pi, pj};
+ * xyz [clouds][n][3], idx [clouds][n][k].  No backward: the coordinates are data. */
+int dsir_t_relpos(void* stream, const float* xyz, const int32_t* idx, int n, int k, int clouds, float* out);
+
+/* The inlier model's input of one registration iteration (network/model.py:571-573; the src cloud moved by the previous
+ * cumulative pose, :587 with R_t.detach()): out[pair][j] = {T x_src[j], x_ref[idx[pair][j]]}; xyz_src [P][J][3], xyz_ref
+ * [P][K][3], T = NULL (iteration 0) or the pose of pair p at T + p t_stride ([3][4] row-major), out [P][J][6]. */
+int dsir_t_inlier_input(void* stream, const float* xyz_src, const float* xyz_ref, const int32_t* idx, const float* T, int t_stride,
+                        int pairs, int J, int K, float* out);
+
+/* Att_pooling (RandLANet.py:148-155) after its fc: S [points][k][C] scores in, softmax over k written back in place (kept
+ * for the backward), out[point][c] = sum_k cat[point][k][c] S[point][k][c].  Backward: dCat = direct part (the caller adds
+ * dS W_fc with dsir_t_gemm beta = 1), dS = d loss / d scores. */
+int dsir_t_attpool_fwd(void* stream, const float* cat, float* S, int64_t points, int k, int C, float* out);
+int dsir_t_attpool_bwd(void* stream, const float* dOut, const float* cat, const float* A, int64_t points, int k, int C, float* dCat,
+                       float* dS);
+
+/* RandLA.random_sample (RandLANet.py:374-391): out[cloud][j][c] = max_t X[cloud][pool[cloud][j][t]][c]; arg = the row
+ * that won (first of equals); backward adds dOut to that row. */
+int dsir_t_maxpool_fwd(void* stream, const float* X, int n, int C, const int32_t* pool, int m, int k, int clouds, float* out,
+                       int32_t* arg);
+int dsir_t_maxpool_bwd(void* stream, const float* dOut, const int32_t* arg, int m, int C, int clouds, float* dX, int n);
+
+/* F.leaky_relu(a + b, 0.2) (RandLANet.py:230) and its backward (d a = d b = dOut * slope(out)). */
+int dsir_t_add_leaky_fwd(void* stream, const float* a, const float* b, int64_t n, float* out);
+int dsir_t_add_leaky_bwd(void* stream, const float* dOut, const float* out, int64_t n, float* d);
+
+/* nn.Dropout (RandLANet.py:366) with the mask supplied: y = x * mask * scale (forward and backward alike). */
+int dsir_t_mul_mask(void* stream, const float* x, const uint8_t* mask, float scale, int64_t n, float* y);
+/* y += a x */
+int dsir_t_axpy(void* stream, float a, const float* x, int64_t n, float* y);
+
+/* torch.optim.Adam.step (train.py:323, :446; betas 0.9 / 0.999, eps 1e-8, no weight decay, no amsgrad):
+ * m = b1 m + (1 - b1) g; v = b2 v + (1 - b2) g^2; p -= lr / (1 - b1^step) * m / (sqrt(v) / sqrt(1 - b2^step) + eps). */
+int dsir_t_adam(void* stream, float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
+                int step);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,310 @@
+"""The training slice (backward half): the inlier model's forward-in-training-mode, backward and
+Adam step.  CPU: the oracle restatement (oracle/train.py) against the vectors the imported reference's autograd produced
+(tests/golden/train_cases.npz, oracle/gen_golden_train.py).  GPU: the HIP operators one by one against torch autograd, then
+the whole pass and the optimiser against the same reference vectors, through the C ABI of include/dsir_train.h."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+from deepsir_amd.arch import NetConfig
+from deepsir_amd.weights import generate_state_dict
+from oracle.gen_golden_train import FULL_MAX, case_inputs, sample_index
+from oracle.network import OracleNet, to_torch
+from oracle import train as otrain
+
+GOLD = np.load(os.path.join(ROOT, "tests", "golden", "train_cases.npz"))
+CFG = NetConfig(feat_len=3)
+
+
+def _case(c):
+    meta = json.loads(str(GOLD[f"c{c}_meta"]))
+    d = case_inputs(CFG, meta["n"], meta["seed"])
+    sd = generate_state_dict(CFG, meta["wseed"], meta["variant"])
+    keep = np.unpackbits(GOLD[f"c{c}_keep"])[: 2 * 64 * meta["n"]].reshape(2, 64, meta["n"]).astype(bool)
+    return meta, d, sd, keep
+
+
+ZERO_BY_CONSTRUCTION = ("fc_label.0.bias", "fc_label.3.bias")   # a bias in front of BatchNorm: the batch mean removes it
+
+
+def _check_grads(c, grads, seed, rtol, atol=1e-7):
+    """grads: name -> flat numpy; against the reference's (whole tensors, or samples + sum + norm).  Gradients that are
+    zero by construction are rounding noise on both sides: required to be noise (1e-4 of the layer's weight gradient)."""
+    checked = 0
+    for name, g in grads.items():
+        g = np.asarray(g, np.float64).reshape(-1)
+        key = f"c{c}_g_{name}"
+        if name.endswith(ZERO_BY_CONSTRUCTION):
+            wscale = np.abs(GOLD[f"c{c}_g_{name[:-4]}weight"]).max()
+            assert np.abs(g).max() <= 1e-4 * wscale and np.abs(GOLD[key]).max() <= 1e-4 * wscale, name
+            continue
+        if key in GOLD:
+            ref = GOLD[key].astype(np.float64)
+        else:
+            ref = GOLD[key + "_samples"].astype(np.float64)
+            s, nrm = GOLD[key + "_sum_norm"]
+            assert abs(np.sqrt((g ** 2).sum()) - nrm) <= rtol * nrm + atol * np.sqrt(g.size), name
+            g = g[sample_index(name[len("inlier_model."):], g.size, seed)]
+        scale = np.abs(ref).max()
+        assert np.abs(g - ref).max() <= rtol * scale + atol, f"{name}: {np.abs(g - ref).max():.3e} vs scale {scale:.3e}"
+        checked += 1
+    assert checked > 100
+
+
+@pytest.mark.parametrize("c", range(int(GOLD["n_cases"])))
+def test_oracle_training_pass_matches_reference_autograd(c):
+    meta, d, sd, keep = _case(c)
+    net = OracleNet(CFG, sd)
+    params = otrain.trainable(net)
+    t = to_torch(d)
+    logits = otrain.randla_train(net, "inlier_model", t["cat"], t["points_src_xyz"], t["points_src_neigh_idx"], t["points_src_sub_idx"],
+                                 t["points_src_interp_idx"], torch.from_numpy(keep))
+    assert np.abs(logits.detach().numpy() - GOLD[f"c{c}_logits"]).max() < 2e-5
+    (logits * t["G"]).sum().backward()
+    _check_grads(c, {k: v.grad.numpy() for k, v in params.items()}, meta["seed"], 2e-4)
+    for k in GOLD.files:
+        if k.startswith(f"c{c}_buf_"):
+            assert np.allclose(net.p[k[len(f"c{c}_buf_"):]].numpy(), GOLD[k], rtol=1e-5, atol=1e-6), k
+
+
+def _adam_targets():
+    return {k[len("adam_"):]: GOLD[k] for k in GOLD.files if k.startswith("adam_inlier_model.")}
+
+
+def test_oracle_adam_steps_match_reference():
+    meta, d, sd, _ = _case(1)
+    net = OracleNet(CFG, sd)
+    params = otrain.trainable(net)
+    opt = otrain.adam_reference(params, 1e-3)
+    t = to_torch(d)
+    n = meta["n"]
+    for s in range(3):
+        keep = np.unpackbits(GOLD["adam_keep"][s])[: 2 * 64 * n].reshape(2, 64, n).astype(bool)
+        opt.zero_grad()
+        lg = otrain.randla_train(net, "inlier_model", t["cat"], t["points_src_xyz"], t["points_src_neigh_idx"], t["points_src_sub_idx"],
+                                 t["points_src_interp_idx"], torch.from_numpy(keep))
+        (lg * t["G"]).sum().backward()
+        opt.step()
+    # the reference ran case 1's single pass first: its running statistics had one more update (checked on the device test)
+    for name, ref in _adam_targets().items():
+        if name.endswith("running_var"):
+            continue
+        v = net.p[name].detach().numpy().reshape(-1)
+        v = v if v.size <= FULL_MAX else v[sample_index(name[len("inlier_model."):], v.size, meta["seed"])]
+        assert np.abs(v - ref).max() <= 2e-4 * np.abs(ref).max() + 1e-6, name
+
+
+# ------------------------------------------------------------------------------------------------- GPU
+def _dev():
+    return torch.device("cuda:0")
+
+
+@pytest.mark.gpu
+def test_ops_against_torch_autograd():
+    """Every operator of include/dsir_train.h on small ragged shapes (tile edges, odd channel counts)."""
+    import torch.nn.functional as F
+    from deepsir_amd.train import _Ops
+    o = _Ops(_dev())
+    g = torch.Generator().manual_seed(5)
+    rnd = lambda *s: torch.randn(*s, generator=g)
+    # 1x1 convolution: forward, d input (with accumulation), d weight / d bias
+    for rows, cin, cout in ((1000, 10, 8), (333, 96, 160), (77, 6, 1), (4100, 64, 64)):
+        x, w, b, dy = rnd(rows, cin).requires_grad_(), rnd(cout, cin).requires_grad_(), rnd(cout).requires_grad_(), rnd(rows, cout)
+        y = F.linear(x, w, b)
+        y.backward(dy)
+        xd, wd, bd, dyd = x.detach().to(_dev()), w.detach().to(_dev()), b.detach().to(_dev()), dy.to(_dev())
+        assert torch.allclose(o.conv(xd, wd, bd).cpu(), y.detach(), rtol=1e-4, atol=1e-4)
+        assert torch.allclose(o.conv_dx(dyd, wd).cpu(), x.grad, rtol=1e-4, atol=1e-4)
+        base = torch.ones(rows, cin, device=_dev())
+        assert torch.allclose(o.conv_dx(dyd, wd, into=base).cpu(), x.grad + 1.0, rtol=1e-4, atol=1e-4)
+        dw, db = torch.zeros(cout, cin, device=_dev()), torch.zeros(cout, device=_dev())
+        o.conv_dw(dyd, xd, dw, db)
+        o.conv_dw(dyd, xd, dw, db)                                        # accumulates
+        assert torch.allclose(dw.cpu(), 2 * w.grad, rtol=1e-4, atol=2e-3)
+        assert torch.allclose(db.cpu(), 2 * b.grad, rtol=1e-4, atol=2e-3)
+    # GroupNorm (+ LeakyReLU) per cloud; BatchNorm1d in training mode = one cloud, one group per channel
+    for clouds, M, C_, groups, act in ((3, 500, 32, 4, True), (2, 77, 128, 8, False), (1, 900, 64, 64, True)):
+        y = rnd(clouds, C_, M).requires_grad_()
+        ga, be, dout = (torch.rand(C_, generator=g) + 0.5).requires_grad_(), rnd(C_).requires_grad_(), rnd(clouds, C_, M)
+        ref = F.group_norm(y, groups, ga, be, 1e-5) if groups != C_ else F.batch_norm(y, None, None, ga, be, True, 0.1, 1e-5)
+        ref = F.leaky_relu(ref, 0.2) if act else ref
+        ref.backward(dout)
+        pm = lambda t: t.detach().permute(0, 2, 1).reshape(clouds * M, C_).contiguous().to(_dev())
+        out, stats = o.gn_fwd(pm(y), clouds, groups, ga.detach().to(_dev()), be.detach().to(_dev()), act)
+        assert torch.allclose(out.cpu(), pm(ref).cpu(), rtol=1e-4, atol=1e-4)
+        dga, dbe = torch.zeros(C_, device=_dev()), torch.zeros(C_, device=_dev())
+        dy = o.gn_bwd(pm(dout), pm(y), stats, clouds, groups, ga.detach().to(_dev()), be.detach().to(_dev()), act, dga, dbe)
+        assert torch.allclose(dy.cpu(), pm(y.grad).cpu(), rtol=1e-3, atol=1e-4)
+        assert torch.allclose(dga.cpu(), ga.grad, rtol=1e-4, atol=1e-3) and torch.allclose(dbe.cpu(), be.grad, rtol=1e-4, atol=1e-3)
+    # gather / scatter-add, max-pool, attentive pooling, add + LeakyReLU
+    clouds, n, m, C_ = 2, 300, 75, 24
+    x = rnd(clouds, n, C_).requires_grad_()
+    idx = torch.randint(0, n, (clouds, n * 16), generator=g)
+    cat = torch.zeros(clouds * n * 16, C_ + 5, device=_dev())
+    o.gather(x.detach().to(_dev()), idx.int().to(_dev()), cat, 5)
+    ref = torch.gather(x, 1, idx[:, :, None].expand(-1, -1, C_))
+    assert torch.equal(cat[:, 5:].cpu(), ref.detach().reshape(-1, C_))
+    dy = rnd(clouds * n * 16, C_ + 5)
+    ref.backward(dy[:, 5:].reshape(clouds, n * 16, C_))
+    assert torch.allclose(o.scatter_add(dy.to(_dev()), 5, C_, idx.int().to(_dev()), n).cpu(), x.grad, rtol=1e-4, atol=1e-4)
+    x.grad = None
+    pool = torch.randint(0, n, (clouds, m, 16), generator=g)
+    ref = torch.gather(x, 1, pool.reshape(clouds, m * 16, 1).expand(-1, -1, C_)).reshape(clouds, m, 16, C_).max(dim=2)[0]
+    out, arg = o.maxpool_fwd(x.detach().to(_dev()), pool.int().to(_dev()))
+    assert torch.equal(out.cpu(), ref.detach())
+    dp = rnd(clouds, m, C_)
+    ref.backward(dp)
+    assert torch.allclose(o.maxpool_bwd(dp.to(_dev()), arg, n).cpu(), x.grad, rtol=1e-5, atol=1e-5)
+    pts = 130
+    cat = rnd(pts, 16, C_).requires_grad_()
+    sc = rnd(pts, 16, C_).requires_grad_()
+    a = torch.softmax(sc, dim=1)
+    ref = (cat * a).sum(1)
+    dout = rnd(pts, C_)
+    ref.backward(dout)
+    sd = sc.detach().reshape(pts * 16, C_).clone().to(_dev())
+    cd = cat.detach().reshape(pts * 16, C_).to(_dev())
+    out = o.attpool_fwd(cd, sd, pts)
+    assert torch.allclose(out.cpu(), ref.detach(), rtol=1e-4, atol=1e-5) and torch.allclose(sd.cpu().reshape(pts, 16, C_), a.detach(), atol=1e-6)
+    dcat, ds = o.attpool_bwd(dout.to(_dev()), cd, sd, pts)
+    assert torch.allclose(dcat.cpu().reshape(pts, 16, C_), cat.grad, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(ds.cpu().reshape(pts, 16, C_), sc.grad, rtol=1e-4, atol=1e-5)
+    a_, b_ = rnd(1000).requires_grad_(), rnd(1000)
+    ref = F.leaky_relu(a_ + b_, 0.2)
+    ref.backward(torch.ones(1000))
+    out = o.add_leaky_fwd(a_.detach().to(_dev()), b_.to(_dev()))
+    assert torch.allclose(out.cpu(), ref.detach())
+    assert torch.allclose(o.add_leaky_bwd(torch.ones(1000, device=_dev()), out).cpu(), a_.grad)
+    # relative position encoding and the inlier model's input
+    xyz = rnd(clouds, n, 3)
+    nb = torch.randint(0, n, (clouds, n, 16), generator=g)
+    enc = o.relpos(xyz.to(_dev()), nb.int().to(_dev())).cpu().reshape(clouds, n, 16, 10)
+    pj = torch.gather(xyz, 1, nb.reshape(clouds, n * 16, 1).expand(-1, -1, 3)).reshape(clouds, n, 16, 3)
+    pi = xyz[:, :, None, :].expand_as(pj)
+    assert torch.allclose(enc, torch.cat([(pj - pi).norm(dim=3, keepdim=True), pj - pi, pi, pj], 3), atol=1e-6)
+    T = rnd(clouds, 4, 3, 4)
+    ii = torch.randint(0, n, (clouds, n), generator=g)
+    got = o.inlier_input(xyz.to(_dev()), xyz.flip(1).contiguous().to(_dev()), ii.int().to(_dev()), T.to(_dev())[:, 2]).cpu()
+    want = torch.cat([xyz @ T[:, 2, :, :3].transpose(1, 2) + T[:, 2, :, 3][:, None], torch.gather(xyz.flip(1), 1, ii[:, :, None].expand(-1, -1, 3))], 2)
+    assert torch.allclose(got, want, atol=1e-5)
+    torch.cuda.synchronize()
+
+
+def _trainer(sd):
+    from deepsir_amd.train import RandlaTrainer
+    return RandlaTrainer(CFG, sd, "inlier_model", 6, 1, _dev())
+
+
+def _dev_inputs(d):
+    f = lambda k, dt: torch.from_numpy(np.ascontiguousarray(d[k])).to(dt).to(_dev())
+    return (f("cat", torch.float32), f("points_src_xyz", torch.float32), f("points_src_neigh_idx", torch.int32),
+            f("points_src_sub_idx", torch.int32), f("points_src_interp_idx", torch.int32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("c", range(int(GOLD["n_cases"])))
+def test_device_training_pass_matches_reference_autograd(c):
+    """Forward in training mode (logits, running statistics) and every parameter gradient of the inlier model, HIP path
+    vs the imported reference's autograd."""
+    meta, d, sd, keep = _case(c)
+    tr = _trainer(sd)
+    mask = torch.from_numpy(np.ascontiguousarray(keep.transpose(0, 2, 1))).to(torch.uint8).to(_dev())    # [clouds][N][64]
+    logits, tape = tr.forward(*_dev_inputs(d), dropout_mask=mask)
+    ref = GOLD[f"c{c}_logits"].transpose(0, 2, 1)
+    assert np.abs(logits.cpu().numpy() - ref).max() < 5e-4
+    G = torch.from_numpy(d["G"].transpose(0, 2, 1).copy()).to(_dev())
+    tr.backward(tape, G)
+    torch.cuda.synchronize()
+    _check_grads(c, {k: v.cpu().numpy() for k, v in tr.grads.items()}, meta["seed"], 2e-3, 1e-6)
+    for k in GOLD.files:
+        if k.startswith(f"c{c}_buf_"):
+            assert np.allclose(tr.buffers[k[len(f"c{c}_buf_"):]].cpu().numpy(), GOLD[k], rtol=1e-4, atol=1e-5), k
+    # gradients of a second pass add up, as autograd's do
+    logits, tape = tr.forward(*_dev_inputs(d), dropout_mask=mask, update_running_stats=False)
+    tr.backward(tape, G)
+    g2 = tr.grads["inlier_model.fc_label.6.weight"].cpu().numpy().reshape(-1)
+    assert np.allclose(g2, 2 * GOLD[f"c{c}_g_inlier_model.fc_label.6.weight"], rtol=2e-3, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_device_adam_steps_match_reference():
+    """Three optimiser steps (forward in training mode, backward, torch.optim.Adam's rule) vs the imported reference."""
+    meta, d, sd, keep1 = _case(1)
+    tr = _trainer(sd)
+    n = meta["n"]
+    inp = _dev_inputs(d)
+    G = torch.from_numpy(d["G"].transpose(0, 2, 1).copy()).to(_dev())
+    mk = lambda bits: torch.from_numpy(np.ascontiguousarray(np.unpackbits(bits)[: 2 * 64 * n].reshape(2, 64, n).transpose(0, 2, 1))).to(_dev())
+    tr.forward(*inp, dropout_mask=mk(GOLD["c1_keep"]))                    # the reference's single pass of case 1 came first
+    for s in range(3):
+        tr.zero_grad()
+        lg, tape = tr.forward(*inp, dropout_mask=mk(GOLD["adam_keep"][s]))
+        tr.backward(tape, G)
+        tr.adam_step(1e-3)
+    torch.cuda.synchronize()
+    # Adam divides by sqrt(v): a parameter whose gradient is at rounding-noise level still moves by ~lr per step, in the
+    # direction the noise happens to have - on the reference's CPU as here.  So: every entry within the 3 lr any entry can
+    # have moved apart (+ margin), the bulk (clear gradients) tight, the logits close.
+    lr = 1e-3
+    assert np.abs(lg.cpu().numpy() - GOLD["adam_logits_after"].transpose(0, 2, 1)).max() < 0.25
+    assert np.median(np.abs(lg.cpu().numpy() - GOLD["adam_logits_after"].transpose(0, 2, 1))) < 0.02
+    state = tr.state_dict()
+    for name, ref in _adam_targets().items():
+        v = state[name].reshape(-1)
+        v = v if v.size <= FULL_MAX else v[sample_index(name[len("inlier_model."):], v.size, meta["seed"])]
+        err = np.abs(v - ref)
+        if name.endswith("running_var"):
+            assert err.max() <= 2e-3 * np.abs(ref).max(), name
+            continue
+        assert err.max() <= 2 * 3 * lr * 1.05, name
+        assert np.median(err) <= 2e-4, (name, float(np.median(err)))
+
+
+@pytest.mark.gpu
+def test_adam_kernel_matches_torch_optim():
+    """dsir_t_adam against torch.optim.Adam on given gradients, five steps (bias corrections included)."""
+    from deepsir_amd.train import _Ops, _ptr
+    o = _Ops(_dev())
+    g = torch.Generator().manual_seed(11)
+    p = torch.randn(5000, generator=g)
+    ref = p.clone().requires_grad_()
+    opt = torch.optim.Adam([ref], lr=3e-3)
+    pd, m, v = p.to(_dev()), torch.zeros(5000, device=_dev()), torch.zeros(5000, device=_dev())
+    for step in range(1, 6):
+        grad = torch.randn(5000, generator=g) * 10.0 ** float(torch.randint(-6, 2, (1,), generator=g))
+        ref.grad = grad.clone()
+        opt.step()
+        assert o.lib.dsir_t_adam(o.stream, _ptr(pd), _ptr(grad.to(_dev())), _ptr(m), _ptr(v), 5000, 3e-3, 0.9, 0.999, 1e-8, step) == 0
+    assert torch.allclose(pd.cpu(), ref.detach(), rtol=1e-5, atol=2e-6)
+
+
+@pytest.mark.gpu
+def test_train_step_align_lowers_the_loss():
+    """The whole step of the `align` pipeline on the device: inference engine (no_grad half) -> inlier model in training
+    mode per iteration -> ScanAlignmentLoss + gradient -> backward -> Adam.  A few steps on one batch must lower the loss,
+    and the updated weights, loaded back into the engine, must change its poses accordingly."""
+    from deepsir_amd.engine import Engine
+    from deepsir_amd.synth import make_pair
+    from deepsir_amd.train import train_step_align
+    n, P, n_iter = 1024, 2, 3
+    sd = generate_state_dict(CFG, 3, "plain")
+    eng = Engine(CFG, max_points=n, max_pairs=P)
+    eng.load_state_dict(sd)
+    raws = [make_pair(n, 100 + b, 3) for b in range(P)]
+    src = torch.from_numpy(np.concatenate([r["points_src"] for r in raws])).to(_dev())
+    ref = torch.from_numpy(np.concatenate([r["points_ref"] for r in raws])).to(_dev())
+    gt = torch.from_numpy(np.concatenate([r["transform_gt"] for r in raws]).astype(np.float32)).to(_dev())
+    sx, sn, ss, si = eng.knn_pyramid(src)
+    res = eng.register(src, ref, n_iter=n_iter)
+    batch = {"points_src": src, "points_ref": ref, "src_xyz": sx, "src_neigh": sn, "src_sub": ss, "src_interp": si}
+    tr = _trainer(sd)
+    losses = []
+    for step in range(6):
+        out = train_step_align(eng, tr, batch, res, gt, labels=None, lr=2e-3, dropout_seed=None)
+        assert not out["skipped"]
+        losses.append(out["losses"]["total"])
+    assert np.isfinite(losses).all() and losses[-1] < losses[0], losses
