@@ -110,8 +110,9 @@ SYMBOLS = {
     "dsir_t_gemm_dw_scratch": (C.c_size_t, [C.c_int64, C.c_int, C.c_int]),
     "dsir_t_gemm_dw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p,
                                  C.c_void_p, C.c_void_p]),
+    "dsir_t_gn_scratch": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "dsir_t_gn_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
-                                C.c_void_p, C.c_void_p]),
+                                C.c_void_p, C.c_void_p, C.c_void_p]),
     "dsir_t_gn_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                 C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dsir_t_bn_running": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_void_p, C.c_void_p]),

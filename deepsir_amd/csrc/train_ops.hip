@@ -111,24 +111,34 @@ __global__ __launch_bounds__(256) void t_gemm_dw_kernel(const float* __restrict_
   }
 }
 
-__global__ void t_gemm_dw_reduce_kernel(const float* __restrict__ partial, int splits, int N, int K, int Kp, float* __restrict__ dW,
-                                        float* __restrict__ db) {
-  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= (int64_t)N * Kp) return;
-  const int n = (int)(e / Kp), k = (int)(e % Kp);
+// eight lanes per element: lane j sums the splits j, j + 8, ... in order, then a fixed xor tree (deterministic)
+__global__ __launch_bounds__(256) void t_gemm_dw_reduce_kernel(const float* __restrict__ partial, int splits, int N, int K, int Kp,
+                                                               float* __restrict__ dW, float* __restrict__ db) {
+  const int64_t e = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
+  const int j = threadIdx.x & 7;
+  const int64_t total = (int64_t)N * Kp;
   float s = 0.f;
-  for (int i = 0; i < splits; ++i) s += partial[(int64_t)i * N * Kp + e];
+  if (e < total)
+    for (int i = j; i < splits; i += 8) s += partial[(int64_t)i * total + e];
+  s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+  if (e >= total || j != 0) return;
+  const int n = (int)(e / Kp), k = (int)(e % Kp);
   if (k < K) dW[(int64_t)n * K + k] += s;
   else if (db) db[n] += s;
 }
 
 // ---- GroupNorm / BatchNorm(train) -------------------------------------------------------------------------------------
-// one block per (cloud, group): mean and 1 / sqrt(var + eps) over M rows x gw channels, fp64 accumulation
-__global__ __launch_bounds__(256) void t_gn_stats_kernel(const float* __restrict__ Y, int M, int C, int groups, float* __restrict__ stats) {
-  const int cloud = blockIdx.y, g = blockIdx.x, gw = C / groups;
-  const float* base = Y + (int64_t)cloud * M * C + g * gw;
+constexpr int GN_CHUNK_ROWS = 1024, GN_MAX_CHUNKS = 64;
+inline int gn_chunks(int M) { const int c = (M + GN_CHUNK_ROWS - 1) / GN_CHUNK_ROWS; return c < 1 ? 1 : (c > GN_MAX_CHUNKS ? GN_MAX_CHUNKS : c); }
+
+// stage 1: one block per (row chunk, group, cloud): sum and sum of squares over its rows x gw channels, fp64
+__global__ __launch_bounds__(256) void t_gn_stats_kernel(const float* __restrict__ Y, int M, int C, int groups, int rows_per_chunk,
+                                                         double* __restrict__ partial) {
+  const int chunk = blockIdx.x, g = blockIdx.y, cloud = blockIdx.z, gw = C / groups, nchunks = gridDim.x;
+  const int r0 = chunk * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
+  const float* base = Y + ((int64_t)cloud * M + r0) * C + g * gw;
   double s1 = 0.0, s2 = 0.0;
-  const int64_t total = (int64_t)M * gw;
+  const int64_t total = (int64_t)max(r1 - r0, 0) * gw;
   for (int64_t e = threadIdx.x; e < total; e += 256) {
     const float v = base[(e / gw) * C + (e % gw)];
     s1 += v; s2 += (double)v * v;
@@ -138,13 +148,24 @@ __global__ __launch_bounds__(256) void t_gn_stats_kernel(const float* __restrict
   if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = s1; sh[1][threadIdx.x >> 6] = s2; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    const double a = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3], b = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
-    const double mean = a / (double)total;
-    double var = b / (double)total - mean * mean;
-    var = var > 0.0 ? var : 0.0;
-    stats[((int64_t)cloud * groups + g) * 2] = (float)mean;
-    stats[((int64_t)cloud * groups + g) * 2 + 1] = (float)(1.0 / sqrt(var + 1e-5));
+    double* o = partial + (((int64_t)cloud * groups + g) * nchunks + chunk) * 2;
+    o[0] = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
+    o[1] = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
   }
+}
+
+// stage 2: chunks in order -> mean, 1 / sqrt(var + eps)
+__global__ void t_gn_stats_final_kernel(const double* __restrict__ partial, int nchunks, int count, double inv_total,
+                                        float* __restrict__ stats) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;      // cloud * groups + g
+  if (i >= count) return;
+  double a = 0.0, b = 0.0;
+  for (int c = 0; c < nchunks; ++c) { a += partial[((int64_t)i * nchunks + c) * 2]; b += partial[((int64_t)i * nchunks + c) * 2 + 1]; }
+  const double mean = a * inv_total;
+  double var = b * inv_total - mean * mean;
+  var = var > 0.0 ? var : 0.0;
+  stats[2 * i] = (float)mean;
+  stats[2 * i + 1] = (float)(1.0 / sqrt(var + 1e-5));
 }
 
 __global__ void t_gn_apply_kernel(const float* __restrict__ Y, const float* __restrict__ stats, int M, int C, int groups,
@@ -161,19 +182,20 @@ __global__ void t_gn_apply_kernel(const float* __restrict__ Y, const float* __re
   }
 }
 
-// per (cloud, channel): s1 = sum_r g, s2 = sum_r g xhat, g = dOut * slope(v); block = 32 channels x 8 row lanes
+// stage 1, per (cloud, row chunk, channel): s1 = sum_r g, s2 = sum_r g xhat, g = dOut * slope(v); block = 32 channels x 8 row lanes
 __global__ __launch_bounds__(256) void t_gn_bwd_sums_kernel(const float* __restrict__ dOut, const float* __restrict__ Y,
                                                             const float* __restrict__ stats, int M, int C, int groups,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta, int act,
-                                                            float* __restrict__ sums) {
-  const int cloud = blockIdx.y;
+                                                            int rows_per_chunk, float* __restrict__ partial) {
+  const int cloud = blockIdx.z, chunk = blockIdx.y, nchunks = gridDim.y;
   const int c = blockIdx.x * 32 + (threadIdx.x & 31), ry = threadIdx.x >> 5;
   const int gw = C / groups;
+  const int r0 = chunk * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
   double s1 = 0.0, s2 = 0.0;
   if (c < C) {
     const float* st = stats + ((int64_t)cloud * groups + c / gw) * 2;
     const float mean = st[0], rstd = st[1], ga = gamma[c], be = beta[c];
-    for (int r = ry; r < M; r += 8) {
+    for (int r = r0 + ry; r < r1; r += 8) {
       const int64_t e = ((int64_t)cloud * M + r) * C + c;
       const float xh = (Y[e] - mean) * rstd;
       float g = dOut[e];
@@ -187,9 +209,19 @@ __global__ __launch_bounds__(256) void t_gn_bwd_sums_kernel(const float* __restr
   if (ry == 0 && c < C) {
     double a = 0.0, b = 0.0;
     for (int i = 0; i < 8; ++i) { a += sh[0][i][threadIdx.x]; b += sh[1][i][threadIdx.x]; }
-    sums[((int64_t)cloud * C + c) * 2] = (float)a;
-    sums[((int64_t)cloud * C + c) * 2 + 1] = (float)b;
+    float* o = partial + (((int64_t)cloud * nchunks + chunk) * C + c) * 2;
+    o[0] = (float)a; o[1] = (float)b;
   }
+}
+
+// stage 2: chunks in order -> sums[cloud][C][2]
+__global__ void t_gn_bwd_sums_final_kernel(const float* __restrict__ partial, int nchunks, int C, int64_t count, float* __restrict__ sums) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // (cloud * C + c) * 2 + which
+  if (i >= count) return;
+  const int64_t cloud = i / (2 * C), rest = i % (2 * C);
+  double a = 0.0;
+  for (int k = 0; k < nchunks; ++k) a += partial[(cloud * nchunks + k) * 2 * C + rest];
+  sums[i] = (float)a;
 }
 
 // dY = rstd (gamma g - mean_group(gamma g) - xhat mean_group(gamma g xhat)); one block per (row range, cloud)
@@ -421,6 +453,7 @@ inline DwPlan dw_plan(int64_t rows, int N, int K, bool bias) {
   int64_t sp = (rows + 511) / 512;                       // >= 512 rows per split
   const int64_t cap = tiles >= 2048 ? 1 : 2048 / tiles;   // ~ 2048 workgroups in all
   sp = sp > cap ? cap : sp;
+  sp = sp > 1024 ? 1024 : sp;
   sp = sp < 1 ? 1 : sp;
   p.rows_per_split = (((rows + sp - 1) / sp) + TK - 1) / TK * TK;
   p.splits = (int)((rows + p.rows_per_split - 1) / p.rows_per_split);
@@ -456,34 +489,49 @@ int dsir_t_gemm_dw(void* stream, const float* dY, int ldy, const float* X, int l
   const dim3 grid((unsigned)((N + TB - 1) / TB), (unsigned)((p.Kp + TB - 1) / TB), (unsigned)p.splits);
   hipLaunchKernelGGL(t_gemm_dw_kernel, grid, dim3(256), 0, (hipStream_t)stream, dY, ldy, X, ldx, rows, p.rows_per_split, N, K, p.Kp,
                      partial);
-  hipLaunchKernelGGL(t_gemm_dw_reduce_kernel, dim3(grid1((int64_t)N * p.Kp)), dim3(256), 0, (hipStream_t)stream, partial, p.splits, N, K,
+  hipLaunchKernelGGL(t_gemm_dw_reduce_kernel, dim3((unsigned)(((int64_t)N * p.Kp + 31) / 32)), dim3(256), 0, (hipStream_t)stream, partial, p.splits, N, K,
                      p.Kp, dW, db);
   return done();
 }
 
+size_t dsir_t_gn_scratch(int clouds, int M, int C) {
+  const size_t nch = (size_t)gn_chunks(M);
+  return ((size_t)clouds * nch * C * 2 + (size_t)clouds * C * 2) * sizeof(double);
+}
+
 int dsir_t_gn_fwd(void* stream, const float* Y, int clouds, int M, int C, int groups, const float* gamma, const float* beta, int act,
-                  float* out, float* stats) {
-  if (!Y || !gamma || !beta || !out || !stats || clouds < 1 || M < 1 || C < 1 || groups < 1 || C % groups) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL(t_gn_stats_kernel, dim3(groups, clouds), dim3(256), 0, (hipStream_t)stream, Y, M, C, groups, stats);
+                  float* out, float* stats, void* scratch) {
+  if (!Y || !gamma || !beta || !out || !stats || !scratch || clouds < 1 || M < 1 || C < 1 || groups < 1 || C % groups)
+    return (int)hipErrorInvalidValue;
+  hipStream_t st = (hipStream_t)stream;
+  const int nch = gn_chunks(M), rpc = (M + nch - 1) / nch;
+  double* partial = reinterpret_cast<double*>(scratch);
+  hipLaunchKernelGGL(t_gn_stats_kernel, dim3(nch, groups, clouds), dim3(256), 0, st, Y, M, C, groups, rpc, partial);
+  hipLaunchKernelGGL(t_gn_stats_final_kernel, dim3((clouds * groups + 255) / 256), dim3(256), 0, st, partial, nch, clouds * groups,
+                     1.0 / ((double)M * (C / groups)), stats);
   const int64_t total = (int64_t)clouds * M * C;
-  hipLaunchKernelGGL(t_gn_apply_kernel, dim3(grid1(total)), dim3(256), 0, (hipStream_t)stream, Y, stats, M, C, groups, gamma, beta, act, out,
-                     total);
+  hipLaunchKernelGGL(t_gn_apply_kernel, dim3(grid1(total)), dim3(256), 0, st, Y, stats, M, C, groups, gamma, beta, act, out, total);
   return done();
 }
 
 int dsir_t_gn_bwd(void* stream, const float* dOut, const float* Y, const float* stats, int clouds, int M, int C, int groups,
-                  const float* gamma, const float* beta, int act, float* dY, float* dgamma, float* dbeta, float* scratch) {
+                  const float* gamma, const float* beta, int act, float* dY, float* dgamma, float* dbeta, void* scratch) {
   if (!dOut || !Y || !stats || !gamma || !beta || !dY || !dgamma || !dbeta || !scratch || clouds < 1 || M < 1 || C < 1 || groups < 1 ||
       C % groups || groups > 4096)
     return (int)hipErrorInvalidValue;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(t_gn_bwd_sums_kernel, dim3((C + 31) / 32, clouds), dim3(256), 0, st, dOut, Y, stats, M, C, groups, gamma, beta, act,
-                     scratch);
+  const int nch = gn_chunks(M), rpc = (M + nch - 1) / nch;
+  float* partial = reinterpret_cast<float*>(scratch);
+  float* sums = partial + (size_t)clouds * nch * C * 2;
+  hipLaunchKernelGGL(t_gn_bwd_sums_kernel, dim3((C + 31) / 32, nch, clouds), dim3(256), 0, st, dOut, Y, stats, M, C, groups, gamma, beta, act,
+                     rpc, partial);
+  const int64_t cnt = (int64_t)clouds * C * 2;
+  hipLaunchKernelGGL(t_gn_bwd_sums_final_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, partial, nch, C, cnt, sums);
   int rpb = (int)(((int64_t)16384 + C - 1) / C);         // ~ 16 k elements per block
   rpb = rpb < 1 ? 1 : rpb;
   hipLaunchKernelGGL(t_gn_bwd_apply_kernel, dim3((M + rpb - 1) / rpb, clouds), dim3(256), (size_t)groups * 2 * sizeof(float), st, dOut, Y,
-                     stats, scratch, M, C, groups, gamma, beta, act, dY, rpb);
-  hipLaunchKernelGGL(t_gn_bwd_params_kernel, dim3((C + 255) / 256), dim3(256), 0, st, scratch, clouds, C, dgamma, dbeta);
+                     stats, sums, M, C, groups, gamma, beta, act, dY, rpb);
+  hipLaunchKernelGGL(t_gn_bwd_params_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums, clouds, C, dgamma, dbeta);
   return done();
 }
 

@@ -39,10 +39,13 @@ class _Ops:
         self.lib = _lib.load()
         self.device = device
         self._scratch: Optional[torch.Tensor] = None
+        self.stream = 0
+        self.begin()
 
-    @property
-    def stream(self) -> int:
-        return torch.cuda.current_stream(self.device).cuda_stream
+    def begin(self) -> None:
+        """Binds the operators to torch's CURRENT stream (called at the start of every forward / backward / optimiser step:
+        looking the stream up per launch costs more host time than most of these kernels run)."""
+        self.stream = torch.cuda.current_stream(self.device).cuda_stream
 
     def _ok(self, rc: int, what: str) -> None:
         if rc != 0:
@@ -88,15 +91,16 @@ class _Ops:
         M = y.shape[0] // clouds
         out = self.empty(y.shape[0], C_)
         stats = self.empty(clouds, groups, 2)
+        sc = self.scratch(self.lib.dsir_t_gn_scratch(clouds, M, C_))
         self._ok(self.lib.dsir_t_gn_fwd(self.stream, _ptr(y), clouds, M, C_, groups, _ptr(gamma), _ptr(beta), int(act), _ptr(out),
-                                        _ptr(stats)), "dsir_t_gn_fwd")
+                                        _ptr(stats), _ptr(sc)), "dsir_t_gn_fwd")
         return out, stats
 
     def gn_bwd(self, dout, y, stats, clouds, groups, gamma, beta, act, dgamma, dbeta) -> torch.Tensor:
         C_ = y.shape[1]
         M = y.shape[0] // clouds
         dy = self.empty(y.shape[0], C_)
-        sc = self.scratch(clouds * C_ * 2 * 4)
+        sc = self.scratch(self.lib.dsir_t_gn_scratch(clouds, M, C_))
         self._ok(self.lib.dsir_t_gn_bwd(self.stream, _ptr(dout), _ptr(y), _ptr(stats), clouds, M, C_, groups, _ptr(gamma), _ptr(beta),
                                         int(act), _ptr(dy), _ptr(dgamma), _ptr(dbeta), _ptr(sc)), "dsir_t_gn_bwd")
         return dy
@@ -247,6 +251,7 @@ class RandlaTrainer:
         """torch.optim.Adam.step (train.py:323, :446)."""
         self.step_count += 1
         o = self.ops
+        o.begin()
         for k, p in self.params.items():
             o._ok(o.lib.dsir_t_adam(o.stream, _ptr(p), _ptr(self.grads[k]), _ptr(self.adam_m[k]), _ptr(self.adam_v[k]), p.numel(), lr,
                                     betas[0], betas[1], eps, self.step_count), "dsir_t_adam")
@@ -336,6 +341,7 @@ class RandlaTrainer:
         features [clouds][N][feat_in]; pyramids as ``Engine.knn_pyramid`` returns them (int32).
         -> logits [clouds][N][num_classes], tape."""
         o = self.ops
+        o.begin()
         pf = self.prefix
         clouds, N, cin = features.shape
         L = len(self.cfg.d_out)
@@ -397,6 +403,7 @@ class RandlaTrainer:
         """Accumulates d loss / d parameter into ``self.grads`` (call ``zero_grad`` between steps, not between the
         registration iterations of one step: their gradients add up, as autograd's do)."""
         o = self.ops
+        o.begin()
         pf = self.prefix
         net = tape.misc["net"]
         clouds, N, n, L = net["clouds"], net["N"], net["n"], net["L"]
@@ -457,6 +464,7 @@ def train_step_align(engine, trainer: RandlaTrainer, batch: dict, result: dict, 
     gen = torch.Generator(device="cpu")
     if dropout_seed is not None:
         gen.manual_seed(int(dropout_seed))
+    trainer.ops.begin()
     for it in range(n_iter):
         # the src cloud moved by the previous cumulative pose (model.py:587; R_t.detach()) next to its correspondences
         cat = trainer.ops.inlier_input(xyz_s, xyz_r, idx[it], None if it == 0 else T[:, it - 1])

@@ -37,12 +37,14 @@ int dsir_t_gemm_dw(void* stream, const float* dY, int ldy, const float* X, int l
 
 /* nn.GroupNorm(groups, C) (+ LeakyReLU 0.2 when act) over one cloud's [M][C] block (RandLANet.py:90-107), also
  * nn.BatchNorm1d in training mode (clouds = 1, M = all rows, groups = C; RandLANet.py:44): biased variance, eps 1e-5.
- * stats [clouds][groups][2] = {mean, rstd} are kept for the backward. */
+ * stats [clouds][groups][2] = {mean, rstd} are kept for the backward.  scratch: dsir_t_gn_scratch(clouds, M, C) bytes
+ * (partial sums of up to 64 row chunks per cloud, reduced in chunk order). */
+size_t dsir_t_gn_scratch(int clouds, int M, int C);
 int dsir_t_gn_fwd(void* stream, const float* Y, int clouds, int M, int C, int groups, const float* gamma, const float* beta,
-                  int act, float* out, float* stats);
-/* dY (may alias dOut) = d loss / d Y; dgamma / dbeta accumulate.  scratch: clouds * C * 2 floats. */
+                  int act, float* out, float* stats, void* scratch);
+/* dY (may alias dOut) = d loss / d Y; dgamma / dbeta accumulate. */
 int dsir_t_gn_bwd(void* stream, const float* dOut, const float* Y, const float* stats, int clouds, int M, int C, int groups,
-                  const float* gamma, const float* beta, int act, float* dY, float* dgamma, float* dbeta, float* scratch);
+                  const float* gamma, const float* beta, int act, float* dY, float* dgamma, float* dbeta, void* scratch);
 
 /* The running statistics nn.BatchNorm1d keeps in training mode (momentum 0.1, unbiased variance); stats = dsir_t_gn_fwd's
  * with groups = C over M rows. */

@@ -308,3 +308,56 @@ def test_train_step_align_lowers_the_loss():
         assert not out["skipped"]
         losses.append(out["losses"]["total"])
     assert np.isfinite(losses).all() and losses[-1] < losses[0], losses
+
+
+@pytest.mark.gpu
+def test_train_step_align_gradients_match_the_oracle():
+    """The composed step (inlier input per iteration, training-mode forward, ScanAlignmentLoss incl. the confidence term,
+    gradients of all iterations accumulated) against the same composition under torch autograd on the CPU oracle."""
+    from deepsir_amd.engine import Engine
+    from deepsir_amd.synth import make_pair
+    from deepsir_amd.train import train_step_align
+    from oracle import align_loss as oal
+    n, P, n_iter = 1024, 2, 3
+    sd = generate_state_dict(CFG, 4, "plain")
+    eng = Engine(CFG, max_points=n, max_pairs=P)
+    eng.load_state_dict(sd)
+    raws = [make_pair(n, 200 + b, 3) for b in range(P)]
+    src_np = np.concatenate([r["points_src"] for r in raws])
+    ref_np = np.concatenate([r["points_ref"] for r in raws])
+    gt_np = np.concatenate([r["transform_gt"] for r in raws]).astype(np.float32)
+    src, ref, gt = (torch.from_numpy(a).to(_dev()) for a in (src_np, ref_np, gt_np))
+    sx, sn, ss, si = eng.knn_pyramid(src)
+    res = eng.register(src, ref, n_iter=n_iter)
+    rng = np.random.Generator(np.random.Philox(key=8))
+    labels_np = (rng.random((n_iter, P, n)) < 0.6).astype(np.float32)
+    batch = {"points_src": src, "points_ref": ref, "src_xyz": sx, "src_neigh": sn, "src_sub": ss, "src_interp": si}
+    tr = _trainer(sd)
+    out = train_step_align(eng, tr, batch, res, gt, labels=torch.from_numpy(labels_np).to(_dev()), apply=False)
+    torch.cuda.synchronize()
+    # ---- the same composition on the oracle
+    net = OracleNet(CFG, sd)
+    params = otrain.trainable(net)
+    idx = [res["idx"][i].cpu().long() for i in range(n_iter)]
+    T = res["transforms"].cpu()
+    ps, pr = torch.from_numpy(src_np[:, :, :3]), torch.from_numpy(ref_np[:, :, :3])
+    pyr = [t.cpu() for t in (sx, sn.long(), ss.long(), si.long())]
+    logits = []
+    for i in range(n_iter):
+        cur = ps if i == 0 else OracleNet.se3_apply(T[:, i - 1], ps)
+        cat = torch.cat([cur, torch.gather(pr, 1, idx[i][:, :, None].expand(-1, -1, 3))], 2)
+        logits.append(otrain.randla_train(net, "inlier_model", cat, *pyr, None).squeeze(1))
+    poses = oal.replay(ps, pr, idx, logits)
+    d = oal.scan_alignment_loss(ps, poses, torch.from_numpy(gt_np), logits, [torch.from_numpy(l) for l in labels_np])
+    d["total"].backward()
+    assert abs(out["losses"]["total"] - float(d["total"])) < 1e-4 * max(1.0, abs(float(d["total"])))
+    assert np.abs(out["logits"].cpu().numpy() - torch.stack(logits).detach().numpy()).max() < 1e-3
+    worst = 0.0
+    for k, p in params.items():
+        g, r = tr.grads[k].cpu().numpy().reshape(-1), p.grad.numpy().reshape(-1)
+        if k.endswith(ZERO_BY_CONSTRUCTION):
+            continue
+        err = np.abs(g - r).max() / (np.abs(r).max() + 1e-12)
+        worst = max(worst, err)
+        assert err < 2e-2, (k, err)
+    assert worst > 0.0
