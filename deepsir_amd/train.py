@@ -212,8 +212,12 @@ class RandlaTrainer:
         self.cfg, self.prefix, self.feat_in, self.num_classes = cfg, prefix, feat_in, num_classes
         self.device = torch.device(device)
         self.ops = _Ops(self.device)
-        self.params: Dict[str, torch.Tensor] = {}
+        # ONE flat device buffer each for parameters, gradients and the two Adam moments (every tensor a 256-byte aligned
+        # view): zero_grad is one fill, the optimiser step ONE launch over all parameters
+        host: Dict[str, torch.Tensor] = {}
         self.buffers: Dict[str, torch.Tensor] = {}
+        offsets: Dict[str, int] = {}
+        total = 0
         for spec in randla_specs(prefix, feat_in, num_classes, cfg):
             if spec.kind == "bn_count":
                 continue
@@ -224,16 +228,24 @@ class RandlaTrainer:
             if tuple(t.shape) != tuple(spec.shape):
                 raise ValueError(f"{spec.name}: shape {tuple(t.shape)} != {tuple(spec.shape)}")
             t = t.reshape(t.shape[0], -1).contiguous() if t.dim() > 1 else t.contiguous()
-            (self.buffers if spec.kind in ("bn_mean", "bn_var") else self.params)[spec.name] = t.to(self.device)
-        self.grads = {k: torch.zeros_like(v) for k, v in self.params.items()}
-        self.adam_m = {k: torch.zeros_like(v) for k, v in self.params.items()}
-        self.adam_v = {k: torch.zeros_like(v) for k, v in self.params.items()}
+            if spec.kind in ("bn_mean", "bn_var"):
+                self.buffers[spec.name] = t.to(self.device)
+            else:
+                host[spec.name] = t
+                offsets[spec.name] = total
+                total += (t.numel() + 63) // 64 * 64
+        self.flat_p = torch.zeros(total, dtype=torch.float32, device=self.device)
+        self.flat_g, self.flat_m, self.flat_v = (torch.zeros_like(self.flat_p) for _ in range(3))
+        view = lambda flat, k: flat[offsets[k]:offsets[k] + host[k].numel()].view(host[k].shape)
+        self.params: Dict[str, torch.Tensor] = {k: view(self.flat_p, k) for k in host}
+        self.grads: Dict[str, torch.Tensor] = {k: view(self.flat_g, k) for k in host}
+        for k, t in host.items():
+            self.params[k].copy_(t)
         self.step_count = 0
 
     # ------------------------------------------------------------------ bookkeeping
     def zero_grad(self) -> None:
-        for g in self.grads.values():
-            g.zero_()
+        self.flat_g.zero_()
 
     def state_dict(self) -> Dict[str, np.ndarray]:
         """Parameters and BatchNorm running statistics in the reference's shapes (host)."""
@@ -252,9 +264,8 @@ class RandlaTrainer:
         self.step_count += 1
         o = self.ops
         o.begin()
-        for k, p in self.params.items():
-            o._ok(o.lib.dsir_t_adam(o.stream, _ptr(p), _ptr(self.grads[k]), _ptr(self.adam_m[k]), _ptr(self.adam_v[k]), p.numel(), lr,
-                                    betas[0], betas[1], eps, self.step_count), "dsir_t_adam")
+        o._ok(o.lib.dsir_t_adam(o.stream, _ptr(self.flat_p), _ptr(self.flat_g), _ptr(self.flat_m), _ptr(self.flat_v), self.flat_p.numel(),
+                                lr, betas[0], betas[1], eps, self.step_count), "dsir_t_adam")   # the alignment padding stays 0
 
     # ------------------------------------------------------------------ layers
     def _mlp2d(self, tape: RandlaTape, name: str, x: torch.Tensor, clouds: int, act: bool = True) -> torch.Tensor:
@@ -479,9 +490,99 @@ def train_step_align(engine, trainer: RandlaTrainer, batch: dict, result: dict, 
     g = out["grad_logits"]
     for it in range(n_iter):
         trainer.backward(tapes[it], g[it])
-    bad = any(bool(torch.isnan(v).any()) for v in trainer.grads.values())
+    bad = bool(torch.isnan(trainer.flat_g).any())
     if apply and not bad:
         trainer.adam_step(lr)
     out["logits"] = lg_all
     out["skipped"] = bad
     return out
+
+
+class AlignTrainStep:
+    """``train_step_align`` for a fixed batch geometry with its two launch-bound halves replayed from hipGraphs.
+
+    A step is ~6 000 small launches (20 operators x ~60 layers x n_iter, forward and backward); issued one by one from the
+    host they cost more wall time than they run (32 pairs x 5000 points: 370 ms per step for 115 ms of kernels).  The
+    operators are launched on torch's current stream, so ``torch.cuda.graph`` captures them like torch's own kernels: graph F
+    = the n_iter training-mode forwards (inlier input, layers, BatchNorm running statistics), graph B = zero_grad + the n_iter
+    backwards.  Between them the loss and its gradient (``Engine.align_loss_backward``, its own launch) and after them ONE
+    Adam launch over the flat parameter buffer, whose bias corrections change per step and therefore stay outside.
+    The first call runs eagerly (it IS a training step), the second captures, later ones replay.  Inputs are copied into
+    static device buffers; results are those of ``train_step_align`` bit for bit except for the order of the fp32 atomics."""
+
+    def __init__(self, engine, trainer: RandlaTrainer, pairs: int, n_src: int, n_ref: int, n_iter: int, dropout: bool = True,
+                 use_graph: bool = True):
+        self.engine, self.tr = engine, trainer
+        self.P, self.N, self.K, self.n_iter, self.dropout, self.use_graph = pairs, n_src, n_ref, n_iter, dropout, use_graph
+        dev = trainer.device
+        S = sum(level_sizes(n_src, trainer.cfg.sub_sampling_ratio)[:len(trainer.cfg.d_out)])
+        S1 = sum(level_sizes(n_src, trainer.cfg.sub_sampling_ratio)[1:len(trainer.cfg.d_out) + 1])
+        z = lambda shape, dt=torch.float32: torch.zeros(shape, dtype=dt, device=dev)
+        self.xyz_s, self.xyz_r = z((pairs, n_src, 3)), z((pairs, n_ref, 3))
+        self.src_xyz, self.neigh = z((pairs, S, 3)), z((pairs, S, K_NN), torch.int32)
+        self.sub, self.interp = z((pairs, S1, K_NN), torch.int32), z((pairs, S, 1), torch.int32)
+        self.idx, self.T = z((n_iter, pairs, n_src), torch.int32), z((pairs, n_iter, 3, 4))
+        self.masks = z((n_iter, pairs, n_src, trainer.cfg.out_feat_dim), torch.uint8) if dropout else None
+        self.logits, self.grad = z((n_iter, pairs, n_src)), z((n_iter, pairs, n_src))
+        self.tapes: List[RandlaTape] = []
+        self.gf = self.gb = None
+        self.calls = 0
+        self.gen = torch.Generator(device=dev)
+
+    def _forward_all(self) -> None:
+        tr = self.tr
+        tr.ops.begin()
+        self.tapes = []
+        for it in range(self.n_iter):
+            cat = tr.ops.inlier_input(self.xyz_s, self.xyz_r, self.idx[it], None if it == 0 else self.T[:, it - 1])
+            lg, tape = tr.forward(cat, self.src_xyz, self.neigh, self.sub, self.interp, None if self.masks is None else self.masks[it])
+            self.logits[it].copy_(lg.reshape(self.P, self.N))
+            self.tapes.append(tape)
+
+    def _backward_all(self) -> None:
+        self.tr.zero_grad()
+        for it in range(self.n_iter):
+            self.tr.backward(self.tapes[it], self.grad[it])
+
+    def step(self, batch: dict, result: dict, transform_gt, labels=None, lr: float = 1e-3, dropout_seed: Optional[int] = None,
+             loss_kwargs: Optional[dict] = None, apply: bool = True) -> dict:
+        tr = self.tr
+        self.xyz_s.copy_(batch["points_src"][:, :, :3]); self.xyz_r.copy_(batch["points_ref"][:, :, :3])
+        self.src_xyz.copy_(batch["src_xyz"]); self.neigh.copy_(batch["src_neigh"])
+        self.sub.copy_(batch["src_sub"]); self.interp.copy_(batch["src_interp"])
+        self.idx.copy_(result["idx"]); self.T.copy_(result["transforms"])
+        if self.masks is not None:
+            if dropout_seed is not None:
+                self.gen.manual_seed(int(dropout_seed))
+            self.masks.copy_(torch.rand(self.masks.shape, generator=self.gen, device=tr.device) >= 0.5)
+        self.calls += 1
+        graphs = self.use_graph and self.calls >= 2
+        if graphs and self.gf is None:
+            tr.ops._scratch = None                                     # the captured launches get scratch from the graph's pool
+            torch.cuda.synchronize()
+            self.gf = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.gf):
+                self._forward_all()
+        if graphs:
+            self.gf.replay()
+        else:
+            self._forward_all()
+        out = self.engine.align_loss_backward(self.xyz_s, self.xyz_r, self.idx, self.logits, labels, transform_gt, **(loss_kwargs or {}))
+        self.grad.copy_(out["grad_logits"])
+        if graphs and self.gb is None:
+            torch.cuda.synchronize()
+            self.gb = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.gb, pool=self.gf.pool()):
+                self._backward_all()
+            tr.ops._scratch = None                                     # eager callers allocate their own again
+        if graphs:
+            self.gb.replay()
+        else:
+            self._backward_all()
+        tr.ops.begin()
+        bad = bool(torch.isnan(tr.flat_g).any())
+        if apply and not bad:
+            tr.adam_step(lr)
+        out["logits"] = self.logits
+        out["skipped"] = bad
+        return out

@@ -361,3 +361,35 @@ def test_train_step_align_gradients_match_the_oracle():
         worst = max(worst, err)
         assert err < 2e-2, (k, err)
     assert worst > 0.0
+
+
+@pytest.mark.gpu
+def test_graph_replayed_step_equals_the_eager_step():
+    """AlignTrainStep (forward and backward halves replayed from hipGraphs) against train_step_align, three steps each from
+    the same start: same losses and, up to the order of the fp32 atomics in the scatter-adds, the same weights."""
+    from deepsir_amd.engine import Engine
+    from deepsir_amd.synth import make_pair
+    from deepsir_amd.train import AlignTrainStep, train_step_align
+    n, P, n_iter = 1024, 2, 3
+    sd = generate_state_dict(CFG, 6, "plain")
+    eng = Engine(CFG, max_points=n, max_pairs=P)
+    eng.load_state_dict(sd)
+    raws = [make_pair(n, 300 + b, 3) for b in range(P)]
+    src = torch.from_numpy(np.concatenate([r["points_src"] for r in raws])).to(_dev())
+    ref = torch.from_numpy(np.concatenate([r["points_ref"] for r in raws])).to(_dev())
+    gt = torch.from_numpy(np.concatenate([r["transform_gt"] for r in raws]).astype(np.float32)).to(_dev())
+    sx, sn, ss, si = eng.knn_pyramid(src)
+    res = eng.register(src, ref, n_iter=n_iter)
+    batch = {"points_src": src, "points_ref": ref, "src_xyz": sx, "src_neigh": sn, "src_sub": ss, "src_interp": si}
+    a, b = _trainer(sd), _trainer(sd)
+    stepper = AlignTrainStep(eng, b, P, n, n, n_iter, dropout=False)
+    la, lb = [], []
+    for s in range(4):
+        la.append(train_step_align(eng, a, batch, res, gt, lr=1e-3)["losses"]["total"])
+        lb.append(stepper.step(batch, res, gt, lr=1e-3)["losses"]["total"])
+    assert stepper.gf is not None and stepper.gb is not None
+    assert np.allclose(la, lb, rtol=2e-3), (la, lb)
+    assert la[-1] < la[0]
+    torch.cuda.synchronize()
+    d = (a.flat_p - b.flat_p).abs()
+    assert float(d.max()) <= 2 * 4 * 1e-3 * 1.05 and float(d.median()) < 1e-4     # see test_device_adam_steps_match_reference
