@@ -19,6 +19,18 @@ LABEL_WEIGHTS = (3, 1, 1, 3, 2, 0, 0, 0, 6, 5, 6, 4, 7, 7, 6, 8, 4, 9, 9)
 """Semantic score LUT, reference network/model.py:146-150 (not in the state-dict)."""
 
 
+SEMANTIC_KITTI_POINTS_PER_CLASS = (55437630, 320797, 541736, 2578735, 3274484, 552662, 184064, 78858, 240942562, 17294618, 170599734,
+                                   6369672, 230413074, 101130274, 476491114, 9833174, 129609852, 4506626, 1168181)
+"""Training-set point counts of the 19 SemanticKITTI classes: the constants behind SemanticLoss's cross-entropy weights
+(reference network/loss.py:906-909)."""
+
+
+def semantic_class_weights():
+    """SemanticLoss.get_class_weights('SemanticKITTI') (loss.py:896-912): 1 / (class frequency + 0.02) -> 19 floats."""
+    total = float(sum(SEMANTIC_KITTI_POINTS_PER_CLASS))
+    return [1.0 / (n / total + 0.02) for n in SEMANTIC_KITTI_POINTS_PER_CLASS]
+
+
 @dataclass
 class NetConfig:
     """The ``args`` fields the hot path reads (reference arguments.py:27-82,

@@ -442,6 +442,63 @@ __global__ void t_bn_running_kernel(const float* __restrict__ stats, int C, doub
   rvar[c] = (float)((1.0 - momentum) * rvar[c] + momentum * var);
 }
 
+// weighted cross entropy, stage 1: one thread per row; labels 0 = ignored, class = label - 1 (SemanticLoss.compute_loss);
+// dlogits = w_y (softmax - onehot) (scaled by 1 / sum w in stage 2); per-block partial {sum w nll, sum w, correct, valid}
+__global__ __launch_bounds__(256) void t_wce_rows_kernel(const float* __restrict__ logits, const int32_t* __restrict__ labels,
+                                                         const float* __restrict__ cw, int64_t rows, int C, float* __restrict__ dlogits,
+                                                         double* __restrict__ partial) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  double nll = 0.0, w = 0.0, correct = 0.0, valid = 0.0;
+  if (r < rows) {
+    const float* x = logits + r * C;
+    float* d = dlogits + r * C;
+    const int lab = labels[r];
+    if (lab < 1 || lab > C) {
+      for (int c = 0; c < C; ++c) d[c] = 0.f;
+    } else {
+      const int y = lab - 1;
+      float mx = x[0];
+      int am = 0;
+      for (int c = 1; c < C; ++c) if (x[c] > mx) { mx = x[c]; am = c; }
+      float se = 0.f;
+      for (int c = 0; c < C; ++c) se += expf(x[c] - mx);
+      const float lse = mx + logf(se), wy = cw[y];
+      for (int c = 0; c < C; ++c) d[c] = wy * (expf(x[c] - lse) - (c == y ? 1.f : 0.f));
+      nll = (double)wy * (double)(lse - x[y]); w = wy; correct = am == y ? 1.0 : 0.0; valid = 1.0;
+    }
+  }
+  nll = wave_sum(nll); w = wave_sum(w); correct = wave_sum(correct); valid = wave_sum(valid);
+  __shared__ double sh[4][4];
+  if ((threadIdx.x & 63) == 0) { const int i = threadIdx.x >> 6; sh[0][i] = nll; sh[1][i] = w; sh[2][i] = correct; sh[3][i] = valid; }
+  __syncthreads();
+  if (threadIdx.x < 4) partial[(int64_t)blockIdx.x * 4 + threadIdx.x] = sh[threadIdx.x][0] + sh[threadIdx.x][1] + sh[threadIdx.x][2] + sh[threadIdx.x][3];
+}
+
+// stage 2 (one block): blocks in order -> out {loss = sum w nll / sum w, sum w, correct, valid}
+__global__ __launch_bounds__(256) void t_wce_final_kernel(const double* __restrict__ partial, int blocks, double* __restrict__ out) {
+  __shared__ double sh[4][256];
+  double a[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int b = threadIdx.x; b < blocks; b += 256)
+    for (int k = 0; k < 4; ++k) a[k] += partial[(int64_t)b * 4 + k];
+  for (int k = 0; k < 4; ++k) sh[k][threadIdx.x] = a[k];
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    double t = 0.0;
+    for (int i = 0; i < 256; ++i) t += sh[threadIdx.x][i];
+    sh[threadIdx.x][0] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    out[0] = sh[1][0] > 0.0 ? sh[0][0] / sh[1][0] : 0.0;
+    out[1] = sh[1][0]; out[2] = sh[2][0]; out[3] = sh[3][0];
+  }
+}
+
+__global__ void t_wce_scale_kernel(float* __restrict__ d, int64_t n, const double* __restrict__ out, float scale) {
+  const float f = out[1] > 0.0 ? (float)((double)scale / out[1]) : 0.f;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) d[e] *= f;
+}
+
 inline unsigned grid1(int64_t n) { const int64_t g = (n + 255) / 256; return (unsigned)(g < 1 ? 1 : (g > 8192 ? 8192 : g)); }
 inline int done() { return (int)hipGetLastError(); }
 
@@ -599,6 +656,20 @@ int dsir_t_bn_running(void* stream, const float* stats, int C, int64_t M, float 
   if (!stats || !running_mean || !running_var || C < 1 || M < 1) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(t_bn_running_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats, C, (double)M, momentum,
                      running_mean, running_var);
+  return done();
+}
+
+size_t dsir_t_weighted_ce_scratch(int64_t rows) { return (size_t)((rows + 255) / 256) * 4 * sizeof(double); }
+
+int dsir_t_weighted_ce(void* stream, const float* logits, const int32_t* labels, const float* class_weights, int64_t rows, int C,
+                       float grad_scale, float* dlogits, double* out, void* scratch) {
+  if (!logits || !labels || !class_weights || !dlogits || !out || !scratch || rows < 1 || C < 1) return (int)hipErrorInvalidValue;
+  hipStream_t st = (hipStream_t)stream;
+  const int blocks = (int)((rows + 255) / 256);
+  double* partial = reinterpret_cast<double*>(scratch);
+  hipLaunchKernelGGL(t_wce_rows_kernel, dim3(blocks), dim3(256), 0, st, logits, labels, class_weights, rows, C, dlogits, partial);
+  hipLaunchKernelGGL(t_wce_final_kernel, dim3(1), dim3(256), 0, st, partial, blocks, out);
+  hipLaunchKernelGGL(t_wce_scale_kernel, dim3(grid1(rows * C)), dim3(256), 0, st, dlogits, rows * C, out, grad_scale);
   return done();
 }
 

@@ -21,7 +21,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .arch import NetConfig, level_sizes, randla_specs
+from .arch import NetConfig, level_sizes, randla_specs, semantic_class_weights
 
 K_NN = 16
 
@@ -171,6 +171,17 @@ class _Ops:
 
     def axpy(self, a: float, x: torch.Tensor, y: torch.Tensor) -> None:
         self._ok(self.lib.dsir_t_axpy(self.stream, a, _ptr(x), x.numel(), _ptr(y)), "dsir_t_axpy")
+
+    def weighted_ce(self, logits: torch.Tensor, labels: torch.Tensor, class_weights: torch.Tensor, grad_scale: float = 1.0):
+        """SemanticLoss.compute_loss: logits [rows][C], labels [rows] int32 (0 = ignored, class = label - 1)
+        -> (d loss / d logits [rows][C], device float64 [4] = {loss, sum of weights, correct, valid})."""
+        rows, C_ = logits.shape
+        d = self.empty(rows, C_)
+        out = self.empty(4, dtype=torch.float64)
+        sc = self.scratch(self.lib.dsir_t_weighted_ce_scratch(rows))
+        self._ok(self.lib.dsir_t_weighted_ce(self.stream, _ptr(logits), _ptr(labels), _ptr(class_weights), rows, C_, grad_scale, _ptr(d),
+                                             _ptr(out), _ptr(sc)), "dsir_t_weighted_ce")
+        return d, out
 
     def acc(self, dst: Optional[torch.Tensor], src: torch.Tensor) -> torch.Tensor:
         """dst += src (dst None: a private copy of src)."""
@@ -408,11 +419,13 @@ class RandlaTrainer:
                 h = y
         tape.misc["net"] = dict(clouds=clouds, N=N, n=n, skips_shapes=[s.shape for s in skips], args=args, dec=dec, xf=xf, fc=fc,
                                 mask=dropout_mask, L=L)
+        tape.misc["feat"] = feat.reshape(clouds, N, -1)            # RandLA.forward's first output (before the dropout)
         return h.reshape(clouds, N, self.num_classes), tape
 
-    def backward(self, tape: RandlaTape, dlogits: torch.Tensor) -> None:
+    def backward(self, tape: RandlaTape, dlogits: torch.Tensor, dfeat: Optional[torch.Tensor] = None) -> None:
         """Accumulates d loss / d parameter into ``self.grads`` (call ``zero_grad`` between steps, not between the
-        registration iterations of one step: their gradients add up, as autograd's do)."""
+        registration iterations of one step: their gradients add up, as autograd's do).  dlogits [clouds][N][num_classes];
+        dfeat [clouds][N][out_feat_dim] (optional): gradient w.r.t. the feature output ``tape.misc['feat']``."""
         o = self.ops
         o.begin()
         pf = self.prefix
@@ -429,6 +442,8 @@ class RandlaTrainer:
             d = o.conv_dx(d, w)
         if net["mask"] is not None:
             d = o.mul_mask(d, net["mask"].reshape(-1).contiguous(), 2.0)
+        if dfeat is not None:
+            o.axpy(1.0, dfeat.reshape(d.shape).contiguous().float(), d)
         o.conv_dw(d, net["xf"], self.grads[pf + ".mlp_out.weight"], None)
         dx = o.conv_dx(d, self.params[pf + ".mlp_out.weight"])                                        # [clouds N][C]
         shapes = net["skips_shapes"]
@@ -496,6 +511,45 @@ def train_step_align(engine, trainer: RandlaTrainer, batch: dict, result: dict, 
     out["logits"] = lg_all
     out["skipped"] = bad
     return out
+
+
+def train_step_label(trainer: RandlaTrainer, batch: dict, labels_src: torch.Tensor, labels_ref: torch.Tensor, lr: float = 1e-3,
+                     dropout_seed: Optional[int] = None, apply: bool = True) -> dict:
+    """One optimisation step of the `label` pipeline (train.py:412-415, :448): the semantic head of the feature extractor.
+    ``forward_pair`` runs ``feat_extractor`` on the src and on the ref clouds SEPARATELY (model.py:629-632: BatchNorm batch
+    statistics per call), ``SemanticLoss.forward`` adds the two weighted cross entropies (loss.py:991-995).
+    ``trainer``: a RandlaTrainer over prefix 'feat_extractor' (feat_in = cfg.feat_len, num_classes 19); ``batch``: points_src /
+    points_ref [P][N][feat_len] and both pyramids ({src,ref}_{xyz,neigh,sub,interp}); labels_* [P][N] int32 in 0..19
+    (0 = unlabeled, ignored)."""
+    o = trainer.ops
+    o.begin()
+    dev = trainer.device
+    cw = torch.tensor(semantic_class_weights(), dtype=torch.float32, device=dev)
+    trainer.zero_grad()
+    gen = torch.Generator(device="cpu")
+    if dropout_seed is not None:
+        gen.manual_seed(int(dropout_seed))
+    res = {}
+    outs = []
+    for side, labels in (("src", labels_src), ("ref", labels_ref)):
+        pts = batch[f"points_{side}"].contiguous()
+        P, N, _ = pts.shape
+        mask = None
+        if dropout_seed is not None:
+            mask = (torch.rand(P, N, trainer.cfg.out_feat_dim, generator=gen) >= 0.5).to(torch.uint8).to(dev)
+        logits, tape = trainer.forward(pts, batch[f"{side}_xyz"], batch[f"{side}_neigh"], batch[f"{side}_sub"], batch[f"{side}_interp"], mask)
+        d, out = o.weighted_ce(logits.reshape(P * N, trainer.num_classes), labels.reshape(-1).contiguous(), cw)
+        trainer.backward(tape, d)
+        outs.append(out)
+        res[f"logits_{side}"] = logits
+    vals = torch.stack(outs).cpu().numpy()                      # one host read for both sides
+    res["loss"] = float(vals[0, 0] + vals[1, 0])
+    res["acc"] = float(vals[0, 2] / max(vals[0, 3], 1.0) + vals[1, 2] / max(vals[1, 3], 1.0))    # acc_src + acc_ref (loss.py:994)
+    bad = bool(torch.isnan(trainer.flat_g).any())
+    if apply and not bad:
+        trainer.adam_step(lr)
+    res["skipped"] = bad
+    return res
 
 
 class AlignTrainStep:

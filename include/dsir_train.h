@@ -79,6 +79,16 @@ int dsir_t_maxpool_fwd(void* stream, const float* X, int n, int C, const int32_t
                        int32_t* arg);
 int dsir_t_maxpool_bwd(void* stream, const float* dOut, const int32_t* arg, int m, int C, int clouds, float* dX, int n);
 
+/* SemanticLoss.compute_loss (network/loss.py:930-960, :919-928): F.cross_entropy(weight = class weights, reduction 'mean')
+ * over the points whose label is not 0 ("unlabeled"), class = label - 1; logits [rows][C] point-major, labels [rows] in 0..C.
+ * out (device, 4 doubles) = {loss = sum w_y nll / sum w_y, sum w_y, correct arg-max predictions, valid rows};
+ * dlogits [rows][C] = grad_scale * d loss / d logits (ignored rows 0).  scratch: dsir_t_weighted_ce_scratch(rows) bytes.
+ * The reference passes the weights as a [1, C] tensor, which F.cross_entropy of the torch in this image rejects; the rule
+ * here is the documented one for a [C] weight vector (oracle/train.py restates it; parity unpinned). */
+size_t dsir_t_weighted_ce_scratch(int64_t rows);
+int dsir_t_weighted_ce(void* stream, const float* logits, const int32_t* labels, const float* class_weights, int64_t rows, int C,
+                       float grad_scale, float* dlogits, double* out, void* scratch);
+
 /* F.leaky_relu(a + b, 0.2) (RandLANet.py:230) and its backward (d a = d b = dOut * slope(out)). */
 int dsir_t_add_leaky_fwd(void* stream, const float* a, const float* b, int64_t n, float* out);
 int dsir_t_add_leaky_bwd(void* stream, const float* dOut, const float* out, int64_t n, float* d);

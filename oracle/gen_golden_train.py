@@ -109,6 +109,10 @@ def main(ref_root="/root/reference"):
                 v = sd[k].reshape(-1)
                 out["adam_inlier_model." + k] = v if v.size <= FULL_MAX else v[sample_index(k, v.size, seed)]
             out["adam_logits_after"] = lg.detach().numpy()
+    # the constants of the `label` pipeline's loss (SemanticLoss.get_class_weights, loss.py:896-912); the loss itself cannot be
+    # run under this image's torch (a [1, C] weight tensor is rejected by F.cross_entropy) - see oracle/train.py
+    from network.loss import SemanticLoss  # type: ignore
+    out["semantic_class_weights"] = np.asarray(SemanticLoss.get_class_weights("SemanticKITTI"), np.float64).reshape(-1)
     out["n_cases"] = np.asarray(len(cases))
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "train_cases.npz"), **out)
     print("written", os.path.getsize(os.path.join(ROOT, "tests", "golden", "train_cases.npz")), "bytes")

@@ -78,3 +78,17 @@ def randla_train(net: OracleNet, prefix: str, features: torch.Tensor, xyz_multi:
 def adam_reference(params: Dict[str, torch.Tensor], lr: float = 1e-3) -> torch.optim.Adam:
     """The reference's optimiser (train.py:323)."""
     return torch.optim.Adam(list(params.values()), lr=lr)
+
+
+def semantic_loss(logits: torch.Tensor, labels: torch.Tensor, class_weights) -> torch.Tensor:
+    """SemanticLoss.compute_loss (loss.py:930-960): points labelled 0 are dropped, class = label - 1 (the `reducing_list`
+    gather), weighted cross entropy with reduction 'mean' (:919-928).  logits [B, C, N], labels [B, N] int64.
+    PARITY UNPINNED: the reference hands F.cross_entropy a [1, C] weight tensor, which the torch of this image rejects
+    ("weight tensor should be defined either for all 19 classes or no classes"), so its own loss cannot be run here; this is
+    the same call with the weights as the [C] vector the API documents."""
+    C = logits.shape[1]
+    lg = logits.transpose(1, 2).reshape(-1, C)
+    lb = labels.reshape(-1)
+    keep = lb != 0
+    w = torch.as_tensor(class_weights, dtype=torch.float32).reshape(-1)
+    return F.cross_entropy(lg[keep], lb[keep] - 1, weight=w, reduction="mean")

@@ -98,6 +98,17 @@ def test_oracle_adam_steps_match_reference():
         assert np.abs(v - ref).max() <= 2e-4 * np.abs(ref).max() + 1e-6, name
 
 
+def test_semantic_class_weights_are_the_references():
+    from deepsir_amd.arch import semantic_class_weights
+    assert np.allclose(semantic_class_weights(), GOLD["semantic_class_weights"], rtol=1e-12)
+    lg = torch.randn(2, 19, 50, generator=torch.Generator().manual_seed(0))
+    lb = torch.zeros(2, 50, dtype=torch.long)
+    lb[0, :7] = torch.arange(1, 8)
+    w = torch.tensor(semantic_class_weights())
+    want = sum(-w[c] * torch.log_softmax(lg[0, :, c], 0)[c] for c in range(7)) / w[:7].sum()     # class = label - 1, label 0 ignored
+    assert abs(float(otrain.semantic_loss(lg, lb, semantic_class_weights())) - float(want)) < 1e-5
+
+
 # ------------------------------------------------------------------------------------------------- GPU
 def _dev():
     return torch.device("cuda:0")
@@ -393,3 +404,60 @@ def test_graph_replayed_step_equals_the_eager_step():
     torch.cuda.synchronize()
     d = (a.flat_p - b.flat_p).abs()
     assert float(d.max()) <= 2 * 4 * 1e-3 * 1.05 and float(d.median()) < 1e-4     # see test_device_adam_steps_match_reference
+
+
+@pytest.mark.gpu
+def test_label_pipeline_training_step_matches_the_oracle():
+    """`label` pipeline (semantic head of the feature extractor): weighted cross entropy over the labelled points (op vs
+    F.cross_entropy), then the whole step - two training-mode forwards (src, ref: separate BatchNorm statistics),
+    loss_src + loss_ref, backward - against the same composition under torch autograd on the oracle; then Adam lowers it."""
+    import torch.nn.functional as F
+    from deepsir_amd.arch import semantic_class_weights
+    from deepsir_amd.engine import Engine
+    from deepsir_amd.synth import make_pair
+    from deepsir_amd.train import RandlaTrainer, _Ops, train_step_label
+    o = _Ops(_dev())
+    g = torch.Generator().manual_seed(3)
+    cw = torch.tensor(semantic_class_weights())
+    lg = torch.randn(3000, 19, generator=g).requires_grad_()
+    lb = torch.randint(0, 20, (3000,), generator=g)
+    keep = lb != 0
+    ref = F.cross_entropy(lg[keep], lb[keep] - 1, weight=cw)
+    ref.backward()
+    d, out = o.weighted_ce(lg.detach().to(_dev()), lb.int().to(_dev()), cw.to(_dev()))
+    out = out.cpu().numpy()
+    assert abs(out[0] - float(ref)) < 1e-5 and out[3] == int(keep.sum())
+    assert out[2] == int((lg.detach()[keep].argmax(1) == lb[keep] - 1).sum())
+    assert torch.allclose(d.cpu(), lg.grad, rtol=1e-4, atol=1e-8)
+    # ---- the step
+    n, P = 1024, 2
+    sd = generate_state_dict(CFG, 7, "plain")
+    eng = Engine(CFG, max_points=n, max_pairs=P)
+    eng.load_state_dict(sd)
+    raws = [make_pair(n, 400 + b, 3) for b in range(P)]
+    pts = {s: torch.from_numpy(np.concatenate([r[f"points_{s}"] for r in raws])).to(_dev()) for s in ("src", "ref")}
+    batch = {"points_src": pts["src"], "points_ref": pts["ref"]}
+    for s in ("src", "ref"):
+        batch[f"{s}_xyz"], batch[f"{s}_neigh"], batch[f"{s}_sub"], batch[f"{s}_interp"] = eng.knn_pyramid(pts[s])
+    labels = {s: torch.randint(0, 20, (P, n), generator=g) for s in ("src", "ref")}
+    tr = RandlaTrainer(CFG, sd, "feat_extractor", CFG.feat_len, CFG.num_classes, _dev())
+    res = train_step_label(tr, batch, labels["src"].int().to(_dev()), labels["ref"].int().to(_dev()), apply=False)
+    torch.cuda.synchronize()
+    net = OracleNet(CFG, sd)
+    params = otrain.trainable(net, "feat_extractor")
+    total = 0.0
+    for s in ("src", "ref"):
+        pyr = [batch[f"{s}_xyz"].cpu(), batch[f"{s}_neigh"].cpu().long(), batch[f"{s}_sub"].cpu().long(), batch[f"{s}_interp"].cpu().long()]
+        lgt = otrain.randla_train(net, "feat_extractor", pts[s].cpu(), *pyr, None)
+        assert np.abs(res[f"logits_{s}"].cpu().numpy() - lgt.detach().permute(0, 2, 1).numpy()).max() < 1e-3
+        total = total + otrain.semantic_loss(lgt, labels[s], semantic_class_weights())
+    total.backward()
+    assert abs(res["loss"] - float(total)) < 1e-4 * float(total)
+    for k, p in params.items():
+        if k.endswith(ZERO_BY_CONSTRUCTION):
+            continue
+        gd, r = tr.grads[k].cpu().numpy().reshape(-1), p.grad.numpy().reshape(-1)
+        assert np.abs(gd - r).max() <= 5e-3 * np.abs(r).max() + 1e-7, k
+    losses = [train_step_label(tr, batch, labels["src"].int().to(_dev()), labels["ref"].int().to(_dev()), lr=2e-3, dropout_seed=i)["loss"]
+              for i in range(6)]
+    assert losses[-1] < losses[0], losses
