@@ -442,6 +442,239 @@ __global__ void t_bn_running_kernel(const float* __restrict__ stats, int C, doub
   rvar[c] = (float)((1.0 - momentum) * rvar[c] + momentum * var);
 }
 
+// ---- L2 normalisation over channels (F.normalize, p = 2, eps 1e-12) -------------------------------------------------
+__global__ void t_l2norm_fwd_kernel(const float* __restrict__ x, int64_t rows, int C, float* __restrict__ y, float* __restrict__ nrm) {
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (int64_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += x[r * C + c] * x[r * C + c];
+    const float n = fmaxf(sqrtf(s), 1e-12f);
+    nrm[r] = n;
+    for (int c = 0; c < C; ++c) y[r * C + c] = x[r * C + c] / n;
+  }
+}
+__global__ void t_l2norm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ nrm, int64_t rows,
+                                    int C, float* __restrict__ dx) {
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (int64_t)gridDim.x * blockDim.x) {
+    float dot = 0.f;
+    for (int c = 0; c < C; ++c) dot += y[r * C + c] * dy[r * C + c];
+    const float inv = 1.f / nrm[r];
+    for (int c = 0; c < C; ++c) dx[r * C + c] = (dy[r * C + c] - y[r * C + c] * dot) * inv;
+  }
+}
+
+// ---- DetDesLoss = CircleLoss + detection term (reference network/loss.py:500-571, :667-702) -----------------------------
+// Restated INCLUDING what its arithmetic does (oracle/train.py::det_des_loss): dist_min = min_j(dist_pc * false_negative),
+// pos_mask = (dist_pc == dist_min), masked entries enter the log-sum-exps with exponent 0.
+constexpr float kCEps = 1e5f, kCScale = 10.f, kCPosM = 0.1f, kCNegM = 1.4f;
+struct CircleRow { float dist_min, lse_pos, lse_neg, far, close; int arg_far, arg_close, far_masked; };
+
+// dist_pc, dist_feat from the dot products (dot[i][j] = anc_i . pos_j) and the squared norms
+__global__ void t_circle_dist_kernel(const float* __restrict__ dot, const float* __restrict__ anc, const float* __restrict__ pos,
+                                     const float* __restrict__ anc_pc, const float* __restrict__ src_pc, const float* __restrict__ T, int M,
+                                     int C, float* __restrict__ dist_pc, float* __restrict__ dist_feat, int64_t total) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int j = (int)(e % M);
+    const int64_t pi = e / M;                 // pair * M + i
+    const int64_t pair = pi / M;
+    const int64_t pj = pair * M + j;
+    const float* t = T + pair * 12;
+    const float* q = src_pc + pj * 3;
+    const float px = t[0] * q[0] + t[1] * q[1] + t[2] * q[2] + t[3], py = t[4] * q[0] + t[5] * q[1] + t[6] * q[2] + t[7],
+                pz = t[8] * q[0] + t[9] * q[1] + t[10] * q[2] + t[11];
+    const float* a = anc_pc + pi * 3;
+    const float dx = a[0] - px, dy = a[1] - py, dz = a[2] - pz;
+    dist_pc[e] = sqrtf(dx * dx + dy * dy + dz * dz);
+    float sa = 0.f, sb = 0.f;
+    for (int c = 0; c < C; ++c) { sa += anc[pi * C + c] * anc[pi * C + c]; sb += pos[pj * C + c] * pos[pj * C + c]; }
+    dist_feat[e] = sqrtf(((-2.f * dot[e]) + sa) + sb + 1e-16f);
+  }
+}
+
+__device__ __forceinline__ void circle_terms(float dpc, float dft, float dist_min, float thres, float& posw, float& negw, float& pw,
+                                             float& nw, bool& pmask) {
+  const bool fn = dpc < thres;
+  pmask = dpc == dist_min;
+  const bool negm = !(pmask || fn);
+  const float p = dft - (negm ? kCEps : 0.f);
+  pw = fmaxf(p - kCPosM, 0.f);
+  posw = kCScale * (p - kCPosM) * pw;
+  const float n = dft + (negm ? 0.f : kCEps);
+  nw = fmaxf(kCNegM - n, 0.f);
+  negw = kCScale * (kCNegM - n) * nw;
+}
+
+template <typename F>
+__device__ __forceinline__ float block_reduce(float v, float* sh, F op) {
+  sh[threadIdx.x] = v;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] = op(sh[threadIdx.x], sh[threadIdx.x + o]);
+    __syncthreads();
+  }
+  const float r = sh[0];
+  __syncthreads();
+  return r;
+}
+
+// one block per (row i, pair): dist_min, the two row log-sum-exps, furthest positive / closest negative with their columns
+__global__ __launch_bounds__(256) void t_circle_rows_kernel(const float* __restrict__ dist_pc, const float* __restrict__ dist_feat, int M,
+                                                            float thres, CircleRow* __restrict__ rows) {
+  __shared__ float sh[256];
+  __shared__ int shi[256];
+  const int64_t pi = (int64_t)blockIdx.y * M + blockIdx.x;
+  const float* dp = dist_pc + pi * M;
+  const float* df = dist_feat + pi * M;
+  float v = INFINITY;
+  for (int j = threadIdx.x; j < M; j += 256) v = fminf(v, dp[j] < thres ? dp[j] : 0.f);
+  const float dist_min = block_reduce(v, sh, [](float a, float b) { return fminf(a, b); });
+  float mp = -INFINITY, mn = -INFINITY, far = -INFINITY, close = INFINITY;
+  int afar = 0x7fffffff, aclose = 0x7fffffff;
+  for (int j = threadIdx.x; j < M; j += 256) {
+    float posw, negw, pw, nw; bool pm;
+    circle_terms(dp[j], df[j], dist_min, thres, posw, negw, pw, nw, pm);
+    mp = fmaxf(mp, posw); mn = fmaxf(mn, negw);
+    const float f = pm ? df[j] : 0.f, c = df[j] + (pm ? kCEps : 0.f);
+    if (f > far) { far = f; afar = j; }
+    if (c < close) { close = c; aclose = j; }
+  }
+  const float gmp = block_reduce(mp, sh, [](float a, float b) { return fmaxf(a, b); });
+  const float gmn = block_reduce(mn, sh, [](float a, float b) { return fmaxf(a, b); });
+  float sp = 0.f, sn = 0.f;
+  for (int j = threadIdx.x; j < M; j += 256) {
+    float posw, negw, pw, nw; bool pm;
+    circle_terms(dp[j], df[j], dist_min, thres, posw, negw, pw, nw, pm);
+    sp += expf(posw - gmp); sn += expf(negw - gmn);
+  }
+  sp = block_reduce(sp, sh, [](float a, float b) { return a + b; });
+  sn = block_reduce(sn, sh, [](float a, float b) { return a + b; });
+  // arg max / arg min: the first column attaining the extreme (torch.max / torch.min return the first on the CPU)
+  const float gfar = block_reduce(far, sh, [](float a, float b) { return fmaxf(a, b); });
+  const float gclose = block_reduce(close, sh, [](float a, float b) { return fminf(a, b); });
+  shi[threadIdx.x] = far == gfar ? afar : 0x7fffffff;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) shi[threadIdx.x] = min(shi[threadIdx.x], shi[threadIdx.x + o]); __syncthreads(); }
+  const int jfar = shi[0];
+  __syncthreads();
+  shi[threadIdx.x] = close == gclose ? aclose : 0x7fffffff;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) shi[threadIdx.x] = min(shi[threadIdx.x], shi[threadIdx.x + o]); __syncthreads(); }
+  const int jclose = shi[0];
+  if (threadIdx.x == 0) {
+    CircleRow r;
+    r.dist_min = dist_min; r.lse_pos = gmp + logf(sp); r.lse_neg = gmn + logf(sn); r.far = gfar; r.close = gclose;
+    r.arg_far = jfar; r.arg_close = jclose; r.far_masked = (jfar < M && dp[jfar] == dist_min) ? 1 : 0;
+    rows[pi] = r;
+  }
+}
+
+// one block per (column j, pair): the column log-sum-exp of the negative terms
+__global__ __launch_bounds__(256) void t_circle_cols_kernel(const float* __restrict__ dist_pc, const float* __restrict__ dist_feat, int M,
+                                                            float thres, const CircleRow* __restrict__ rows, float* __restrict__ lse_col) {
+  __shared__ float sh[256];
+  const int64_t pair = blockIdx.y;
+  const int j = blockIdx.x;
+  float mn = -INFINITY;
+  for (int i = threadIdx.x; i < M; i += 256) {
+    const int64_t e = (pair * M + i) * M + j;
+    float posw, negw, pw, nw; bool pm;
+    circle_terms(dist_pc[e], dist_feat[e], rows[pair * M + i].dist_min, thres, posw, negw, pw, nw, pm);
+    mn = fmaxf(mn, negw);
+  }
+  const float gmn = block_reduce(mn, sh, [](float a, float b) { return fmaxf(a, b); });
+  float sn = 0.f;
+  for (int i = threadIdx.x; i < M; i += 256) {
+    const int64_t e = (pair * M + i) * M + j;
+    float posw, negw, pw, nw; bool pm;
+    circle_terms(dist_pc[e], dist_feat[e], rows[pair * M + i].dist_min, thres, posw, negw, pw, nw, pm);
+    sn += expf(negw - gmn);
+  }
+  sn = block_reduce(sn, sh, [](float a, float b) { return a + b; });
+  if (threadIdx.x == 0) lse_col[pair * M + j] = gmn + logf(sn);
+}
+
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }   // F.softplus (threshold 20)
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
+
+// one block: the loss values and the per-row / per-column coefficients of the backward pass
+// coef[pi] = {A = sigmoid(lse_pos + lse_neg_row) / (10 P M), B = sigmoid(lse_pos + lse_neg_col) / (10 P M), c = det_w score / sum / (P M)}
+__global__ __launch_bounds__(256) void t_circle_final_kernel(const CircleRow* __restrict__ rows, const float* __restrict__ lse_col,
+                                                             const float* __restrict__ score, int P, int M, float det_w,
+                                                             float* __restrict__ coef, double* __restrict__ out) {
+  __shared__ double sh[3][256];
+  __shared__ float ssum;
+  double lf = 0.0, ld = 0.0, acc = 0.0;
+  const float inv = 1.f / ((float)P * (float)M);
+  for (int p = 0; p < P; ++p) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < M; i += 256) s += score[(int64_t)p * M + i];
+    sh[0][threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { double t = 0.0; for (int k = 0; k < 256; ++k) t += sh[0][k]; ssum = (float)t; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < M; i += 256) {
+      const int64_t pi = (int64_t)p * M + i;
+      const CircleRow r = rows[pi];
+      const float xr = r.lse_pos + r.lse_neg, xc = r.lse_pos + lse_col[pi];
+      lf += (double)(softplus_f(xr) / kCScale + softplus_f(xc) / kCScale);
+      const float diff = r.far - r.close, sc = score[pi] / ssum;
+      ld += (double)(diff * sc);
+      acc += diff < 0.f ? 1.0 : 0.0;
+      coef[pi * 3] = sigmoid_f(xr) / kCScale * inv;
+      coef[pi * 3 + 1] = sigmoid_f(xc) / kCScale * inv;
+      coef[pi * 3 + 2] = det_w * sc * inv;
+    }
+    __syncthreads();
+  }
+  sh[0][threadIdx.x] = lf; sh[1][threadIdx.x] = ld; sh[2][threadIdx.x] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0.0, b = 0.0, c = 0.0;
+    for (int k = 0; k < 256; ++k) { a += sh[0][k]; b += sh[1][k]; c += sh[2][k]; }
+    out[1] = a * inv; out[2] = b * inv; out[0] = out[1] + out[2] * det_w; out[3] = c * 100.0 / (double)M;
+  }
+}
+
+// one block per (row i, pair): Wn[i][j] = -2 d loss / d sq[i][j] (and its transpose), rowsum[i] = sum_j 2 d loss / d sq[i][j]
+__global__ __launch_bounds__(256) void t_circle_grad_kernel(const float* __restrict__ dist_pc, const float* __restrict__ dist_feat, int M,
+                                                            float thres, const CircleRow* __restrict__ rows, const float* __restrict__ lse_col,
+                                                            const float* __restrict__ coef, float* __restrict__ Wn, float* __restrict__ Wnt,
+                                                            float* __restrict__ rowsum) {
+  __shared__ float sh[256];
+  const int64_t pair = blockIdx.y, pi = pair * M + blockIdx.x;
+  const CircleRow r = rows[pi];
+  const float A = coef[pi * 3], B = coef[pi * 3 + 1], cd = coef[pi * 3 + 2];
+  float rs = 0.f;
+  for (int j = threadIdx.x; j < M; j += 256) {
+    const int64_t e = pi * M + j;
+    float posw, negw, pw, nw; bool pm;
+    circle_terms(dist_pc[e], dist_feat[e], r.dist_min, thres, posw, negw, pw, nw, pm);
+    const float Bj = coef[(pair * M + j) * 3 + 1];
+    float g = (A + B) * expf(posw - r.lse_pos) * kCScale * pw - A * expf(negw - r.lse_neg) * kCScale * nw -
+              Bj * expf(negw - lse_col[pair * M + j]) * kCScale * nw;
+    if (j == r.arg_far && r.far_masked) g += cd;
+    if (j == r.arg_close) g -= cd;
+    const float w2 = g / dist_feat[e];                    // 2 d loss / d sq (d sqrt(u) = du / (2 sqrt(u)))
+    Wn[e] = -w2;
+    Wnt[(pair * M + j) * M + blockIdx.x] = -w2;
+    rs += w2;
+  }
+  rs = block_reduce(rs, sh, [](float a, float b) { return a + b; });
+  if (threadIdx.x == 0) rowsum[pi] = rs;
+}
+
+__global__ __launch_bounds__(256) void t_rowsum_neg_kernel(const float* __restrict__ Wnt, int M, float* __restrict__ colsum) {
+  __shared__ float sh[256];
+  const int64_t pj = (int64_t)blockIdx.y * M + blockIdx.x;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < M; i += 256) s -= Wnt[pj * M + i];
+  s = block_reduce(s, sh, [](float a, float b) { return a + b; });
+  if (threadIdx.x == 0) colsum[pj] = s;
+}
+
+__global__ void t_scale_rows_kernel(const float* __restrict__ s, const float* __restrict__ x, int C, float* __restrict__ y, int64_t total) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) y[e] = s[e / C] * x[e];
+}
+
 // weighted cross entropy, stage 1: one thread per row; labels 0 = ignored, class = label - 1 (SemanticLoss.compute_loss);
 // dlogits = w_y (softmax - onehot) (scaled by 1 / sum w in stage 2); per-block partial {sum w nll, sum w, correct, valid}
 __global__ __launch_bounds__(256) void t_wce_rows_kernel(const float* __restrict__ logits, const int32_t* __restrict__ labels,
@@ -656,6 +889,58 @@ int dsir_t_bn_running(void* stream, const float* stats, int C, int64_t M, float 
   if (!stats || !running_mean || !running_var || C < 1 || M < 1) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(t_bn_running_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats, C, (double)M, momentum,
                      running_mean, running_var);
+  return done();
+}
+
+int dsir_t_l2norm_fwd(void* stream, const float* x, int64_t rows, int C, float* y, float* norms) {
+  if (!x || !y || !norms || rows < 1 || C < 1) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(t_l2norm_fwd_kernel, dim3(grid1(rows)), dim3(256), 0, (hipStream_t)stream, x, rows, C, y, norms);
+  return done();
+}
+
+int dsir_t_l2norm_bwd(void* stream, const float* dy, const float* y, const float* norms, int64_t rows, int C, float* dx) {
+  if (!dy || !y || !norms || !dx || rows < 1 || C < 1) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(t_l2norm_bwd_kernel, dim3(grid1(rows)), dim3(256), 0, (hipStream_t)stream, dy, y, norms, rows, C, dx);
+  return done();
+}
+
+size_t dsir_t_det_des_loss_scratch(int pairs, int M) {
+  const size_t mm = (size_t)pairs * M * M, pm = (size_t)pairs * M;
+  return (5 * mm + pm * 8 + pm * 8) * sizeof(float) + pm * sizeof(CircleRow) + 256;
+}
+
+int dsir_t_det_des_loss(void* stream, const float* feat_ref, const float* feat_src, const float* pt_ref, const float* pt_src,
+                        const float* score_ref, const float* transform_gt, int pairs, int M, int C, float thres_radius, float det_loss_weight,
+                        double* out, float* d_feat_ref, float* d_feat_src, void* scratch) {
+  if (!feat_ref || !feat_src || !pt_ref || !pt_src || !score_ref || !transform_gt || !out || !d_feat_ref || !d_feat_src || !scratch ||
+      pairs < 1 || M < 1 || C < 1 || !(thres_radius > 0.f))
+    return (int)hipErrorInvalidValue;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t mm = (size_t)pairs * M * M, pm = (size_t)pairs * M;
+  float* dot = reinterpret_cast<float*>(scratch);
+  float* dist_pc = dot + mm; float* dist_feat = dist_pc + mm; float* Wn = dist_feat + mm; float* Wnt = Wn + mm;
+  float* lse_col = Wnt + mm; float* coef = lse_col + pm; float* rowsum = coef + 3 * pm; float* colsum = rowsum + pm;
+  CircleRow* rows = reinterpret_cast<CircleRow*>(colsum + pm + (((uintptr_t)(colsum + pm) & 7) ? 1 : 0));
+  for (int p = 0; p < pairs; ++p)       // dot[i][j] = anc_i . pos_j: the GEMM of square_distance_V2 (matchnet.py:110)
+    hipLaunchKernelGGL(t_gemm_kernel, dim3((M + TB - 1) / TB, (M + TB - 1) / TB), dim3(256), 0, st, feat_ref + (size_t)p * M * C, C,
+                       feat_src + (size_t)p * M * C, C, 1, (const float*)nullptr, dot + (size_t)p * M * M, M, (int64_t)M, C, M, 0.f);
+  hipLaunchKernelGGL(t_circle_dist_kernel, dim3(grid1((int64_t)mm)), dim3(256), 0, st, dot, feat_ref, feat_src, pt_ref, pt_src, transform_gt, M,
+                     C, dist_pc, dist_feat, (int64_t)mm);
+  hipLaunchKernelGGL(t_circle_rows_kernel, dim3(M, pairs), dim3(256), 0, st, dist_pc, dist_feat, M, thres_radius, rows);
+  hipLaunchKernelGGL(t_circle_cols_kernel, dim3(M, pairs), dim3(256), 0, st, dist_pc, dist_feat, M, thres_radius, rows, lse_col);
+  hipLaunchKernelGGL(t_circle_final_kernel, dim3(1), dim3(256), 0, st, rows, lse_col, score_ref, pairs, M, det_loss_weight, coef, out);
+  hipLaunchKernelGGL(t_circle_grad_kernel, dim3(M, pairs), dim3(256), 0, st, dist_pc, dist_feat, M, thres_radius, rows, lse_col, coef, Wn, Wnt,
+                     rowsum);
+  hipLaunchKernelGGL(t_rowsum_neg_kernel, dim3(M, pairs), dim3(256), 0, st, Wnt, M, colsum);
+  // d anc_i = rowsum_i anc_i + sum_j Wn_ij pos_j;  d pos_j = colsum_j pos_j + sum_i Wn_ij anc_i
+  hipLaunchKernelGGL(t_scale_rows_kernel, dim3(grid1((int64_t)pm * C)), dim3(256), 0, st, rowsum, feat_ref, C, d_feat_ref, (int64_t)pm * C);
+  hipLaunchKernelGGL(t_scale_rows_kernel, dim3(grid1((int64_t)pm * C)), dim3(256), 0, st, colsum, feat_src, C, d_feat_src, (int64_t)pm * C);
+  for (int p = 0; p < pairs; ++p) {
+    hipLaunchKernelGGL(t_gemm_kernel, dim3((M + TB - 1) / TB, (C + TB - 1) / TB), dim3(256), 0, st, Wn + (size_t)p * M * M, M,
+                       feat_src + (size_t)p * M * C, 1, C, (const float*)nullptr, d_feat_ref + (size_t)p * M * C, C, (int64_t)M, M, C, 1.f);
+    hipLaunchKernelGGL(t_gemm_kernel, dim3((M + TB - 1) / TB, (C + TB - 1) / TB), dim3(256), 0, st, Wnt + (size_t)p * M * M, M,
+                       feat_ref + (size_t)p * M * C, 1, C, (const float*)nullptr, d_feat_src + (size_t)p * M * C, C, (int64_t)M, M, C, 1.f);
+  }
   return done();
 }
 

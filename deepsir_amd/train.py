@@ -21,7 +21,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .arch import NetConfig, level_sizes, randla_specs, semantic_class_weights
+from .arch import NetConfig, level_sizes, network_specs, randla_specs, semantic_class_weights
 
 K_NN = 16
 
@@ -183,6 +183,28 @@ class _Ops:
                                              _ptr(out), _ptr(sc)), "dsir_t_weighted_ce")
         return d, out
 
+    def l2norm_fwd(self, x: torch.Tensor):
+        y, nrm = torch.empty_like(x), self.empty(x.shape[0])
+        self._ok(self.lib.dsir_t_l2norm_fwd(self.stream, _ptr(x), x.shape[0], x.shape[1], _ptr(y), _ptr(nrm)), "dsir_t_l2norm_fwd")
+        return y, nrm
+
+    def l2norm_bwd(self, dy: torch.Tensor, y: torch.Tensor, nrm: torch.Tensor) -> torch.Tensor:
+        dx = torch.empty_like(y)
+        self._ok(self.lib.dsir_t_l2norm_bwd(self.stream, _ptr(dy), _ptr(y), _ptr(nrm), y.shape[0], y.shape[1], _ptr(dx)), "dsir_t_l2norm_bwd")
+        return dx
+
+    def det_des_loss(self, feat_ref, feat_src, pt_ref, pt_src, score_ref, transform_gt, thres_radius: float, det_loss_weight: float = 1.0):
+        """DetDesLoss + its backward: feat_* [P][M][C], pt_* [P][M][3], score_ref [P][M], transform_gt [P][3][4]
+        -> (device float64 [4] = {total, loss_feat, loss_det, accuracy}, d_feat_ref, d_feat_src)."""
+        P, M, C_ = feat_ref.shape
+        out = self.empty(4, dtype=torch.float64)
+        d_ref, d_src = torch.empty_like(feat_ref), torch.empty_like(feat_src)
+        sc = self.scratch(self.lib.dsir_t_det_des_loss_scratch(P, M))
+        self._ok(self.lib.dsir_t_det_des_loss(self.stream, _ptr(feat_ref), _ptr(feat_src), _ptr(pt_ref), _ptr(pt_src), _ptr(score_ref),
+                                              _ptr(transform_gt), P, M, C_, float(thres_radius), float(det_loss_weight), _ptr(out), _ptr(d_ref),
+                                              _ptr(d_src), _ptr(sc)), "dsir_t_det_des_loss")
+        return out, d_ref, d_src
+
     def acc(self, dst: Optional[torch.Tensor], src: torch.Tensor) -> torch.Tensor:
         """dst += src (dst None: a private copy of src)."""
         src = src.contiguous()
@@ -200,36 +222,17 @@ class _Ops:
         return out
 
 
-class _Layer:
-    """What the backward of one conv (+ norm) needs."""
-    __slots__ = ("name", "x", "y", "stats", "clouds", "groups", "act", "norm")
+class _ParamStore:
+    """Parameters, gradients and Adam moments of a set of layers: ONE flat device buffer each (every tensor a 256-byte
+    aligned view), so that zero_grad is one fill and the optimiser step ONE launch; BatchNorm running statistics apart."""
 
-
-class RandlaTape:
-    def __init__(self):
-        self.layers: Dict[str, _Layer] = {}
-        self.blocks: List[dict] = []
-        self.misc: dict = {}
-
-
-class RandlaTrainer:
-    """One ``RandLA`` (network/RandLANet.py:233-372) with its parameters, gradients and Adam state on the device.
-
-    ``state_dict``: the reference's keys under ``prefix`` (others are ignored).  ``feat_in`` / ``num_classes``: 6 / 1 for the
-    inlier model (network/model.py:181-191)."""
-
-    def __init__(self, cfg: NetConfig, state_dict: Dict[str, "np.ndarray | torch.Tensor"], prefix: str = "inlier_model", feat_in: int = 6,
-                 num_classes: int = 1, device: "str | torch.device" = "cuda:0"):
-        self.cfg, self.prefix, self.feat_in, self.num_classes = cfg, prefix, feat_in, num_classes
-        self.device = torch.device(device)
-        self.ops = _Ops(self.device)
-        # ONE flat device buffer each for parameters, gradients and the two Adam moments (every tensor a 256-byte aligned
-        # view): zero_grad is one fill, the optimiser step ONE launch over all parameters
+    def _build_store(self, specs, state_dict) -> None:
         host: Dict[str, torch.Tensor] = {}
         self.buffers: Dict[str, torch.Tensor] = {}
+        self._shapes = {sp.name: sp.shape for sp in specs}
         offsets: Dict[str, int] = {}
         total = 0
-        for spec in randla_specs(prefix, feat_in, num_classes, cfg):
+        for spec in specs:
             if spec.kind == "bn_count":
                 continue
             if spec.name not in state_dict:
@@ -254,29 +257,87 @@ class RandlaTrainer:
             self.params[k].copy_(t)
         self.step_count = 0
 
-    # ------------------------------------------------------------------ bookkeeping
     def zero_grad(self) -> None:
         self.flat_g.zero_()
 
     def state_dict(self) -> Dict[str, np.ndarray]:
         """Parameters and BatchNorm running statistics in the reference's shapes (host)."""
-        shapes = {s.name: s.shape for s in randla_specs(self.prefix, self.feat_in, self.num_classes, self.cfg)}
-        out = {}
-        for k, v in list(self.params.items()) + list(self.buffers.items()):
-            out[k] = v.detach().cpu().numpy().reshape(shapes[k])
-        return out
+        return {k: v.detach().cpu().numpy().reshape(self._shapes[k]) for k, v in list(self.params.items()) + list(self.buffers.items())}
 
     def grad_dict(self) -> Dict[str, np.ndarray]:
-        shapes = {s.name: s.shape for s in randla_specs(self.prefix, self.feat_in, self.num_classes, self.cfg)}
-        return {k: v.detach().cpu().numpy().reshape(shapes[k]) for k, v in self.grads.items()}
+        return {k: v.detach().cpu().numpy().reshape(self._shapes[k]) for k, v in self.grads.items()}
 
     def adam_step(self, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8) -> None:
-        """torch.optim.Adam.step (train.py:323, :446)."""
+        """torch.optim.Adam.step (train.py:323, :446) over the flat buffer (the alignment padding stays 0)."""
         self.step_count += 1
         o = self.ops
         o.begin()
         o._ok(o.lib.dsir_t_adam(o.stream, _ptr(self.flat_p), _ptr(self.flat_g), _ptr(self.flat_m), _ptr(self.flat_v), self.flat_p.numel(),
-                                lr, betas[0], betas[1], eps, self.step_count), "dsir_t_adam")   # the alignment padding stays 0
+                                lr, betas[0], betas[1], eps, self.step_count), "dsir_t_adam")
+
+    # ---- MLP (RandLANet.py:34-55) in training mode: Conv1d + BatchNorm1d (batch statistics) + LeakyReLU, last layer bare
+    def _mlp1d(self, saved: list, prefix: str, x: torch.Tensor, n_layers: int, update_running: bool = True) -> torch.Tensor:
+        o = self.ops
+        pos = 0
+        for i in range(n_layers):
+            w, bias = self.params[f"{prefix}.{pos}.weight"], self.params[f"{prefix}.{pos}.bias"]
+            y = o.conv(x, w, bias)
+            if i < n_layers - 1:
+                g, be = self.params[f"{prefix}.{pos + 1}.weight"], self.params[f"{prefix}.{pos + 1}.bias"]
+                out, stats = o.gn_fwd(y, 1, w.shape[0], g, be, True)
+                if update_running:
+                    o._ok(o.lib.dsir_t_bn_running(o.stream, _ptr(stats), w.shape[0], y.shape[0], 0.1,
+                                                  _ptr(self.buffers[f"{prefix}.{pos + 1}.running_mean"]),
+                                                  _ptr(self.buffers[f"{prefix}.{pos + 1}.running_var"])), "dsir_t_bn_running")
+                saved.append((prefix, pos, x, y, stats))
+                x = out
+                pos += 3
+            else:
+                saved.append((prefix, pos, x, None, None))
+                x = y
+        return x
+
+    def _mlp1d_bwd(self, saved: list, d: torch.Tensor, need_dx: bool = True) -> Optional[torch.Tensor]:
+        """``saved``: the entries one _mlp1d call appended, walked backwards."""
+        o = self.ops
+        for k, (prefix, pos, xin, y, stats) in enumerate(reversed(saved)):
+            w = self.params[f"{prefix}.{pos}.weight"]
+            if y is not None:
+                g, be = self.params[f"{prefix}.{pos + 1}.weight"], self.params[f"{prefix}.{pos + 1}.bias"]
+                d = o.gn_bwd(d, y, stats, 1, w.shape[0], g, be, True, self.grads[f"{prefix}.{pos + 1}.weight"],
+                             self.grads[f"{prefix}.{pos + 1}.bias"])
+            o.conv_dw(d, xin, self.grads[f"{prefix}.{pos}.weight"], self.grads[f"{prefix}.{pos}.bias"])
+            if k == len(saved) - 1 and not need_dx:
+                return None
+            d = o.conv_dx(d, w)
+        return d
+
+
+class _Layer:
+    """What the backward of one conv (+ norm) needs."""
+    __slots__ = ("name", "x", "y", "stats", "clouds", "groups", "act", "norm")
+
+
+class RandlaTape:
+    def __init__(self):
+        self.layers: Dict[str, _Layer] = {}
+        self.blocks: List[dict] = []
+        self.misc: dict = {}
+
+
+class RandlaTrainer(_ParamStore):
+    """One ``RandLA`` (network/RandLANet.py:233-372) with its parameters, gradients and Adam state on the device.
+
+    ``state_dict``: the reference's keys under ``prefix`` (others are ignored).  ``feat_in`` / ``num_classes``: 6 / 1 for the
+    inlier model (network/model.py:181-191)."""
+
+    def __init__(self, cfg: NetConfig, state_dict: Dict[str, "np.ndarray | torch.Tensor"], prefix: str = "inlier_model", feat_in: int = 6,
+                 num_classes: int = 1, device: "str | torch.device" = "cuda:0"):
+        self.cfg, self.prefix, self.feat_in, self.num_classes = cfg, prefix, feat_in, num_classes
+        self.device = torch.device(device)
+        self.ops = _Ops(self.device)
+        self._specs = randla_specs(prefix, feat_in, num_classes, cfg)
+        self._build_store(self._specs, state_dict)
 
     # ------------------------------------------------------------------ layers
     def _mlp2d(self, tape: RandlaTape, name: str, x: torch.Tensor, clouds: int, act: bool = True) -> torch.Tensor:
@@ -511,6 +572,88 @@ def train_step_align(engine, trainer: RandlaTrainer, batch: dict, result: dict, 
     out["logits"] = lg_all
     out["skipped"] = bad
     return out
+
+
+class AggregationTrainer(_ParamStore):
+    """``mlp_feat`` / ``mlp_att`` / ``mlp_proj`` (network/model.py:160-176) in training mode: the 30 tensors the `feat`
+    pipeline trains - its feature extractor is frozen (model.py:136, :196-198)."""
+
+    def __init__(self, cfg: NetConfig, state_dict, device: "str | torch.device" = "cuda:0"):
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.ops = _Ops(self.device)
+        fcfg = NetConfig(**{**cfg.__dict__, "pipeline": "feat"})
+        self._build_store([sp for sp in network_specs(fcfg) if sp.name.startswith(("mlp_feat.", "mlp_att.", "mlp_proj."))], state_dict)
+
+    def forward(self, xyz: torch.Tensor, feat0: torch.Tensor, score: torch.Tensor, update_running_stats: bool = True):
+        """One side of ``Network.aggregation`` (model.py:209-235) + forward_pair's second F.normalize (:651-652), all clouds of
+        the batch in one call (BatchNorm statistics over batch x points, as the reference's).  xyz [P][M][3], feat0 [P][M][64]
+        (the frozen extractor's selected features), score [P][M] -> descriptors [P][M][64], tape."""
+        o = self.ops
+        o.begin()
+        P, M, C_ = feat0.shape
+        tape = {"f": [], "a": [], "p": [], "shape": (P, M, C_)}
+        a = self._mlp1d(tape["f"], "mlp_feat", feat0.reshape(P * M, C_).contiguous(), 3, update_running_stats)
+        g = o.empty(P * M, 4)
+        g[:, :3] = xyz.reshape(P * M, 3)
+        g[:, 3] = score.reshape(P * M)
+        b = self._mlp1d(tape["a"], "mlp_att", g, 5, update_running_stats)
+        o.axpy(1.0, b, a)                                                  # feat + xyz_g (model.py:226-227)
+        e = self._mlp1d(tape["p"], "mlp_proj", a, 1, update_running_stats)
+        n1, r1 = o.l2norm_fwd(e)
+        n2, r2 = o.l2norm_fwd(n1)
+        tape["norm"] = (n1, r1, n2, r2)
+        return n2.reshape(P, M, C_), tape
+
+    def backward(self, tape: dict, ddesc: torch.Tensor) -> None:
+        o = self.ops
+        o.begin()
+        P, M, C_ = tape["shape"]
+        n1, r1, n2, r2 = tape["norm"]
+        d = o.l2norm_bwd(ddesc.reshape(P * M, C_).contiguous(), n2, r2)
+        d = o.l2norm_bwd(d, n1, r1)
+        d = self._mlp1d_bwd(tape["p"], d)
+        self._mlp1d_bwd(tape["f"], d, need_dx=False)                        # inputs come from the frozen extractor
+        self._mlp1d_bwd(tape["a"], d, need_dx=False)
+
+
+def feat_pipeline_inputs(engine, batch: dict, num_sub: int) -> dict:
+    """What the frozen half of the `feat` pipeline hands the aggregation (model.py:629-648), from the inference engine
+    (an Engine built with pipeline='feat'): top-``num_sub`` key points per cloud with their raw 64-d features and scores."""
+    fp = engine.forward_pair(batch["points_src"], batch["points_ref"], num_sub=num_sub)
+    ops = _Ops(engine.device)
+    out = {}
+    for side in ("src", "ref"):
+        pts = batch[f"points_{side}"]
+        pyr = engine.knn_pyramid(pts)
+        feat, _ = engine.randla_forward("feat_extractor", pts, *pyr, want_logits=False)
+        idx = fp[side]["index"]
+        P, M = idx.shape
+        sel = ops.empty(P * M, feat.shape[2])
+        ops.gather(feat, idx, sel, 0)
+        out[f"xyz_{side}"], out[f"score_{side}"], out[f"feat_{side}"] = fp[side]["xyz"], fp[side]["score"], sel.reshape(P, M, -1)
+    return out
+
+
+def train_step_feat(trainer: AggregationTrainer, inp: dict, transform_gt: torch.Tensor, thres_radius: float, det_loss_weight: float = 1.0,
+                    lr: float = 1e-3, apply: bool = True) -> dict:
+    """One optimisation step of the `feat` pipeline (train.py:407-410, :448): DetDesLoss on the descriptors of the selected key
+    points, backward through the aggregation MLPs in training mode, Adam.  ``inp``: xyz_{src,ref} [P][M][3],
+    feat_{src,ref} [P][M][64], score_{src,ref} [P][M] (``feat_pipeline_inputs``)."""
+    trainer.zero_grad()
+    d_src, tape_s = trainer.forward(inp["xyz_src"], inp["feat_src"], inp["score_src"])      # per module the src pass first, as
+    d_ref, tape_r = trainer.forward(inp["xyz_ref"], inp["feat_ref"], inp["score_ref"])      # in aggregation (model.py:217-224)
+    out, g_ref, g_src = trainer.ops.det_des_loss(d_ref.contiguous(), d_src.contiguous(), inp["xyz_ref"].contiguous(),
+                                                 inp["xyz_src"].contiguous(), inp["score_ref"].contiguous(), transform_gt.contiguous(),
+                                                 thres_radius, det_loss_weight)
+    trainer.backward(tape_s, g_src)
+    trainer.backward(tape_r, g_ref)
+    vals = out.cpu().numpy()
+    bad = bool(torch.isnan(trainer.flat_g).any())
+    if apply and not bad:
+        trainer.adam_step(lr)
+    return {"loss": float(vals[0]), "loss_feat": float(vals[1]), "loss_det": float(vals[2]), "acc": float(vals[3]),
+            "desc_src": d_src, "desc_ref": d_ref, "skipped": bad}
 
 
 def train_step_label(trainer: RandlaTrainer, batch: dict, labels_src: torch.Tensor, labels_ref: torch.Tensor, lr: float = 1e-3,

@@ -89,6 +89,21 @@ size_t dsir_t_weighted_ce_scratch(int64_t rows);
 int dsir_t_weighted_ce(void* stream, const float* logits, const int32_t* labels, const float* class_weights, int64_t rows, int C,
                        float grad_scale, float* dlogits, double* out, void* scratch);
 
+/* F.normalize(x, p = 2, dim = channels) (model.py:232-233, :651-652) and its backward; norms [rows] = max(|x|, 1e-12). */
+int dsir_t_l2norm_fwd(void* stream, const float* x, int64_t rows, int C, float* y, float* norms);
+int dsir_t_l2norm_bwd(void* stream, const float* dy, const float* y, const float* norms, int64_t rows, int C, float* dx);
+
+/* DetDesLoss.forward (network/loss.py:667-702) = CircleLoss.forward(feat_ref, feat_src, pt_ref, T_gt pt_src, score_ref, .)
+ * (:500-571) with chamfer_loss_weight 0 (arguments.py:46), AND its backward w.r.t. both descriptor sets - what the `feat`
+ * pipeline's loss.backward() hands the aggregation MLPs (the feature extractor is frozen there, model.py:136).
+ * feat_* [P][M][C] point-major, pt_* [P][M][3], score_ref [P][M], transform_gt [P][3][4]; N1 = N2 = M as the reference's
+ * element-wise sum of row and column terms requires.  out (device, 4 doubles) = {total, loss_feat, loss_det, accuracy}.
+ * The reference's arithmetic is kept as it executes (see oracle/train.py::det_des_loss, pinned by its autograd). */
+size_t dsir_t_det_des_loss_scratch(int pairs, int M);
+int dsir_t_det_des_loss(void* stream, const float* feat_ref, const float* feat_src, const float* pt_ref, const float* pt_src,
+                        const float* score_ref, const float* transform_gt, int pairs, int M, int C, float thres_radius, float det_loss_weight,
+                        double* out, float* d_feat_ref, float* d_feat_src, void* scratch);
+
 /* F.leaky_relu(a + b, 0.2) (RandLANet.py:230) and its backward (d a = d b = dOut * slope(out)). */
 int dsir_t_add_leaky_fwd(void* stream, const float* a, const float* b, int64_t n, float* out);
 int dsir_t_add_leaky_bwd(void* stream, const float* dOut, const float* out, int64_t n, float* d);

@@ -109,6 +109,52 @@ def main(ref_root="/root/reference"):
                 v = sd[k].reshape(-1)
                 out["adam_inlier_model." + k] = v if v.size <= FULL_MAX else v[sample_index(k, v.size, seed)]
             out["adam_logits_after"] = lg.detach().numpy()
+    # ---- `feat` pipeline: DetDesLoss (loss.py:483-702) through the aggregation MLPs in training mode (model.py:209-235); the
+    # feature extractor is frozen there (model.py:136, :196-198), so the vectors start at what it hands the aggregation
+    fargs = arguments.eval_arguments().parse_args([])
+    fargs.pipeline, fargs.feat_len, fargs.num_sub, fargs.thres_radius = "feat", 3, 256, 0.15
+    fnet = ref_model.Network(fargs)
+    fcfg = NetConfig(feat_len=3, pipeline="feat", num_sub=256)
+    fnet.load_state_dict(to_torch_state_dict(generate_state_dict(fcfg, 21, "separated")), strict=True)
+    fnet.train()
+    raws = [add_pyramids(make_pair(1024, 500 + b, 3), fcfg.num_knn, fcfg.sub_sampling_ratio) for b in range(2)]
+    fd = to_torch({k: np.concatenate([r[k] for r in raws], 0) for k in raws[0]})
+    # the synthetic pairs are exact rigid copies: after T_gt a few points coincide with their match to the last bit or not
+    # depending on the rounding of R p + t, and CircleLoss's pos_mask is an exact float equality.  A 2 mm offset on the ground
+    # truth takes the vectors off that knife edge (the coincidence branch is covered by tests/test_train.py against the oracle)
+    fd["transform_gt"] = fd["transform_gt"].clone()
+    fd["transform_gt"][:, :, 3] += 2e-3
+    rec = {}
+    orig = fnet.aggregation
+    fnet.aggregation = lambda *a, **k: (rec.update(args=[x.detach().clone() if torch.is_tensor(x) else x for x in a]), orig(*a, **k))[1]
+    torch.manual_seed(77)
+    _, ep = fnet(fd, None)
+    ep["transform_gt"] = fd["transform_gt"]
+    loss, acc = fnet.loss_feat_fun(ep)
+    loss.backward()
+    xs, xr, fs, fr, _, _, ss, sr = rec["args"]
+    out["feat_in_xyz_src"], out["feat_in_xyz_ref"] = xs.numpy(), xr.numpy()              # [B,3,M]
+    out["feat_in_feat_src"], out["feat_in_feat_ref"] = fs.numpy(), fr.numpy()            # [B,64,M]
+    out["feat_in_score_src"], out["feat_in_score_ref"] = ss.numpy(), sr.numpy()          # [B,M]
+    out["feat_transform_gt"] = fd["transform_gt"].numpy()
+    out["feat_meta"] = np.array(json.dumps(dict(wseed=21, variant="separated", thres_radius=0.15, det_loss_weight=float(fargs.det_loss_weight),
+                                               num_sub=256)))
+    out["feat_desc_src"], out["feat_desc_ref"] = ep["feat_src"].detach().numpy(), ep["feat_ref"].detach().numpy()
+    out["feat_loss_acc"] = np.array([float(loss), float(acc)])
+    for k, p in fnet.named_parameters():
+        if p.grad is None:
+            continue
+        g = p.grad.detach().numpy().reshape(-1)
+        if g.size <= FULL_MAX:
+            out["feat_g_" + k] = g.astype(np.float32)
+        else:
+            out["feat_g_" + k + "_samples"] = g[sample_index(k, g.size, 21)].astype(np.float32)
+            out["feat_g_" + k + "_sum_norm"] = np.array([g.astype(np.float64).sum(), np.sqrt((g.astype(np.float64) ** 2).sum())])
+    for k, b in fnet.named_buffers():
+        if k.startswith(("mlp_feat", "mlp_att")) and k.endswith(("running_mean", "running_var")):
+            out["feat_buf_" + k] = b.detach().numpy().copy()
+    print(f"feat case: loss {float(loss):.5f} acc {float(acc):.2f}, params with gradient: {sum(p.grad is not None for p in fnet.parameters())}")
+
     # the constants of the `label` pipeline's loss (SemanticLoss.get_class_weights, loss.py:896-912); the loss itself cannot be
     # run under this image's torch (a [1, C] weight tensor is rejected by F.cross_entropy) - see oracle/train.py
     from network.loss import SemanticLoss  # type: ignore

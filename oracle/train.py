@@ -92,3 +92,66 @@ def semantic_loss(logits: torch.Tensor, labels: torch.Tensor, class_weights) -> 
     keep = lb != 0
     w = torch.as_tensor(class_weights, dtype=torch.float32).reshape(-1)
     return F.cross_entropy(lg[keep], lb[keep] - 1, weight=w, reduction="mean")
+
+
+# ------------------------------------------------------------------ `feat` pipeline: aggregation MLPs under DetDesLoss
+def mlp1d_train(net: OracleNet, prefix: str, x: torch.Tensor, n_layers: int, update_running: bool = True) -> torch.Tensor:
+    """MLP (RandLANet.py:34-55) in training mode: Conv1d + BatchNorm1d(batch statistics) + LeakyReLU(0.2), last layer bare."""
+    pos = 0
+    for i in range(n_layers):
+        x = F.conv1d(x, net.p[f"{prefix}.{pos}.weight"], net.p[f"{prefix}.{pos}.bias"])
+        pos += 1
+        if i < n_layers - 1:
+            rm, rv = net.p[f"{prefix}.{pos}.running_mean"], net.p[f"{prefix}.{pos}.running_var"]
+            if not update_running:
+                rm, rv = rm.clone(), rv.clone()
+            x = F.batch_norm(x, rm, rv, net.p[f"{prefix}.{pos}.weight"], net.p[f"{prefix}.{pos}.bias"], True, 0.1, 1e-5)
+            x = F.leaky_relu(x, 0.2)
+            pos += 2
+    return x
+
+
+def aggregate_train(net: OracleNet, xyz: torch.Tensor, feat0: torch.Tensor, score: torch.Tensor, update_running: bool = True):
+    """One cloud batch's half of ``aggregation`` in training mode (model.py:209-235) followed by forward_pair's second
+    F.normalize (:651-652).  xyz [B,3,M], feat0 [B,64,M], score [B,M] -> descriptors [B,64,M]."""
+    g = torch.cat((xyz, score[:, None, :]), dim=1)
+    # the reference calls mlp_feat on src and ref before mlp_att on src and ref (running statistics update order); one side here
+    d = mlp1d_train(net, "mlp_feat", feat0, 3, update_running) + mlp1d_train(net, "mlp_att", g, 5, update_running)
+    d = F.normalize(mlp1d_train(net, "mlp_proj", d, 1, update_running), p=2, dim=1)
+    return F.normalize(d, p=2, dim=1)
+
+
+def det_des_loss(feat_src, feat_ref, pt_src, pt_ref, score_ref, transform_gt, thres_radius: float, det_loss_weight: float = 1.0):
+    """DetDesLoss.forward (loss.py:667-702) = CircleLoss.forward(feat_ref, feat_src, pt_ref, T_gt pt_src, score_ref, score_src)
+    (:500-571), restated line by line INCLUDING what the arithmetic really does: ``dist_min`` is the minimum of
+    ``dist_pc * false_negative`` - zero as soon as one column of the row is outside the radius -, so ``pos_mask`` marks only
+    exact coincidences and the positive set is the false-negative ball; masked entries enter both log-sum-exps with
+    exponent 0 (weight 0), i.e. as exp(0) = 1; the accuracy sums over the batch but divides by the row count.
+    feat_* [B,C,M], pt_* [B,3,M], score_ref [B,M], transform_gt [B,3,4] -> (total, accuracy)."""
+    eps, log_scale, pos_margin, neg_margin = 1e5, 10.0, 0.1, 1.4
+    pos_pc = transform_gt[:, :3, :3] @ pt_src + transform_gt[:, :3, 3][:, :, None]                  # se3_torch.transform_V2
+    anc_feat, pos_feat, anc_pc = feat_ref, feat_src, pt_ref
+    anc_score = score_ref / torch.sum(score_ref, dim=1, keepdim=True)
+    dist_pc = torch.norm(anc_pc.unsqueeze(3) - pos_pc.unsqueeze(2), dim=1)
+    sq = -2 * torch.matmul(anc_feat.permute(0, 2, 1).contiguous(), pos_feat)                         # square_distance_V2 (matchnet.py:96-113)
+    sq = sq + torch.sum(anc_feat ** 2, dim=1)[:, :, None] + torch.sum(pos_feat ** 2, dim=1)[:, None, :]
+    dist_feat = torch.sqrt(sq + 1e-16)
+    fn = dist_pc < thres_radius
+    dist_min = torch.min(dist_pc * fn.float(), dim=2, keepdim=True)[0]
+    pos_mask = torch.eq(dist_pc, dist_min)
+    neg_mask = torch.logical_not(pos_mask | fn)
+    pos = dist_feat - eps * neg_mask.float()
+    pos_w = torch.clamp((pos - pos_margin).detach(), min=0)
+    lse_pos = torch.logsumexp(log_scale * (pos - pos_margin) * pos_w, dim=-1)
+    neg = dist_feat + eps * (~neg_mask).float()
+    neg_w = torch.clamp((neg_margin - neg).detach(), min=0)
+    neg_weighted = log_scale * (neg_margin - neg) * neg_w
+    loss_col = F.softplus(lse_pos + torch.logsumexp(neg_weighted, dim=-1)) / log_scale
+    loss_row = F.softplus(lse_pos + torch.logsumexp(neg_weighted, dim=-2)) / log_scale
+    loss_feat = torch.mean(loss_col + loss_row)
+    furthest_positive = torch.max(dist_feat * pos_mask.float(), dim=-1)[0]
+    closest_negative = torch.min(dist_feat + eps * pos_mask.float(), dim=-1)[0]
+    diff = furthest_positive - closest_negative
+    accuracy = (diff < 0).sum() * 100.0 / diff.shape[1]
+    loss_det = torch.mean(diff * anc_score)
+    return loss_feat + loss_det * det_loss_weight, accuracy

@@ -461,3 +461,96 @@ def test_label_pipeline_training_step_matches_the_oracle():
     losses = [train_step_label(tr, batch, labels["src"].int().to(_dev()), labels["ref"].int().to(_dev()), lr=2e-3, dropout_seed=i)["loss"]
               for i in range(6)]
     assert losses[-1] < losses[0], losses
+
+
+# ------------------------------------------------------------------------------------------------- `feat` pipeline
+def _feat_case():
+    meta = json.loads(str(GOLD["feat_meta"]))
+    cfg = NetConfig(feat_len=3, pipeline="feat", num_sub=meta["num_sub"])
+    sd = generate_state_dict(cfg, meta["wseed"], meta["variant"])
+    t = {k: torch.from_numpy(GOLD["feat_in_" + k]) for k in ("xyz_src", "xyz_ref", "feat_src", "feat_ref", "score_src", "score_ref")}
+    return meta, cfg, sd, t
+
+
+def _check_feat_grads(grads, rtol, atol=1e-7):
+    n = 0
+    for name, g in grads.items():
+        g = np.asarray(g, np.float64).reshape(-1)
+        key = "feat_g_" + name
+        if name.endswith(".bias") and (name[:-4] + "weight") in grads and name.split(".")[0] in ("mlp_feat", "mlp_att") and \
+                not name.endswith(("mlp_feat.6.bias", "mlp_att.12.bias")) and int(name.split(".")[1]) % 3 == 0:
+            continue                                   # a Conv1d bias in front of BatchNorm: zero by construction (noise both sides)
+        if key in GOLD:
+            ref = GOLD[key].astype(np.float64)
+        else:
+            ref = GOLD[key + "_samples"].astype(np.float64)
+            g = g[sample_index(name, g.size, 21)]
+        assert np.abs(g - ref).max() <= rtol * np.abs(ref).max() + atol, (name, float(np.abs(g - ref).max()), float(np.abs(ref).max()))
+        n += 1
+    assert n >= 20
+
+
+def test_oracle_feat_pipeline_matches_reference_autograd():
+    """oracle/train.py's aggregation in training mode + DetDesLoss against the imported reference's own forward / backward
+    (descriptors, loss, accuracy, the gradient of all 30 trainable tensors, BatchNorm running statistics)."""
+    meta, cfg, sd, t = _feat_case()
+    net = OracleNet(cfg, sd)
+    params = {k: v.requires_grad_(True) for k, v in net.p.items()
+              if k.startswith(("mlp_feat", "mlp_att", "mlp_proj")) and v.dtype == torch.float32 and not k.endswith(("running_mean", "running_var"))}
+    # the reference's call order: mlp_feat(src), mlp_feat(ref), mlp_att(src), mlp_att(ref) - per module the src pass first
+    d_src = otrain.aggregate_train(net, t["xyz_src"], t["feat_src"], t["score_src"])
+    d_ref = otrain.aggregate_train(net, t["xyz_ref"], t["feat_ref"], t["score_ref"])
+    assert np.abs(d_src.detach().numpy() - GOLD["feat_desc_src"]).max() < 1e-5
+    assert np.abs(d_ref.detach().numpy() - GOLD["feat_desc_ref"]).max() < 1e-5
+    loss, acc = otrain.det_des_loss(d_src, d_ref, t["xyz_src"], t["xyz_ref"], t["score_ref"], torch.from_numpy(GOLD["feat_transform_gt"]),
+                                    meta["thres_radius"], meta["det_loss_weight"])
+    assert abs(float(loss) - GOLD["feat_loss_acc"][0]) < 1e-5 and abs(float(acc) - GOLD["feat_loss_acc"][1]) < 1e-3
+    loss.backward()
+    _check_feat_grads({k: v.grad.numpy() for k, v in params.items()}, 1e-3)
+    for k in GOLD.files:
+        if k.startswith("feat_buf_"):
+            assert np.allclose(net.p[k[len("feat_buf_"):]].numpy(), GOLD[k], rtol=1e-5, atol=1e-6), k
+
+
+@pytest.mark.gpu
+def test_device_feat_pipeline_step_matches_reference_autograd():
+    """`feat` pipeline on the device: aggregation MLPs in training mode (descriptors, running statistics), DetDesLoss (total,
+    accuracy) and the gradient of all 30 trainable tensors, against the imported reference's own forward / backward; the
+    loss operator also against the oracle on a second problem with coincident points and ties; then Adam lowers the loss."""
+    from deepsir_amd.train import AggregationTrainer, _Ops, train_step_feat
+    meta, cfg, sd, t = _feat_case()
+    tr = AggregationTrainer(cfg, sd, _dev())
+    pm = lambda x: x.permute(0, 2, 1).contiguous().to(_dev())
+    inp = {"xyz_src": pm(t["xyz_src"]), "xyz_ref": pm(t["xyz_ref"]), "feat_src": pm(t["feat_src"]), "feat_ref": pm(t["feat_ref"]),
+           "score_src": t["score_src"].to(_dev()), "score_ref": t["score_ref"].to(_dev())}
+    gt = torch.from_numpy(GOLD["feat_transform_gt"]).to(_dev())
+    res = train_step_feat(tr, inp, gt, meta["thres_radius"], meta["det_loss_weight"], apply=False)
+    torch.cuda.synchronize()
+    assert np.abs(res["desc_src"].cpu().numpy() - GOLD["feat_desc_src"].transpose(0, 2, 1)).max() < 1e-4
+    assert np.abs(res["desc_ref"].cpu().numpy() - GOLD["feat_desc_ref"].transpose(0, 2, 1)).max() < 1e-4
+    assert abs(res["loss"] - GOLD["feat_loss_acc"][0]) < 2e-4 and abs(res["acc"] - GOLD["feat_loss_acc"][1]) < 1.0
+    _check_feat_grads({k: v.cpu().numpy() for k, v in tr.grads.items()}, 5e-3, 1e-6)
+    for k in GOLD.files:
+        if k.startswith("feat_buf_"):
+            assert np.allclose(tr.buffers[k[len("feat_buf_"):]].cpu().numpy(), GOLD[k], rtol=1e-4, atol=1e-5), k
+    # the loss operator alone: exact coincidences (pos_mask true), duplicated descriptors, P = 3
+    o = _Ops(_dev())
+    g = torch.Generator().manual_seed(9)
+    P, M = 3, 200
+    fr = torch.nn.functional.normalize(torch.randn(P, 64, M, generator=g), dim=1).requires_grad_()
+    fs = torch.nn.functional.normalize(torch.randn(P, 64, M, generator=g), dim=1).requires_grad_()
+    ps = torch.rand(P, 3, M, generator=g) * 2
+    T = torch.eye(3, 4)[None].repeat(P, 1, 1)
+    T[:, :, 3] = torch.randn(P, 3, generator=g) * 0.1      # identity rotation: p + t rounds the same in any evaluation order
+    pr = (ps + T[:, :, 3:]).clone()
+    pr[:, :, M // 2:] += torch.randn(P, 3, M - M // 2, generator=g) * 0.3      # half the points coincide exactly after T_gt
+    sc = torch.rand(P, M, generator=g) + 0.1
+    loss, acc = otrain.det_des_loss(fs, fr, ps, pr, sc, T, 0.2, 0.7)
+    loss.backward()
+    out, d_ref, d_src = o.det_des_loss(pm(fr.detach()), pm(fs.detach()), pm(pr), pm(ps), sc.to(_dev()), T.to(_dev()), 0.2, 0.7)
+    out = out.cpu().numpy()
+    assert abs(out[0] - float(loss.detach())) < 1e-4 * max(1.0, abs(float(loss.detach()))) and abs(out[3] - float(acc)) < 1.0
+    assert np.abs(d_ref.cpu().numpy() - fr.grad.permute(0, 2, 1).numpy()).max() <= 5e-3 * float(fr.grad.abs().max())
+    assert np.abs(d_src.cpu().numpy() - fs.grad.permute(0, 2, 1).numpy()).max() <= 5e-3 * float(fs.grad.abs().max())
+    losses = [train_step_feat(tr, inp, gt, meta["thres_radius"], meta["det_loss_weight"], lr=1e-3)["loss"] for _ in range(8)]
+    assert losses[-1] < losses[0], losses
