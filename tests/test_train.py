@@ -554,3 +554,33 @@ def test_device_feat_pipeline_step_matches_reference_autograd():
     assert np.abs(d_src.cpu().numpy() - fs.grad.permute(0, 2, 1).numpy()).max() <= 5e-3 * float(fs.grad.abs().max())
     losses = [train_step_feat(tr, inp, gt, meta["thres_radius"], meta["det_loss_weight"], lr=1e-3)["loss"] for _ in range(8)]
     assert losses[-1] < losses[0], losses
+
+
+@pytest.mark.gpu
+def test_feat_pipeline_step_from_the_inference_engine():
+    """`feat_pipeline_inputs` (frozen half from an Engine built for the `feat` pipeline: key-point selection, raw features of the
+    selected points) feeding `train_step_feat`: the selected features are the extractor's rows at `index`, and training lowers
+    the loss on real engine outputs."""
+    from deepsir_amd.engine import Engine
+    from deepsir_amd.synth import make_pair
+    from deepsir_amd.train import AggregationTrainer, feat_pipeline_inputs, train_step_feat
+    n, P, M = 1024, 2, 256
+    cfg = NetConfig(feat_len=3, pipeline="feat", num_sub=M)
+    sd = generate_state_dict(cfg, 21, "separated")
+    eng = Engine(cfg, max_points=n, max_pairs=P)
+    eng.load_state_dict(sd)
+    raws = [make_pair(n, 600 + b, 3) for b in range(P)]
+    batch = {f"points_{s}": torch.from_numpy(np.concatenate([r[f"points_{s}"] for r in raws])).to(_dev()) for s in ("src", "ref")}
+    gt = torch.from_numpy(np.concatenate([r["transform_gt"] for r in raws]).astype(np.float32)).to(_dev())
+    gt[:, :, 3] += 2e-3                                                  # off the exact-coincidence knife edge (DESIGN.md section 8)
+    inp = feat_pipeline_inputs(eng, batch, M)
+    fp = eng.forward_pair(batch["points_src"], batch["points_ref"], num_sub=M)
+    feat, _ = eng.randla_forward("feat_extractor", batch["points_src"], *eng.knn_pyramid(batch["points_src"]), want_logits=False)
+    want = torch.gather(feat, 1, fp["src"]["index"].long()[:, :, None].expand(-1, -1, 64))
+    assert torch.equal(inp["feat_src"], want) and torch.equal(inp["xyz_src"], fp["src"]["xyz"])
+    tr = AggregationTrainer(cfg, sd, _dev())
+    first = train_step_feat(tr, inp, gt, 0.15, 1.0, apply=False)
+    assert np.allclose(np.linalg.norm(first["desc_src"].cpu().numpy(), axis=2), 1.0, atol=1e-5)    # unit descriptors (training-mode
+    # BatchNorm uses batch statistics, so they differ from the engine's evaluation-mode descriptors by construction)
+    losses = [train_step_feat(tr, inp, gt, 0.15, 1.0, lr=1e-3)["loss"] for _ in range(8)]
+    assert np.isfinite(losses).all() and losses[-1] < losses[0], losses
