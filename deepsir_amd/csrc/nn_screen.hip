@@ -305,10 +305,12 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(DSIR_S
 #endif
   };
 #undef DSIR_MFMA
-  gload(preA, c_begin);
-  lstore(preA, 0);
+  // all three fetches in flight before the first store waits for its own (vmcnt counts them in order)
+  Pre pre0;
+  gload(pre0, c_begin);
   gload(preA, c_begin + SBC);
   gload(preB, c_begin + 2 * SBC);
+  lstore(pre0, 0);
   __syncthreads();
   for (int c0 = c_begin; c0 < c_end; c0 += 2 * SBC) {
     tile(c0, 0, preA);
@@ -323,19 +325,28 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(DSIR_S
   // T = min over the lanes of (their smallest lower bound + its bound width) >= min_k D(row, k) over this block's
   // columns, hence over all columns.  Every column of the block with lower bound <= T is either some lane's smallest
   // (emitted) or makes that lane's runner-up <= T (class emitted).
+  // the epilogue's gathers (|a|^2 of the lane's rows, |b|^2 of their best columns) first, all independent: one memory
+  // latency for the 4 RT elements instead of one each in front of the atomics
+  float sanv[RT][4], sbkv[RT][4];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      sanv[rt][r] = sa[arow + min(row0 + rt * 16 + 4 * fq + r, J - 1)];
+      sbkv[rt][r] = sb[brow + max(k1[rt][r], 0)];
+    }
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = row0 + rt * 16 + 4 * fq + r;
-      const int rr = min(row, J - 1);
-      const float san = sa[arow + rr];
+      const float san = sanv[rt][r];
       const float slo = san - kC1 * san - kC0;       // |a|^2 - d_a
       // z' = 2^22 z: L = slo - 2 z = slo - 2^-21 z'
       const float l1 = fmaf(z1[rt][r], -4.76837158203125e-7f, slo), l2 = fmaf(z2[rt][r], -4.76837158203125e-7f, slo);
       const int k = k1[rt][r];
       float u = INFINITY;
-      if (k >= 0) u = l1 + kW * (kC1 * (san + sb[brow + k]) + kC0);
+      if (k >= 0) u = l1 + kW * (kC1 * (san + sbkv[rt][r]) + kC0);
       float T = u;
 #pragma unroll
       for (int o = 1; o < 16; o <<= 1) T = fminf(T, __shfl_xor(T, o));
