@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void split_norm_kernel(const float* __restrict
 #define DSIR_MORE(x) (x)
 #endif
 template <int RT, int NWV>
-__global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(DSIR_SCREEN_WPE, DSIR_SCREEN_WPE))) void screen_kernel(const _Float16* __restrict__ Ah, const _Float16* __restrict__ Al,
+__device__ __forceinline__ void screen_item(const int wi, const _Float16* __restrict__ Ah, const _Float16* __restrict__ Al,
                                                      const _Float16* __restrict__ Bh, const _Float16* __restrict__ Bl,
                                                      const float* __restrict__ sa, const float* __restrict__ sb, int J, int K,
                                                      int cols_per_split, int rb_count, int splits,
@@ -172,9 +172,6 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(DSIR_S
   __shared__ float4 sbs[2][SBC];                    // 2^11 c, c = -(|b|^2 - d_b) / 2, replicated x4: the first MFMA's C operand
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fq = lane >> 4;
-  const int nwg = gridDim.x, id = blockIdx.x;
-  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = id & 7;
-  const int wi = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3);
   const int rb = wi % rb_count;
   const int split = (wi / rb_count) % splits;
   const int pair = wi / (rb_count * splits);
@@ -186,7 +183,9 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(DSIR_S
   __shared__ int s_skip;
   if (tid == 0) s_skip = ovf[pair] >= ovf_min ? 1 : 0;
   __syncthreads();
-  if (s_skip) return;
+  const int skip = s_skip;
+  __syncthreads();                                   // the next item of a persistent workgroup rewrites s_skip
+  if (skip) return;
 
   // A fragments: lane holds row fr, channels 32 c + 8 fq .. +7; ah = 2^11 x (high part), al = 2^11 x (low part)
   h8 ah[RT][2], al[RT][2];
@@ -363,6 +362,24 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(DSIR_S
         if (l2 <= T) emit(-(1 + split * 16 + fr), l2);
       }
     }
+}
+
+// The launch: one work item (pair, ref split, row block) per workgroup, or - DSIR_SCREEN_PERSIST workgroups per CU - a
+// persistent grid whose workgroups walk the items with stride gridDim (no workgroup launch / drain between items).  XCD-aware
+// in both forms: workgroups are dealt round-robin over the 8 XCDs, the remap hands every XCD a contiguous range of items.
+template <int RT, int NWV>
+__global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(DSIR_SCREEN_WPE, DSIR_SCREEN_WPE))) void screen_kernel(const _Float16* __restrict__ Ah, const _Float16* __restrict__ Al,
+                                                     const _Float16* __restrict__ Bh, const _Float16* __restrict__ Bl,
+                                                     const float* __restrict__ sa, const float* __restrict__ sb, int J, int K,
+                                                     int cols_per_split, int rb_count, int splits,
+                                                     unsigned int* __restrict__ umin, int32_t* __restrict__ cnt,
+                                                     int2* __restrict__ cand, int32_t* __restrict__ ovf,
+                                                     int32_t* __restrict__ rowlist, int ovf_min, int total) {
+  const int nwg = gridDim.x, id = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = id & 7;
+  const int first = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3);
+  for (int wi = first; wi < total; wi += nwg)
+    screen_item<RT, NWV>(wi, Ah, Al, Bh, Bl, sa, sb, J, K, cols_per_split, rb_count, splits, umin, cnt, cand, ovf, rowlist, ovf_min);
 }
 
 // exact D(row, k) exactly as nn_match.hip evaluates it: the k-ordered fmaf chain of v_mfma_f32_16x16x4_f32 from a zero
@@ -568,16 +585,18 @@ void launch_nn_screen(const float* a, const float* b, const void* ah, const void
   if (force_splits > 0) splits = force_splits < tiles ? force_splits : tiles;
   const int cols = ((tiles + splits - 1) / splits) * SBC;
   splits = (K + cols - 1) / cols;
-  const dim3 grid((unsigned)((int64_t)rb_count * splits * pairs));
+  const int total = (int)((int64_t)rb_count * splits * pairs);
+  static const int persist = getenv("DSIR_SCREEN_PERSIST") ? atoi(getenv("DSIR_SCREEN_PERSIST")) : 0;   // workgroups per CU; 0 = one per item
+  const dim3 grid((unsigned)(persist > 0 && total > persist * resident ? persist * resident : total));
   const _Float16 *Ah = reinterpret_cast<const _Float16*>(ah), *Al = reinterpret_cast<const _Float16*>(al);
   const _Float16 *Bh = reinterpret_cast<const _Float16*>(bh), *Bl = reinterpret_cast<const _Float16*>(bl);
   if (evk0) (void)hipEventRecord(evk0, st);
   if (RT == 4)
     hipLaunchKernelGGL((screen_kernel<4, NWV>), grid, dim3(NWV * 64), 0, st, Ah, Al, Bh, Bl, sa, sb, J, K, cols, rb_count, splits, umin,
-                       cnt, cand, ovf, rowlist, ovf_min);
+                       cnt, cand, ovf, rowlist, ovf_min, total);
   else
     hipLaunchKernelGGL((screen_kernel<2, NWV>), grid, dim3(NWV * 64), 0, st, Ah, Al, Bh, Bl, sa, sb, J, K, cols, rb_count, splits, umin,
-                       cnt, cand, ovf, rowlist, ovf_min);
+                       cnt, cand, ovf, rowlist, ovf_min, total);
   if (evk1) (void)hipEventRecord(evk1, st);
   hipLaunchKernelGGL(exact_pick_kernel, dim3((J + 255) / 256, pairs), dim3(256), 0, st, a, b, sa, sb, J, K, umin, cnt, cand, ovf,
                      ovf_min, rowlist, idx);
