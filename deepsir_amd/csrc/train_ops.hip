@@ -32,12 +32,24 @@ __global__ __launch_bounds__(256) void t_gemm_kernel(const float* __restrict__ X
   f32x4 acc[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // rows of X (and of W when it is k-contiguous) are read as one 16-byte load per thread where alignment allows
+  const bool xv = (ldx & 3) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0;
+  const bool wv = wk == 1 && (wn & 3) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0;
   for (int k0 = 0; k0 < K; k0 += TK) {
+    const int kb = k0 + sk;
+    if (xv && xr < rows && kb + 3 < K) {
+      const float4 v = *reinterpret_cast<const float4*>(X + xr * ldx + kb);
+      Xs[sr * TLD + sk] = v.x; Xs[sr * TLD + sk + 1] = v.y; Xs[sr * TLD + sk + 2] = v.z; Xs[sr * TLD + sk + 3] = v.w;
+    } else {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int k = k0 + sk + u;
-      Xs[sr * TLD + sk + u] = (xr < rows && k < K) ? X[xr * ldx + k] : 0.f;
-      Ws[sr * TLD + sk + u] = (wc < N && k < K) ? W[(int64_t)wc * wn + (int64_t)k * wk] : 0.f;
+      for (int u = 0; u < 4; ++u) Xs[sr * TLD + sk + u] = (xr < rows && kb + u < K) ? X[xr * ldx + kb + u] : 0.f;
+    }
+    if (wv && wc < N && kb + 3 < K) {
+      const float4 v = *reinterpret_cast<const float4*>(W + (int64_t)wc * wn + kb);
+      Ws[sr * TLD + sk] = v.x; Ws[sr * TLD + sk + 1] = v.y; Ws[sr * TLD + sk + 2] = v.z; Ws[sr * TLD + sk + 3] = v.w;
+    } else {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) Ws[sr * TLD + sk + u] = (wc < N && kb + u < K) ? W[(int64_t)wc * wn + (int64_t)(kb + u) * wk] : 0.f;
     }
     __syncthreads();
 #pragma unroll
@@ -70,25 +82,36 @@ constexpr int DLD = TB + 16;   // LDS row of the transposed-use tiles: (k-row q,
 __global__ __launch_bounds__(256) void t_gemm_dw_kernel(const float* __restrict__ dY, int ldy, const float* __restrict__ X, int ldx,
                                                         int64_t rows, int64_t rows_per_split, int N, int K, int Kp,
                                                         float* __restrict__ partial) {
-  __shared__ float As[TK * DLD];
-  __shared__ float Bs[TK * DLD];
+  __shared__ __attribute__((aligned(16))) float As[TK * DLD];
+  __shared__ __attribute__((aligned(16))) float Bs[TK * DLD];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int fr = lane & 15, fq = lane >> 4;
   const int n0 = blockIdx.x * TB, k0 = blockIdx.y * TB;
   const int64_t r_begin = (int64_t)blockIdx.z * rows_per_split;
   const int64_t r_end = min(rows, r_begin + rows_per_split);
   const int sr = tid >> 4, sc = (tid & 15) * 4;         // staging: row sr of the chunk, four consecutive columns
+  const bool av = (ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(dY) & 15) == 0;
+  const bool bv = (ldx & 3) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0;
   f32x4 acc[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   for (int64_t r0 = r_begin; r0 < r_end; r0 += TK) {
     const int64_t r = r0 + sr;
     const bool rin = r < r_end;
+    if (av && rin && n0 + sc + 3 < N) {
+      *reinterpret_cast<float4*>(&As[sr * DLD + sc]) = *reinterpret_cast<const float4*>(dY + r * ldy + n0 + sc);
+    } else {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int n = n0 + sc + u, k = k0 + sc + u;
-      As[sr * DLD + sc + u] = (rin && n < N) ? dY[r * ldy + n] : 0.f;
-      Bs[sr * DLD + sc + u] = !rin ? 0.f : (k < K ? X[r * ldx + k] : (k == K && Kp > K ? 1.f : 0.f));
+      for (int u = 0; u < 4; ++u) As[sr * DLD + sc + u] = (rin && n0 + sc + u < N) ? dY[r * ldy + n0 + sc + u] : 0.f;
+    }
+    if (bv && rin && k0 + sc + 3 < K) {
+      *reinterpret_cast<float4*>(&Bs[sr * DLD + sc]) = *reinterpret_cast<const float4*>(X + r * ldx + k0 + sc);
+    } else {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = k0 + sc + u;
+        Bs[sr * DLD + sc + u] = !rin ? 0.f : (k < K ? X[r * ldx + k] : (k == K && Kp > K ? 1.f : 0.f));
+      }
     }
     __syncthreads();
 #pragma unroll
@@ -732,6 +755,13 @@ __global__ void t_wce_scale_kernel(float* __restrict__ d, int64_t n, const doubl
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) d[e] *= f;
 }
 
+// flag[0] = 1 when any element is NaN (train.py:437-441: the step is skipped then)
+__global__ void t_any_nan_kernel(const float* __restrict__ x, int64_t n, int32_t* __restrict__ flag) {
+  bool bad = false;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) bad |= x[e] != x[e];
+  if (__any(bad) && (threadIdx.x & 63) == 0) flag[0] = 1;
+}
+
 inline unsigned grid1(int64_t n) { const int64_t g = (n + 255) / 256; return (unsigned)(g < 1 ? 1 : (g > 8192 ? 8192 : g)); }
 inline int done() { return (int)hipGetLastError(); }
 
@@ -979,6 +1009,13 @@ int dsir_t_mul_mask(void* stream, const float* x, const uint8_t* mask, float sca
 int dsir_t_axpy(void* stream, float a, const float* x, int64_t n, float* y) {
   if (!x || !y || n < 1) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(t_axpy_kernel, dim3(grid1(n)), dim3(256), 0, (hipStream_t)stream, a, x, n, y);
+  return done();
+}
+
+int dsir_t_any_nan(void* stream, const float* x, int64_t n, int32_t* flag) {
+  if (!x || !flag || n < 1) return (int)hipErrorInvalidValue;
+  (void)hipMemsetAsync(flag, 0, sizeof(int32_t), (hipStream_t)stream);
+  hipLaunchKernelGGL(t_any_nan_kernel, dim3(grid1(n)), dim3(256), 0, (hipStream_t)stream, x, n, flag);
   return done();
 }
 

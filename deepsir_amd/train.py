@@ -260,6 +260,14 @@ class _ParamStore:
     def zero_grad(self) -> None:
         self.flat_g.zero_()
 
+    def grads_have_nan(self) -> bool:
+        """train.py:437-441 ("Gradients include NaN values. Parameters will not be updated"): one kernel, one 4-byte read."""
+        o = self.ops
+        o.begin()
+        flag = torch.empty(1, dtype=torch.int32, device=self.device)
+        o._ok(o.lib.dsir_t_any_nan(o.stream, _ptr(self.flat_g), self.flat_g.numel(), _ptr(flag)), "dsir_t_any_nan")
+        return bool(flag.item())
+
     def state_dict(self) -> Dict[str, np.ndarray]:
         """Parameters and BatchNorm running statistics in the reference's shapes (host)."""
         return {k: v.detach().cpu().numpy().reshape(self._shapes[k]) for k, v in list(self.params.items()) + list(self.buffers.items())}
@@ -566,7 +574,7 @@ def train_step_align(engine, trainer: RandlaTrainer, batch: dict, result: dict, 
     g = out["grad_logits"]
     for it in range(n_iter):
         trainer.backward(tapes[it], g[it])
-    bad = bool(torch.isnan(trainer.flat_g).any())
+    bad = trainer.grads_have_nan()
     if apply and not bad:
         trainer.adam_step(lr)
     out["logits"] = lg_all
@@ -649,7 +657,7 @@ def train_step_feat(trainer: AggregationTrainer, inp: dict, transform_gt: torch.
     trainer.backward(tape_s, g_src)
     trainer.backward(tape_r, g_ref)
     vals = out.cpu().numpy()
-    bad = bool(torch.isnan(trainer.flat_g).any())
+    bad = trainer.grads_have_nan()
     if apply and not bad:
         trainer.adam_step(lr)
     return {"loss": float(vals[0]), "loss_feat": float(vals[1]), "loss_det": float(vals[2]), "acc": float(vals[3]),
@@ -688,7 +696,7 @@ def train_step_label(trainer: RandlaTrainer, batch: dict, labels_src: torch.Tens
     vals = torch.stack(outs).cpu().numpy()                      # one host read for both sides
     res["loss"] = float(vals[0, 0] + vals[1, 0])
     res["acc"] = float(vals[0, 2] / max(vals[0, 3], 1.0) + vals[1, 2] / max(vals[1, 3], 1.0))    # acc_src + acc_ref (loss.py:994)
-    bad = bool(torch.isnan(trainer.flat_g).any())
+    bad = trainer.grads_have_nan()
     if apply and not bad:
         trainer.adam_step(lr)
     res["skipped"] = bad
@@ -777,7 +785,7 @@ class AlignTrainStep:
         else:
             self._backward_all()
         tr.ops.begin()
-        bad = bool(torch.isnan(tr.flat_g).any())
+        bad = tr.grads_have_nan()
         if apply and not bad:
             tr.adam_step(lr)
         out["logits"] = self.logits

@@ -113,6 +113,9 @@ int dsir_t_mul_mask(void* stream, const float* x, const uint8_t* mask, float sca
 /* y += a x */
 int dsir_t_axpy(void* stream, float a, const float* x, int64_t n, float* y);
 
+/* "Check if any of the gradients is NaN" (train.py:437-441): flag[0] (device int32) = 1 if any of the n floats is NaN, else 0. */
+int dsir_t_any_nan(void* stream, const float* x, int64_t n, int32_t* flag);
+
 /* torch.optim.Adam.step (train.py:323, :446; betas 0.9 / 0.999, eps 1e-8, no weight decay, no amsgrad):
  * m = b1 m + (1 - b1) g; v = b2 v + (1 - b2) g^2; p -= lr / (1 - b1^step) * m / (sqrt(v) / sqrt(1 - b2^step) + eps). */
 int dsir_t_adam(void* stream, float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
