@@ -538,7 +538,7 @@ class RandlaTrainer(_ParamStore):
 
 def train_step_align(engine, trainer: RandlaTrainer, batch: dict, result: dict, transform_gt: np.ndarray,
                      labels: Optional[np.ndarray] = None, lr: float = 1e-3, dropout_seed: Optional[int] = None,
-                     loss_kwargs: Optional[dict] = None, apply: bool = True) -> dict:
+                     loss_kwargs: Optional[dict] = None, apply: bool = True, dist=None) -> dict:
     """One optimisation step of the `align` pipeline on the inlier model (train.py:396-448).
 
     ``batch``: the device tensors of one ``Engine.register`` call (points_src [P][N][C], the src pyramid
@@ -574,12 +574,27 @@ def train_step_align(engine, trainer: RandlaTrainer, batch: dict, result: dict, 
     g = out["grad_logits"]
     for it in range(n_iter):
         trainer.backward(tapes[it], g[it])
+    all_reduce_gradients(trainer, dist)
     bad = trainer.grads_have_nan()
     if apply and not bad:
         trainer.adam_step(lr)
     out["logits"] = lg_all
     out["skipped"] = bad
     return out
+
+
+def all_reduce_gradients(trainer: "_ParamStore", dist) -> None:
+    """Data-parallel training over the GPUs of a node (one process per GPU): every rank runs the step on its own pairs, then ONE
+    all_reduce of the flat gradient buffer - the whole model is a single bucket, so there is nothing to overlap or schedule -
+    and the mean, before the (identical) optimiser step.  ``dist``: torch.distributed (backend "nccl" = RCCL over xGMI), or
+    None / world size 1: no-op.  GroupNorm is per cloud and needs nothing; BatchNorm statistics stay per rank, as they would
+    under the reference's optimiser with torch's DistributedDataParallel and no SyncBatchNorm."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    w = dist.get_world_size()
+    dist.all_reduce(trainer.flat_g)
+    trainer.ops.begin()
+    trainer.ops.axpy(1.0 / w - 1.0, trainer.flat_g, trainer.flat_g)        # g += (1/w - 1) g, element-wise in place
 
 
 class AggregationTrainer(_ParamStore):
@@ -644,7 +659,7 @@ def feat_pipeline_inputs(engine, batch: dict, num_sub: int) -> dict:
 
 
 def train_step_feat(trainer: AggregationTrainer, inp: dict, transform_gt: torch.Tensor, thres_radius: float, det_loss_weight: float = 1.0,
-                    lr: float = 1e-3, apply: bool = True) -> dict:
+                    lr: float = 1e-3, apply: bool = True, dist=None) -> dict:
     """One optimisation step of the `feat` pipeline (train.py:407-410, :448): DetDesLoss on the descriptors of the selected key
     points, backward through the aggregation MLPs in training mode, Adam.  ``inp``: xyz_{src,ref} [P][M][3],
     feat_{src,ref} [P][M][64], score_{src,ref} [P][M] (``feat_pipeline_inputs``)."""
@@ -657,6 +672,7 @@ def train_step_feat(trainer: AggregationTrainer, inp: dict, transform_gt: torch.
     trainer.backward(tape_s, g_src)
     trainer.backward(tape_r, g_ref)
     vals = out.cpu().numpy()
+    all_reduce_gradients(trainer, dist)
     bad = trainer.grads_have_nan()
     if apply and not bad:
         trainer.adam_step(lr)
@@ -665,7 +681,7 @@ def train_step_feat(trainer: AggregationTrainer, inp: dict, transform_gt: torch.
 
 
 def train_step_label(trainer: RandlaTrainer, batch: dict, labels_src: torch.Tensor, labels_ref: torch.Tensor, lr: float = 1e-3,
-                     dropout_seed: Optional[int] = None, apply: bool = True) -> dict:
+                     dropout_seed: Optional[int] = None, apply: bool = True, dist=None) -> dict:
     """One optimisation step of the `label` pipeline (train.py:412-415, :448): the semantic head of the feature extractor.
     ``forward_pair`` runs ``feat_extractor`` on the src and on the ref clouds SEPARATELY (model.py:629-632: BatchNorm batch
     statistics per call), ``SemanticLoss.forward`` adds the two weighted cross entropies (loss.py:991-995).
@@ -696,6 +712,7 @@ def train_step_label(trainer: RandlaTrainer, batch: dict, labels_src: torch.Tens
     vals = torch.stack(outs).cpu().numpy()                      # one host read for both sides
     res["loss"] = float(vals[0, 0] + vals[1, 0])
     res["acc"] = float(vals[0, 2] / max(vals[0, 3], 1.0) + vals[1, 2] / max(vals[1, 3], 1.0))    # acc_src + acc_ref (loss.py:994)
+    all_reduce_gradients(trainer, dist)
     bad = trainer.grads_have_nan()
     if apply and not bad:
         trainer.adam_step(lr)
@@ -750,7 +767,7 @@ class AlignTrainStep:
             self.tr.backward(self.tapes[it], self.grad[it])
 
     def step(self, batch: dict, result: dict, transform_gt, labels=None, lr: float = 1e-3, dropout_seed: Optional[int] = None,
-             loss_kwargs: Optional[dict] = None, apply: bool = True) -> dict:
+             loss_kwargs: Optional[dict] = None, apply: bool = True, dist=None) -> dict:
         tr = self.tr
         self.xyz_s.copy_(batch["points_src"][:, :, :3]); self.xyz_r.copy_(batch["points_ref"][:, :, :3])
         self.src_xyz.copy_(batch["src_xyz"]); self.neigh.copy_(batch["src_neigh"])
@@ -784,7 +801,7 @@ class AlignTrainStep:
             self.gb.replay()
         else:
             self._backward_all()
-        tr.ops.begin()
+        all_reduce_gradients(tr, dist)
         bad = tr.grads_have_nan()
         if apply and not bad:
             tr.adam_step(lr)

@@ -584,3 +584,19 @@ def test_feat_pipeline_step_from_the_inference_engine():
     # BatchNorm uses batch statistics, so they differ from the engine's evaluation-mode descriptors by construction)
     losses = [train_step_feat(tr, inp, gt, 0.15, 1.0, lr=1e-3)["loss"] for _ in range(8)]
     assert np.isfinite(losses).all() and losses[-1] < losses[0], losses
+
+
+@pytest.mark.gpu
+def test_data_parallel_step_two_ranks_on_one_gpu():
+    """Data-parallel training (`all_reduce_gradients`): two ranks with different pairs (both on the one visible GPU, gloo because
+    RCCL refuses two ranks per device), one all_reduce of the flat gradient buffer per step: the reduced gradient is the mean of
+    the local ones and both ranks end with bit-identical weights."""
+    import subprocess, sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["DSIR_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29733", os.path.join(ROOT, "tools", "train_dp_check.py")], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert j["world_size"] == 2 and j["grad_is_mean"] and j["params_identical"], j
