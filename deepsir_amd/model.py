@@ -1,4 +1,5 @@
-"""Drop-in for the reference's ``network.model.Network`` (align, feat and label pipelines, inference).
+"""Drop-in for the reference's ``network.model.Network`` (align, feat and label pipelines: inference, and the optimisation
+step of each through ``Network.train_step``).
 
 Keeps the reference's host API verbatim (reference network/model.py:119-195,
 :297-298, :520-607; test.py:609-614):
@@ -126,3 +127,60 @@ class Network(nn.Module):
             "pt_ref_new": out["pt_ref_new"],
         }
         return transforms, endpoints
+
+    # ---- one optimisation step of the pipeline: train.py:396-448 without autograd (deepsir_amd/train.py)
+    def train_step(self, data: Dict[str, torch.Tensor], opt=None, lr: float = 1e-3, dropout_seed: Optional[int] = None,
+                   thres_radius: float = 0.1, det_loss_weight: float = 1.0, loss_kwargs: Optional[dict] = None, dist=None) -> dict:
+        """What the reference's loop does per batch - ``my_model(train_data, opt)``, ``loss_*_fun``, ``loss.backward()``,
+        ``optimizer.step()`` (train.py:396-448) - for this network's pipeline, on the device:
+          align: trains ``inlier_model`` (the only sub-network ScanAlignmentLoss reaches; data: transform_gt [B,3,4] and,
+                 for the confidence term, ``matches`` = per pair an int [n',2] array as the reference's data loader gives);
+          label: trains ``feat_extractor`` through SemanticLoss (data: labels_src / labels_ref [B,N] in 0..19);
+          feat:  trains ``mlp_feat`` / ``mlp_att`` / ``mlp_proj`` through DetDesLoss (data: transform_gt; needs num_sub > 0).
+        The updated tensors are written back into this module's buffers (``state_dict()`` is the trained checkpoint) and
+        serve the next ``forward``.  Adam state lives in the trainer kept on the module.  Returns the step's dict (loss ...)."""
+        from . import train as T
+        src, ref = data["points_src"].float(), data["points_ref"].float()
+        B, J, _ = src.shape
+        eng = self._ensure_engine(max(J, ref.shape[1]), B)
+        dev = src.device
+        sd = self.state_dict()
+        if getattr(self, "_trainer", None) is None:
+            if self.pipeline == "align":
+                self._trainer = T.RandlaTrainer(self.cfg, sd, "inlier_model", 6, 1, dev)
+            elif self.pipeline == "label":
+                self._trainer = T.RandlaTrainer(self.cfg, sd, "feat_extractor", self.cfg.feat_len, self.cfg.num_classes, dev)
+            else:
+                self._trainer = T.AggregationTrainer(self.cfg, sd, dev)
+        tr = self._trainer
+        batch = {"points_src": src, "points_ref": ref}
+        for s_, pts in (("src", src), ("ref", ref)):
+            if all(f"points_{s_}_{k}" in data for k in _PYR_KEYS):
+                pyr = [data[f"points_{s_}_xyz"].float()] + [data[f"points_{s_}_{k}"].to(torch.int32) for k in _PYR_KEYS[1:]]
+            else:
+                pyr = eng.knn_pyramid(pts)
+            batch[f"{s_}_xyz"], batch[f"{s_}_neigh"], batch[f"{s_}_sub"], batch[f"{s_}_interp"] = [t.contiguous() for t in pyr]
+        if self.pipeline == "align":
+            n_iter = int(opt[0]) if opt is not None else self.cfg.num_reg_iter
+            res = eng.register(src, ref, n_iter)
+            labels = None
+            if "matches" in data:
+                labels = torch.from_numpy(T.find_correct_correspondence(data["matches"], res["idx"], J)).to(dev)
+            out = T.train_step_align(eng, tr, batch, res, data["transform_gt"].float().to(dev), labels, lr, dropout_seed, loss_kwargs, dist=dist)
+            out["loss"] = out["losses"]["total"]
+        elif self.pipeline == "label":
+            out = T.train_step_label(tr, batch, data["labels_src"].to(torch.int32).to(dev), data["labels_ref"].to(torch.int32).to(dev), lr,
+                                     dropout_seed, dist=dist)
+        else:
+            if self.cfg.num_sub <= 0:
+                raise EngineError("pipeline='feat' trains on the top-num_sub key points: set args.num_sub > 0")
+            inp = T.feat_pipeline_inputs(eng, batch, self.cfg.num_sub)
+            out = T.train_step_feat(tr, inp, data["transform_gt"].float().to(dev), thres_radius, det_loss_weight, lr, dist=dist)
+        if not out.get("skipped", False):
+            new = tr.state_dict()
+            with torch.no_grad():
+                own = dict(self.named_buffers())
+                for k, v in new.items():
+                    own[k].copy_(torch.from_numpy(np.ascontiguousarray(v)).to(own[k].device))
+            self._dirty = True
+        return out

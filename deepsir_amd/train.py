@@ -30,6 +30,23 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
+def find_correct_correspondence(matches: Sequence, idx: "np.ndarray | torch.Tensor", hash_seed: int) -> np.ndarray:
+    """ScanAlignmentLoss.find_correct_correspondence with ``_hash`` (network/loss.py:280-294, :723-749; host work in the
+    reference too): is the predicted pair (j, idx[j]) among the ground-truth matches of its cloud pair?
+    matches: per pair an int array [n', 2] of (src, ref) indices; idx [n_iter][P][J] (``pred_pairs[i][..., 1]``);
+    hash_seed: the reference passes points_src.shape[1] (:819).  -> float32 [n_iter][P][J] of 0 / 1 (the BCE targets)."""
+    ix = idx.detach().cpu().numpy() if isinstance(idx, torch.Tensor) else np.asarray(idx)
+    n_iter, P, J = ix.shape
+    out = np.zeros((n_iter, P, J), np.float32)
+    ar = np.arange(J, dtype=np.int64)
+    for p in range(P):
+        m = matches[p].detach().cpu().numpy() if isinstance(matches[p], torch.Tensor) else np.asarray(matches[p])
+        keys = m[:, 0].astype(np.int64) + m[:, 1].astype(np.int64) * int(hash_seed)
+        for i in range(n_iter):
+            out[i, p] = np.isin(ar + ix[i, p].astype(np.int64) * int(hash_seed), keys)
+    return out
+
+
 class _Ops:
     """The C ABI of include/dsir_train.h on torch device tensors (memory only) and torch's current HIP stream."""
 

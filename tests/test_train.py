@@ -600,3 +600,58 @@ def test_data_parallel_step_two_ranks_on_one_gpu():
     assert r.returncode == 0, r.stderr[-3000:]
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert j["world_size"] == 2 and j["grad_is_mean"] and j["params_identical"], j
+
+
+def test_find_correct_correspondence_is_the_references_rule():
+    from deepsir_amd.train import find_correct_correspondence
+    from oracle.align_loss import find_correct_correspondence as oracle_fcc      # pinned restatement (align_loss_cases.npz)
+    rng = np.random.Generator(np.random.Philox(key=4))
+    J, P, n_iter = 300, 3, 2
+    matches = [np.stack([rng.permutation(J)[:200], rng.integers(0, J, 200)], 1) for _ in range(P)]
+    idx = rng.integers(0, J, (n_iter, P, J))
+    for p in range(P):
+        idx[:, p, matches[p][:50, 0]] = matches[p][:50, 1]                         # some predictions hit their match
+    got = find_correct_correspondence(matches, idx, J)
+    for i in range(n_iter):
+        for p in range(P):
+            want = oracle_fcc(matches[p], np.stack([np.arange(J), idx[i, p]], 1), J)
+            assert np.array_equal(got[i, p].astype(bool), want)
+    assert got.sum() >= n_iter * P * 50
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pipeline", ["align", "label", "feat"])
+def test_network_train_step_drop_in(pipeline):
+    """`Network.train_step`: the reference loop's per-batch work behind the drop-in module - the loss falls over a few steps,
+    the trained tensors land in `state_dict()` and the next `forward` uses them."""
+    from types import SimpleNamespace
+    from deepsir_amd.model import Network
+    from deepsir_amd.synth import make_pair
+    from deepsir_amd.weights import to_torch_state_dict
+    n, P = 1024, 2
+    args = SimpleNamespace(pipeline=pipeline, feat_len=3, num_sub=256 if pipeline == "feat" else -1, num_reg_iter=3)
+    net = Network(args)
+    sd = generate_state_dict(net.cfg, 8, "plain" if pipeline == "label" else "separated")
+    net.load_state_dict(to_torch_state_dict(sd))
+    net.cuda().eval()
+    raws = [make_pair(n, 800 + b, 3) for b in range(P)]
+    data = {k: torch.from_numpy(np.concatenate([r[k] for r in raws])).cuda() for k in ("points_src", "points_ref")}
+    data["transform_gt"] = torch.from_numpy(np.concatenate([r["transform_gt"] for r in raws]).astype(np.float32)).cuda()
+    if pipeline == "feat":
+        data["transform_gt"][:, :, 3] += 2e-3
+    if pipeline == "label":
+        g = torch.Generator().manual_seed(2)
+        data["labels_src"], data["labels_ref"] = (torch.randint(0, 20, (P, n), generator=g) for _ in range(2))
+    if pipeline == "align":
+        data["matches"] = [np.stack([np.arange(n), np.arange(n)], 1) for _ in range(P)]
+    key = {"align": "inlier_model.mlp_out.weight", "label": "feat_extractor.mlp_out.weight", "feat": "mlp_proj.0.weight"}[pipeline]
+    frozen = {"align": "feat_extractor.mlp_out.weight", "label": None, "feat": "feat_extractor.mlp_out.weight"}[pipeline]
+    before = {k: v.clone() for k, v in net.state_dict().items()}
+    losses = [net.train_step(data, (3, False), lr=2e-3, dropout_seed=i)["loss"] for i in range(6)]
+    assert np.isfinite(losses).all() and losses[-1] < losses[0], losses
+    after = net.state_dict()
+    assert not torch.equal(after[key], before[key])
+    if frozen:
+        assert torch.equal(after[frozen], before[frozen])
+    out = net(data, (3, False))                                                     # inference with the trained weights
+    assert out[1] is not None
