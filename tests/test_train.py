@@ -109,6 +109,18 @@ def test_semantic_class_weights_are_the_references():
     assert abs(float(otrain.semantic_loss(lg, lb, semantic_class_weights())) - float(want)) < 1e-5
 
 
+def test_training_has_no_cpu_path():
+    """The training operators are HIP kernels: building a trainer on the CPU fails loudly (no autograd fallback)."""
+    from deepsir_amd.train import AggregationTrainer, RandlaTrainer
+    sd = generate_state_dict(CFG, 1, "plain")
+    with pytest.raises(RuntimeError, match="needs a GPU"):
+        RandlaTrainer(CFG, sd, "inlier_model", 6, 1, "cpu")
+    with pytest.raises(RuntimeError, match="needs a GPU"):
+        AggregationTrainer(CFG, sd, "cpu")
+    lib = __import__("deepsir_amd._lib", fromlist=["load"]).load()
+    assert lib.dsir_t_gemm(None, None, 0, None, 0, 0, None, None, 0, 0, 0, 0, 0.0) != 0          # argument validation, no launch
+
+
 # ------------------------------------------------------------------------------------------------- GPU
 def _dev():
     return torch.device("cuda:0")
