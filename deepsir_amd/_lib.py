@@ -139,6 +139,7 @@ SYMBOLS = {
     "dsir_t_add_leaky_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "dsir_t_add_leaky_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "dsir_t_mul_mask": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int64, C.c_void_p]),
+    "dsir_t_sigmoid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "dsir_t_axpy": (C.c_int, [C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]),
     "dsir_t_any_nan": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "dsir_t_adam": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float,

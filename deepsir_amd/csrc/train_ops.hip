@@ -439,6 +439,9 @@ __global__ void t_mul_mask_kernel(const float* __restrict__ x, const uint8_t* __
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
     y[e] = mask[e] ? x[e] * scale : 0.f;
 }
+__global__ void t_sigmoid_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ y) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) y[e] = 1.f / (1.f + expf(-x[e]));
+}
 __global__ void t_axpy_kernel(float a, const float* __restrict__ x, int64_t n, float* __restrict__ y) {
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) y[e] += a * x[e];
 }
@@ -1003,6 +1006,12 @@ int dsir_t_add_leaky_bwd(void* stream, const float* dOut, const float* out, int6
 int dsir_t_mul_mask(void* stream, const float* x, const uint8_t* mask, float scale, int64_t n, float* y) {
   if (!x || !mask || !y || n < 1) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(t_mul_mask_kernel, dim3(grid1(n)), dim3(256), 0, (hipStream_t)stream, x, mask, scale, n, y);
+  return done();
+}
+
+int dsir_t_sigmoid(void* stream, const float* x, int64_t n, float* y) {
+  if (!x || !y || n < 1) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(t_sigmoid_kernel, dim3(grid1(n)), dim3(256), 0, (hipStream_t)stream, x, n, y);
   return done();
 }
 

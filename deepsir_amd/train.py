@@ -222,6 +222,11 @@ class _Ops:
                                               _ptr(d_src), _ptr(sc)), "dsir_t_det_des_loss")
         return out, d_ref, d_src
 
+    def sigmoid(self, x: torch.Tensor) -> torch.Tensor:
+        y = torch.empty_like(x)
+        self._ok(self.lib.dsir_t_sigmoid(self.stream, _ptr(x), x.numel(), _ptr(y)), "dsir_t_sigmoid")
+        return y
+
     def acc(self, dst: Optional[torch.Tensor], src: torch.Tensor) -> torch.Tensor:
         """dst += src (dst None: a private copy of src)."""
         src = src.contiguous()
@@ -553,6 +558,67 @@ class RandlaTrainer(_ParamStore):
                 self._mlp2d_bwd(tape, pf + ".mlp_pre", dfeat.reshape(clouds * N, -1), need_dx=False)
 
 
+def forward_align_train(engine, inlier: RandlaTrainer, extractor: RandlaTrainer, aggregation: "AggregationTrainer", batch: dict,
+                        n_iter: int, masks: Optional[dict] = None) -> dict:
+    """``forward_align_4`` (network/model.py:520-607) as the reference's training loop runs it: ``my_model.train()`` (train.py:379)
+    puts EVERY BatchNorm on batch statistics (and keeps updating its running statistics) and every Dropout on - also in the
+    sub-networks the `align` pipeline freezes.  So the frozen half is run here in training mode too: the feature extractor by
+    ``extractor.forward`` (src, then ref), the key-point score by the engine's score operator, ``aggregation.forward`` for
+    src and ref in EVERY iteration (model.py:552), the arg-min and the weighted Kabsch step by the engine's operators, the
+    inlier model by ``inlier.forward`` with its tape kept.  masks: {'fe_src', 'fe_ref': [P][N][64] uint8, 'inlier': [n_iter][P][N][64]}
+    Dropout keep flags (None: dropout off).
+    -> idx [n_iter][P][J] i32, logits [n_iter][P][J], tapes, xyz_src / xyz_ref [P][.][3] (for the loss)."""
+    o = inlier.ops
+    masks = masks or {}
+    side = {}
+    for s_ in ("src", "ref"):
+        pts = batch[f"points_{s_}"].contiguous()
+        logits, tape = extractor.forward(pts, batch[f"{s_}_xyz"], batch[f"{s_}_neigh"], batch[f"{s_}_sub"], batch[f"{s_}_interp"],
+                                         masks.get(f"fe_{s_}"))
+        feat = tape.misc["feat"].contiguous()
+        score, _label = engine.score(feat, logits.contiguous(), batch[f"{s_}_xyz"], batch[f"{s_}_neigh"])
+        side[s_] = (pts[:, :, :3].contiguous(), feat, score)
+    xyz0, f_s, sc_s = side["src"]
+    xyz_r, f_r, sc_r = side["ref"]
+    P, J, _ = xyz0.shape
+    idxs, logits, tapes = [], [], []
+    cur = xyz0
+    for it in range(n_iter):
+        d_s, _ = aggregation.forward(cur, f_s, sc_s, second_normalize=False)
+        d_r, _ = aggregation.forward(xyz_r, f_r, sc_r, second_normalize=False)
+        idx = engine.nn_match(d_s.contiguous(), d_r.contiguous())
+        cat = o.inlier_input(cur, xyz_r, idx, None)
+        m = masks.get("inlier")
+        lg, tape = inlier.forward(cat, batch["src_xyz"], batch["src_neigh"], batch["src_sub"], batch["src_interp"], None if m is None else m[it])
+        lg = lg.reshape(P, J)
+        T_it, _bad = engine.kabsch(cur, cat[:, :, 3:].contiguous(), o.sigmoid(lg.contiguous()))
+        cur = o.inlier_input(cur, xyz_r, idx, T_it)[:, :, :3].contiguous()        # xyz_src <- R_t.detach() xyz_src (model.py:587)
+        idxs.append(idx); logits.append(lg); tapes.append(tape)
+    return {"idx": torch.stack(idxs).contiguous(), "logits": torch.stack(logits).contiguous(), "tapes": tapes, "xyz_src": xyz0,
+            "xyz_ref": xyz_r}
+
+
+def train_step_align_full(engine, inlier: RandlaTrainer, extractor: RandlaTrainer, aggregation: "AggregationTrainer", batch: dict,
+                          transform_gt, n_iter: int, labels_fn=None, lr: float = 1e-3, masks: Optional[dict] = None,
+                          loss_kwargs: Optional[dict] = None, apply: bool = True, dist=None) -> dict:
+    """One optimisation step of the `align` pipeline with the WHOLE network in training mode, as train.py:379-448 runs it
+    (``forward_align_train``): only the inlier model receives gradients and is updated (model.py:136, :182), but the frozen
+    sub-networks' BatchNorm running statistics move, as they do in the reference.  labels_fn(idx) -> [n_iter][P][J] float 0/1
+    (``find_correct_correspondence``) or None: no confidence term."""
+    inlier.zero_grad()
+    fw = forward_align_train(engine, inlier, extractor, aggregation, batch, n_iter, masks)
+    labels = None if labels_fn is None else labels_fn(fw["idx"])
+    out = engine.align_loss_backward(fw["xyz_src"], fw["xyz_ref"], fw["idx"], fw["logits"], labels, transform_gt, **(loss_kwargs or {}))
+    for it in range(n_iter):
+        inlier.backward(fw["tapes"][it], out["grad_logits"][it])
+    all_reduce_gradients(inlier, dist)
+    bad = inlier.grads_have_nan()
+    if apply and not bad:
+        inlier.adam_step(lr)
+    out.update(logits=fw["logits"], idx=fw["idx"], skipped=bad)
+    return out
+
+
 def train_step_align(engine, trainer: RandlaTrainer, batch: dict, result: dict, transform_gt: np.ndarray,
                      labels: Optional[np.ndarray] = None, lr: float = 1e-3, dropout_seed: Optional[int] = None,
                      loss_kwargs: Optional[dict] = None, apply: bool = True, dist=None) -> dict:
@@ -625,8 +691,10 @@ class AggregationTrainer(_ParamStore):
         fcfg = NetConfig(**{**cfg.__dict__, "pipeline": "feat"})
         self._build_store([sp for sp in network_specs(fcfg) if sp.name.startswith(("mlp_feat.", "mlp_att.", "mlp_proj."))], state_dict)
 
-    def forward(self, xyz: torch.Tensor, feat0: torch.Tensor, score: torch.Tensor, update_running_stats: bool = True):
-        """One side of ``Network.aggregation`` (model.py:209-235) + forward_pair's second F.normalize (:651-652), all clouds of
+    def forward(self, xyz: torch.Tensor, feat0: torch.Tensor, score: torch.Tensor, update_running_stats: bool = True,
+                second_normalize: bool = True):
+        """One side of ``Network.aggregation`` (model.py:209-235) + forward_pair's second F.normalize (:651-652; not in the
+        `align` pipeline, which matches on aggregation's own output: ``second_normalize=False``), all clouds of
         the batch in one call (BatchNorm statistics over batch x points, as the reference's).  xyz [P][M][3], feat0 [P][M][64]
         (the frozen extractor's selected features), score [P][M] -> descriptors [P][M][64], tape."""
         o = self.ops
@@ -641,6 +709,9 @@ class AggregationTrainer(_ParamStore):
         o.axpy(1.0, b, a)                                                  # feat + xyz_g (model.py:226-227)
         e = self._mlp1d(tape["p"], "mlp_proj", a, 1, update_running_stats)
         n1, r1 = o.l2norm_fwd(e)
+        if not second_normalize:
+            tape["norm"] = (n1, r1, None, None)
+            return n1.reshape(P, M, C_), tape
         n2, r2 = o.l2norm_fwd(n1)
         tape["norm"] = (n1, r1, n2, r2)
         return n2.reshape(P, M, C_), tape
@@ -650,7 +721,9 @@ class AggregationTrainer(_ParamStore):
         o.begin()
         P, M, C_ = tape["shape"]
         n1, r1, n2, r2 = tape["norm"]
-        d = o.l2norm_bwd(ddesc.reshape(P * M, C_).contiguous(), n2, r2)
+        d = ddesc.reshape(P * M, C_).contiguous()
+        if n2 is not None:
+            d = o.l2norm_bwd(d, n2, r2)
         d = o.l2norm_bwd(d, n1, r1)
         d = self._mlp1d_bwd(tape["p"], d)
         self._mlp1d_bwd(tape["f"], d, need_dx=False)                        # inputs come from the frozen extractor

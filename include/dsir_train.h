@@ -110,6 +110,8 @@ int dsir_t_add_leaky_bwd(void* stream, const float* dOut, const float* out, int6
 
 /* nn.Dropout (RandLANet.py:366) with the mask supplied: y = x * mask * scale (forward and backward alike). */
 int dsir_t_mul_mask(void* stream, const float* x, const uint8_t* mask, float scale, int64_t n, float* y);
+/* logit.sigmoid() (model.py:577): the correspondence weights of the weighted Kabsch step */
+int dsir_t_sigmoid(void* stream, const float* x, int64_t n, float* y);
 /* y += a x */
 int dsir_t_axpy(void* stream, float a, const float* x, int64_t n, float* y);
 

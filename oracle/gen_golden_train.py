@@ -155,6 +155,53 @@ def main(ref_root="/root/reference"):
             out["feat_buf_" + k] = b.detach().numpy().copy()
     print(f"feat case: loss {float(loss):.5f} acc {float(acc):.2f}, params with gradient: {sum(p.grad is not None for p in fnet.parameters())}")
 
+    # ---- `align` pipeline, the whole training forward as train.py runs it (my_model.train(): BatchNorm on batch statistics and
+    # Dropout on in the frozen sub-networks too), ScanAlignmentLoss without the confidence term, backward
+    from network.loss import ScanAlignmentLoss  # noqa: F401  type: ignore
+    aargs = arguments.eval_arguments().parse_args([])
+    aargs.pipeline, aargs.feat_len, aargs.num_sub = "align", 3, -1
+    anet = ref_model.Network(aargs)
+    acfg = NetConfig(feat_len=3)
+    anet.load_state_dict(to_torch_state_dict(generate_state_dict(acfg, 33, "separated")), strict=True)
+    anet.train()
+    n_it = 2
+    araws = [add_pyramids(make_pair(1024, 900 + b, 3), acfg.num_knn, acfg.sub_sampling_ratio) for b in range(2)]
+    ad = to_torch({k: np.concatenate([r[k] for r in araws], 0) for k in araws[0]})
+    keeps = {"fe": [], "inl": []}
+    h1 = anet.feat_extractor.dropout.register_forward_hook(lambda m_, i, o_: keeps["fe"].append((o_ != 0).detach().clone()))
+    h2 = anet.inlier_model.dropout.register_forward_hook(lambda m_, i, o_: keeps["inl"].append((o_ != 0).detach().clone()))
+    torch.manual_seed(4242)
+    orig_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a_, **k_: self
+    try:
+        tfs, aep = anet(ad, (n_it, False))
+        aep["transform_gt"], aep["transform_pred"] = ad["transform_gt"], tfs
+        aloss = anet.loss_align_fun(aep, reduction="mean")["total"]
+        aloss.backward()
+    finally:
+        torch.Tensor.cuda = orig_cuda
+    h1.remove(); h2.remove()
+    assert len(keeps["fe"]) == 2 and len(keeps["inl"]) == n_it
+    out["align_meta"] = np.array(json.dumps(dict(n=1024, seeds=[900, 901], wseed=33, variant="separated", n_iter=n_it)))
+    out["align_keep_fe"] = np.stack([np.packbits(k.numpy().astype(np.uint8)) for k in keeps["fe"]])
+    out["align_keep_inl"] = np.stack([np.packbits(k.numpy().astype(np.uint8)) for k in keeps["inl"]])
+    out["align_idx"] = np.stack([p_[:, :, 1].numpy() for p_ in aep["pred_pairs"]]).astype(np.int16)
+    out["align_logits"] = np.stack([l_.detach().numpy() for l_ in aep["perm_matrices"]])
+    out["align_transforms"] = np.stack([t_.detach().numpy() for t_ in tfs], 1)
+    out["align_loss"] = np.array(float(aloss))
+    for k, p_ in anet.named_parameters():
+        if p_.grad is None:
+            continue
+        g = p_.grad.detach().numpy().reshape(-1)
+        if g.size <= FULL_MAX:
+            out["align_g_" + k] = g.astype(np.float32)
+        else:
+            out["align_g_" + k + "_samples"] = g[sample_index(k, g.size, 33)].astype(np.float32)
+    for k, b_ in anet.named_buffers():
+        if k.endswith(("running_mean", "running_var")):
+            out["align_buf_" + k] = b_.detach().numpy().copy()
+    print(f"align case: loss {float(aloss):.5f}, tensors with gradient: {sum(p_.grad is not None for p_ in anet.parameters())}")
+
     # the constants of the `label` pipeline's loss (SemanticLoss.get_class_weights, loss.py:896-912); the loss itself cannot be
     # run under this image's torch (a [1, C] weight tensor is rejected by F.cross_entropy) - see oracle/train.py
     from network.loss import SemanticLoss  # type: ignore

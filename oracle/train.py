@@ -47,8 +47,9 @@ def fc_label_train(net: OracleNet, prefix: str, x: torch.Tensor, update_running:
 
 def randla_train(net: OracleNet, prefix: str, features: torch.Tensor, xyz_multi: torch.Tensor, neigh_idx: torch.Tensor,
                  sub_idx: torch.Tensor, interp_idx: torch.Tensor, keep_mask: Optional[torch.Tensor] = None,
-                 update_running: bool = True) -> torch.Tensor:
-    """RandLA.forward in training mode -> logits [B, ncls, N].  keep_mask [B, 64, N] bool (None: dropout off)."""
+                 update_running: bool = True, return_feat: bool = False):
+    """RandLA.forward in training mode -> logits [B, ncls, N] (and the 64-d features before the dropout when asked).
+    keep_mask [B, 64, N] bool (None: dropout off)."""
     L = len(net.cfg.d_out)
     N = features.shape[1]
     n = level_sizes(N, net.cfg.sub_sampling_ratio)
@@ -70,9 +71,9 @@ def randla_train(net: OracleNet, prefix: str, features: torch.Tensor, xyz_multi:
         up = _gather_pts(x.squeeze(3), interp_idx[:, a:b, 0]).unsqueeze(3)
         x = net.mlp2d(f"{prefix}.decoder_blocks.{j}", torch.cat([skips[-j - 2], up], dim=1))
     feat = F.conv2d(x, net.p[prefix + ".mlp_out.weight"]).squeeze(3)
-    if keep_mask is not None:
-        feat = feat * keep_mask.to(feat.dtype) * 2.0          # nn.Dropout(0.5) with its mask made explicit
-    return fc_label_train(net, prefix + ".fc_label", feat, update_running)
+    dropped = feat if keep_mask is None else feat * keep_mask.to(feat.dtype) * 2.0   # nn.Dropout(0.5) with its mask made explicit
+    logits = fc_label_train(net, prefix + ".fc_label", dropped, update_running)
+    return (logits, feat) if return_feat else logits
 
 
 def adam_reference(params: Dict[str, torch.Tensor], lr: float = 1e-3) -> torch.optim.Adam:
@@ -155,3 +156,50 @@ def det_des_loss(feat_src, feat_ref, pt_src, pt_ref, score_ref, transform_gt, th
     accuracy = (diff < 0).sum() * 100.0 / diff.shape[1]
     loss_det = torch.mean(diff * anc_score)
     return loss_feat + loss_det * det_loss_weight, accuracy
+
+
+def register_train(net: OracleNet, data: Dict[str, torch.Tensor], n_iter: int, masks: Optional[dict] = None):
+    """forward_align_4 (model.py:520-607) with the whole network in training mode, as train.py:379 runs it: BatchNorm on batch
+    statistics and Dropout on in the frozen sub-networks as well.  masks: {'fe_src', 'fe_ref': [B,64,N] bool,
+    'inlier': list of n_iter [B,64,N] bool} (None entries: dropout off).  -> (cumulative transforms, idx list, logits list)."""
+    masks = masks or {}
+    side = {}
+    for s_ in ("src", "ref"):
+        k = "points_" + s_
+        with torch.no_grad():                                                                # requires_grad False (freeze_model)
+            logits, feat = randla_train(net, "feat_extractor", data[k], data[k + "_xyz"], data[k + "_neigh_idx"], data[k + "_sub_idx"],
+                                        data[k + "_interp_idx"], masks.get("fe_" + s_), True, True)
+            prob, label = torch.max(logits, dim=1, keepdim=True)
+            N = data[k].shape[1]
+            xyz = data[k + "_xyz"].permute(0, 2, 1)[:, :, :N].contiguous()
+            score = net.score(feat, xyz, prob, label, data[k + "_neigh_idx"][:, :N])
+        side[s_] = (xyz, feat, score)
+    x_s, f_s, sc_s = side["src"]
+    x_r, f_r, sc_r = side["ref"]
+    xyz = x_s
+    transforms, idxs, lgs = [], [], []
+    for it in range(n_iter):
+        with torch.no_grad():
+            # per module the src call precedes the ref call (model.py:217-224); aggregate_train keeps that order per module
+            d_s = aggregate_train_first(net, xyz, f_s, sc_s)
+            d_r = aggregate_train_first(net, x_r, f_r, sc_r)
+            idx = OracleNet.nn_match(d_s, d_r)
+        ref_new = torch.gather(x_r, 2, idx[:, None, :].expand(-1, 3, -1))
+        cat = torch.cat((xyz, ref_new), dim=1).permute(0, 2, 1).contiguous()
+        m = masks.get("inlier")
+        logit = randla_train(net, "inlier_model", cat, data["points_src_xyz"], data["points_src_neigh_idx"], data["points_src_sub_idx"],
+                             data["points_src_interp_idx"], None if m is None else m[it]).squeeze(1)
+        p_s, p_r = xyz.permute(0, 2, 1).contiguous(), ref_new.permute(0, 2, 1).contiguous()
+        T, _ = OracleNet.kabsch(p_s, p_r, logit.sigmoid()[:, :, None])
+        xyz = OracleNet.se3_apply(T.detach(), p_s).permute(0, 2, 1).contiguous()
+        transforms.append(T if it == 0 else OracleNet.se3_compose(T, transforms[-1]))
+        idxs.append(idx); lgs.append(logit)
+    return transforms, idxs, lgs
+
+
+def aggregate_train_first(net: OracleNet, xyz, feat0, score):
+    """``aggregation`` (model.py:209-235) for one side in training mode, WITHOUT forward_pair's second normalize (the align
+    pipeline matches on aggregation's own output, model.py:552-566)."""
+    g = torch.cat((xyz, score[:, None, :]), dim=1)
+    d = mlp1d_train(net, "mlp_feat", feat0, 3) + mlp1d_train(net, "mlp_att", g, 5)
+    return F.normalize(mlp1d_train(net, "mlp_proj", d, 1), p=2, dim=1)

@@ -659,11 +659,105 @@ def test_network_train_step_drop_in(pipeline):
     key = {"align": "inlier_model.mlp_out.weight", "label": "feat_extractor.mlp_out.weight", "feat": "mlp_proj.0.weight"}[pipeline]
     frozen = {"align": "feat_extractor.mlp_out.weight", "label": None, "feat": "feat_extractor.mlp_out.weight"}[pipeline]
     before = {k: v.clone() for k, v in net.state_dict().items()}
-    losses = [net.train_step(data, (3, False), lr=2e-3, dropout_seed=i)["loss"] for i in range(6)]
+    losses = [net.train_step(data, (3, False), lr=2e-3, dropout_seed=None if pipeline == "align" else i)["loss"] for i in range(6)]
     assert np.isfinite(losses).all() and losses[-1] < losses[0], losses
     after = net.state_dict()
     assert not torch.equal(after[key], before[key])
     if frozen:
         assert torch.equal(after[frozen], before[frozen])
+    if pipeline == "align":       # my_model.train(): the frozen sub-networks' BatchNorm running statistics move, their weights do not
+        assert not torch.equal(after["mlp_att.1.running_mean"], before["mlp_att.1.running_mean"])
+        assert torch.equal(after["mlp_att.0.weight"], before["mlp_att.0.weight"])
+        l2 = [net.train_step(data, (3, False), lr=2e-3, dropout_seed=i, frozen_mode="eval")["loss"] for i in range(2)]
+        assert np.isfinite(l2).all()
     out = net(data, (3, False))                                                     # inference with the trained weights
     assert out[1] is not None
+
+
+# ------------------------------------------------------------------------------------------------- `align`, whole network in training mode
+def _align_case():
+    from oracle.knn import add_pyramids
+    from deepsir_amd.synth import make_pair
+    meta = json.loads(str(GOLD["align_meta"]))
+    cfg = NetConfig(feat_len=3)
+    sd = generate_state_dict(cfg, meta["wseed"], meta["variant"])
+    raws = [add_pyramids(make_pair(meta["n"], s, 3), cfg.num_knn, cfg.sub_sampling_ratio) for s in meta["seeds"]]
+    d = {k: np.concatenate([r[k] for r in raws], 0) for k in raws[0]}
+    n, B = meta["n"], len(meta["seeds"])
+    unpack = lambda bits: np.unpackbits(bits)[: B * 64 * n].reshape(B, 64, n).astype(bool)
+    masks = {"fe_src": unpack(GOLD["align_keep_fe"][0]), "fe_ref": unpack(GOLD["align_keep_fe"][1]),
+             "inlier": [unpack(b) for b in GOLD["align_keep_inl"]]}
+    return meta, cfg, sd, d, masks
+
+
+def _check_align_grads(grads, rtol, atol):
+    n = 0
+    for name, g in grads.items():
+        if name.endswith(ZERO_BY_CONSTRUCTION):
+            continue
+        g = np.asarray(g, np.float64).reshape(-1)
+        key = "align_g_" + name
+        ref = GOLD[key].astype(np.float64) if key in GOLD else GOLD[key + "_samples"].astype(np.float64)
+        if key not in GOLD:
+            g = g[sample_index(name, g.size, 33)]
+        assert np.abs(g - ref).max() <= rtol * np.abs(ref).max() + atol, (name, float(np.abs(g - ref).max()), float(np.abs(ref).max()))
+        n += 1
+    assert n > 100
+
+
+def test_oracle_whole_network_training_forward_matches_reference():
+    """forward_align_4 with EVERY sub-network in training mode (my_model.train(), train.py:379), ScanAlignmentLoss, backward:
+    the oracle composition against the imported reference's own run - correspondences, logits, poses, loss, the gradient of all
+    155 inlier tensors and the running statistics of every BatchNorm (frozen sub-networks included)."""
+    from oracle import align_loss as oal
+    meta, cfg, sd, d, masks = _align_case()
+    net = OracleNet(cfg, sd)
+    params = otrain.trainable(net)
+    t = to_torch(d)
+    tm = {"fe_src": torch.from_numpy(masks["fe_src"]), "fe_ref": torch.from_numpy(masks["fe_ref"]),
+          "inlier": [torch.from_numpy(m) for m in masks["inlier"]]}
+    T, idx, lg = otrain.register_train(net, t, meta["n_iter"], tm)
+    assert np.array_equal(torch.stack(idx).numpy(), GOLD["align_idx"].astype(np.int64))
+    assert np.abs(torch.stack(lg).detach().numpy() - GOLD["align_logits"]).max() < 5e-5
+    assert np.abs(torch.stack(T, 1).detach().numpy() - GOLD["align_transforms"]).max() < 1e-5
+    loss = oal.scan_alignment_loss(t["points_src"][:, :, :3], T, t["transform_gt"], lg, None)["total"]
+    assert abs(float(loss.detach()) - float(GOLD["align_loss"])) < 1e-5
+    loss.backward()
+    _check_align_grads({k: v.grad.numpy() for k, v in params.items()}, 1e-3, 1e-8)
+    bufs = [k for k in GOLD.files if k.startswith("align_buf_")]
+    assert len(bufs) == 2 * (2 + 2 + 4 + 2)
+    for k in bufs:
+        assert np.allclose(net.p[k[len("align_buf_"):]].numpy(), GOLD[k], rtol=1e-4, atol=1e-6), k
+
+
+@pytest.mark.gpu
+def test_device_whole_network_training_step_matches_reference():
+    """`train_step_align_full` (whole network in training mode on the device: extractor, score, aggregation per iteration,
+    arg-min, inlier model, Kabsch, loss, backward) against the imported reference's own training forward / backward."""
+    from deepsir_amd.engine import Engine
+    from deepsir_amd.train import AggregationTrainer, RandlaTrainer, train_step_align_full
+    meta, cfg, sd, d, masks = _align_case()
+    n, P, n_iter = meta["n"], len(meta["seeds"]), meta["n_iter"]
+    eng = Engine(cfg, max_points=n, max_pairs=P)
+    eng.load_state_dict(sd)
+    f = lambda k, dt: torch.from_numpy(np.ascontiguousarray(d[k])).to(dt).to(_dev())
+    batch = {"points_src": f("points_src", torch.float32), "points_ref": f("points_ref", torch.float32)}
+    for s in ("src", "ref"):
+        batch[f"{s}_xyz"], batch[f"{s}_neigh"] = f(f"points_{s}_xyz", torch.float32), f(f"points_{s}_neigh_idx", torch.int32)
+        batch[f"{s}_sub"], batch[f"{s}_interp"] = f(f"points_{s}_sub_idx", torch.int32), f(f"points_{s}_interp_idx", torch.int32)
+    mk = lambda m: torch.from_numpy(np.ascontiguousarray(m.transpose(0, 2, 1))).to(torch.uint8).to(_dev())
+    dm = {"fe_src": mk(masks["fe_src"]), "fe_ref": mk(masks["fe_ref"]), "inlier": torch.stack([mk(m) for m in masks["inlier"]])}
+    inl = RandlaTrainer(cfg, sd, "inlier_model", 6, 1, _dev())
+    fe = RandlaTrainer(cfg, sd, "feat_extractor", cfg.feat_len, cfg.num_classes, _dev())
+    ag = AggregationTrainer(cfg, sd, _dev())
+    out = train_step_align_full(eng, inl, fe, ag, batch, f("transform_gt", torch.float32), n_iter, None, masks=dm, apply=False)
+    torch.cuda.synchronize()
+    agree = (out["idx"].cpu().numpy() == GOLD["align_idx"].astype(np.int32)).mean()
+    assert agree == 1.0, agree
+    assert np.abs(out["logits"].cpu().numpy() - GOLD["align_logits"]).max() < 2e-3
+    assert np.abs(out["transforms"].cpu().numpy() - GOLD["align_transforms"]).max() < 1e-4
+    assert abs(out["losses"]["total"] - float(GOLD["align_loss"])) < 1e-4
+    _check_align_grads({k: v.cpu().numpy() for k, v in inl.grads.items()}, 1e-2, 1e-7)
+    for tr in (inl, fe, ag):
+        for k, v in tr.buffers.items():
+            assert np.allclose(v.cpu().numpy(), GOLD["align_buf_" + k], rtol=1e-3, atol=1e-5), k
