@@ -139,6 +139,8 @@ SYMBOLS = {
     "dsir_t_add_leaky_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "dsir_t_add_leaky_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "dsir_t_mul_mask": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int64, C.c_void_p]),
+    "dsir_t_topk_scratch": (C.c_size_t, [C.c_int, C.c_int]),
+    "dsir_t_topk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dsir_t_sigmoid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "dsir_t_axpy": (C.c_int, [C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]),
     "dsir_t_any_nan": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),

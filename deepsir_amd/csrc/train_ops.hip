@@ -8,6 +8,7 @@
 
 #include "device_utils.h"
 #include "dsir_train.h"
+#include "kernels.h"
 
 namespace dsir {
 namespace {
@@ -1006,6 +1007,14 @@ int dsir_t_add_leaky_bwd(void* stream, const float* dOut, const float* out, int6
 int dsir_t_mul_mask(void* stream, const float* x, const uint8_t* mask, float scale, int64_t n, float* y) {
   if (!x || !mask || !y || n < 1) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(t_mul_mask_kernel, dim3(grid1(n)), dim3(256), 0, (hipStream_t)stream, x, mask, scale, n, y);
+  return done();
+}
+
+size_t dsir_t_topk_scratch(int clouds, int n) { return topk_scratch_bytes(clouds, n); }
+
+int dsir_t_topk(void* stream, const float* score, int clouds, int n, int k, int32_t* idx, float* score_out, void* scratch) {
+  if (!score || !idx || !score_out || !scratch || clouds < 1 || n < 1 || k < 1 || k > n) return (int)hipErrorInvalidValue;
+  if (int r = launch_topk(score, clouds, n, k, idx, score_out, scratch, (hipStream_t)stream)) return r;
   return done();
 }
 

@@ -141,7 +141,8 @@ class Network(nn.Module):
                  (``train_step_align_full``); 'eval': the frozen half from ONE inference pass of the engine (faster; the
                  correspondences are those of the evaluation-mode network);
           label: trains ``feat_extractor`` through SemanticLoss (data: labels_src / labels_ref [B,N] in 0..19);
-          feat:  trains ``mlp_feat`` / ``mlp_att`` / ``mlp_proj`` through DetDesLoss (data: transform_gt; needs num_sub > 0).
+          feat:  trains ``mlp_feat`` / ``mlp_att`` / ``mlp_proj`` through DetDesLoss (data: transform_gt; needs num_sub > 0); frozen_mode
+                 as for align: 'train' runs the frozen extractor in training mode, 'eval' takes the key points from the engine.
         The updated tensors are written back into this module's buffers (``state_dict()`` is the trained checkpoint) and
         serve the next ``forward``.  Adam state lives in the trainer kept on the module.  Returns the step's dict (loss ...)."""
         from . import train as T
@@ -196,7 +197,17 @@ class Network(nn.Module):
         else:
             if self.cfg.num_sub <= 0:
                 raise EngineError("pipeline='feat' trains on the top-num_sub key points: set args.num_sub > 0")
-            inp = T.feat_pipeline_inputs(eng, batch, self.cfg.num_sub)
+            if frozen_mode == "train":      # the frozen extractor in training mode, as my_model.train() leaves it
+                if getattr(self, "_frozen_trainers", None) is None:
+                    self._frozen_trainers = (T.RandlaTrainer(self.cfg, sd, "feat_extractor", self.cfg.feat_len, self.cfg.num_classes, dev),)
+                masks = None
+                if dropout_seed is not None:
+                    g = torch.Generator(device=dev).manual_seed(int(dropout_seed))
+                    masks = {f"fe_{s_}": (torch.rand(B, n_, 64, generator=g, device=dev) >= 0.5).to(torch.uint8)
+                             for s_, n_ in (("src", J), ("ref", ref.shape[1]))}
+                inp = T.feat_pipeline_inputs_train(eng, self._frozen_trainers[0], batch, self.cfg.num_sub, masks)
+            else:
+                inp = T.feat_pipeline_inputs(eng, batch, self.cfg.num_sub)
             out = T.train_step_feat(tr, inp, data["transform_gt"].float().to(dev), thres_radius, det_loss_weight, lr, dist=dist)
         if not out.get("skipped", False):
             new = tr.state_dict()

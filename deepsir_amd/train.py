@@ -222,6 +222,14 @@ class _Ops:
                                               _ptr(d_src), _ptr(sc)), "dsir_t_det_des_loss")
         return out, d_ref, d_src
 
+    def topk(self, score: torch.Tensor, k: int):
+        """score [clouds][n] -> (idx [clouds][k] int32, score [clouds][k]): torch.topk's selection (model.py:692)."""
+        clouds, n = score.shape
+        idx, out = self.empty(clouds, k, dtype=torch.int32), self.empty(clouds, k)
+        sc = self.scratch(self.lib.dsir_t_topk_scratch(clouds, n))
+        self._ok(self.lib.dsir_t_topk(self.stream, _ptr(score), clouds, n, k, _ptr(idx), _ptr(out), _ptr(sc)), "dsir_t_topk")
+        return idx, out
+
     def sigmoid(self, x: torch.Tensor) -> torch.Tensor:
         y = torch.empty_like(x)
         self._ok(self.lib.dsir_t_sigmoid(self.stream, _ptr(x), x.numel(), _ptr(y)), "dsir_t_sigmoid")
@@ -745,6 +753,31 @@ def feat_pipeline_inputs(engine, batch: dict, num_sub: int) -> dict:
         sel = ops.empty(P * M, feat.shape[2])
         ops.gather(feat, idx, sel, 0)
         out[f"xyz_{side}"], out[f"score_{side}"], out[f"feat_{side}"] = fp[side]["xyz"], fp[side]["score"], sel.reshape(P, M, -1)
+    return out
+
+
+def feat_pipeline_inputs_train(engine, extractor: RandlaTrainer, batch: dict, num_sub: int, masks: Optional[dict] = None) -> dict:
+    """The same hand-over with the frozen extractor in TRAINING mode, as train.py:379 leaves it (BatchNorm of its semantic head
+    on batch statistics, Dropout on: the labels behind the key-point scores are those of the training-mode head):
+    ``extractor.forward`` per side, the engine's score operator, top-``num_sub`` selection, gathers.  masks: {'fe_src', 'fe_ref'}
+    [P][N][64] uint8 keep flags or None."""
+    o = extractor.ops
+    masks = masks or {}
+    out = {}
+    for side in ("src", "ref"):
+        pts = batch[f"points_{side}"].contiguous()
+        logits, tape = extractor.forward(pts, batch[f"{side}_xyz"], batch[f"{side}_neigh"], batch[f"{side}_sub"], batch[f"{side}_interp"],
+                                         masks.get(f"fe_{side}"))
+        feat = tape.misc["feat"].contiguous()
+        score, _ = engine.score(feat, logits.contiguous(), batch[f"{side}_xyz"], batch[f"{side}_neigh"])
+        o.begin()
+        idx, sel_score = o.topk(score, num_sub)
+        P, M = idx.shape
+        sel_feat, sel_xyz = o.empty(P * M, feat.shape[2]), o.empty(P * M, 3)
+        o.gather(feat, idx, sel_feat, 0)
+        o.gather(pts[:, :, :3].contiguous(), idx, sel_xyz, 0)
+        out[f"xyz_{side}"], out[f"score_{side}"], out[f"feat_{side}"] = sel_xyz.reshape(P, M, 3), sel_score, sel_feat.reshape(P, M, -1)
+        out[f"index_{side}"] = idx
     return out
 
 

@@ -110,6 +110,11 @@ int dsir_t_add_leaky_bwd(void* stream, const float* dOut, const float* out, int6
 
 /* nn.Dropout (RandLANet.py:366) with the mask supplied: y = x * mask * scale (forward and backward alike). */
 int dsir_t_mul_mask(void* stream, const float* x, const uint8_t* mask, float scale, int64_t n, float* y);
+/* torch.topk(score, k) of feat_score (model.py:692): the k best key points per cloud, descending score, equal scores in
+ * ascending index (csrc/select.hip, the operator dsir_forward_pair uses); idx [clouds][k], score_out [clouds][k]. */
+size_t dsir_t_topk_scratch(int clouds, int n);
+int dsir_t_topk(void* stream, const float* score, int clouds, int n, int k, int32_t* idx, float* score_out, void* scratch);
+
 /* logit.sigmoid() (model.py:577): the correspondence weights of the weighted Kabsch step */
 int dsir_t_sigmoid(void* stream, const float* x, int64_t n, float* y);
 /* y += a x */

@@ -127,8 +127,13 @@ def main(ref_root="/root/reference"):
     rec = {}
     orig = fnet.aggregation
     fnet.aggregation = lambda *a, **k: (rec.update(args=[x.detach().clone() if torch.is_tensor(x) else x for x in a]), orig(*a, **k))[1]
+    fkeeps = []
+    fh = fnet.feat_extractor.dropout.register_forward_hook(lambda m_, i, o_: fkeeps.append((o_ != 0).detach().clone()))
     torch.manual_seed(77)
     _, ep = fnet(fd, None)
+    fh.remove()
+    out["feat_keep_fe"] = np.stack([np.packbits(k_.numpy().astype(np.uint8)) for k_ in fkeeps])
+    out["feat_seeds"] = np.array([500, 501])
     ep["transform_gt"] = fd["transform_gt"]
     loss, acc = fnet.loss_feat_fun(ep)
     loss.backward()

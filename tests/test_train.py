@@ -761,3 +761,42 @@ def test_device_whole_network_training_step_matches_reference():
     for tr in (inl, fe, ag):
         for k, v in tr.buffers.items():
             assert np.allclose(v.cpu().numpy(), GOLD["align_buf_" + k], rtol=1e-3, atol=1e-5), k
+
+
+@pytest.mark.gpu
+def test_feat_pipeline_front_end_in_training_mode_matches_reference():
+    """The frozen extractor as train.py leaves it (training mode: Dropout on, BatchNorm of the semantic head on batch
+    statistics) -> key-point scores -> top-num_sub selection: the key points, their raw features and scores handed to the
+    aggregation equal what the imported reference handed its own (the `feat_in_*` vectors of train_cases.npz)."""
+    from oracle.knn import add_pyramids
+    from deepsir_amd.engine import Engine
+    from deepsir_amd.synth import make_pair
+    from deepsir_amd.train import RandlaTrainer, feat_pipeline_inputs_train
+    meta, cfg, sd, t = _feat_case()
+    n, P, M = 1024, 2, meta["num_sub"]
+    raws = [add_pyramids(make_pair(n, int(s), 3), cfg.num_knn, cfg.sub_sampling_ratio) for s in GOLD["feat_seeds"]]
+    d = {k: np.concatenate([r[k] for r in raws], 0) for k in raws[0]}
+    eng = Engine(cfg, max_points=n, max_pairs=P)
+    eng.load_state_dict(sd)
+    f = lambda k, dt: torch.from_numpy(np.ascontiguousarray(d[k])).to(dt).to(_dev())
+    batch = {"points_src": f("points_src", torch.float32), "points_ref": f("points_ref", torch.float32)}
+    for s in ("src", "ref"):
+        batch[f"{s}_xyz"], batch[f"{s}_neigh"] = f(f"points_{s}_xyz", torch.float32), f(f"points_{s}_neigh_idx", torch.int32)
+        batch[f"{s}_sub"], batch[f"{s}_interp"] = f(f"points_{s}_sub_idx", torch.int32), f(f"points_{s}_interp_idx", torch.int32)
+    unpack = lambda bits: torch.from_numpy(np.ascontiguousarray(np.unpackbits(bits)[: P * 64 * n].reshape(P, 64, n).transpose(0, 2, 1))).to(_dev())
+    masks = {"fe_src": unpack(GOLD["feat_keep_fe"][0]), "fe_ref": unpack(GOLD["feat_keep_fe"][1])}
+    fe = RandlaTrainer(cfg, sd, "feat_extractor", cfg.feat_len, cfg.num_classes, _dev())
+    inp = feat_pipeline_inputs_train(eng, fe, batch, M, masks)
+    torch.cuda.synchronize()
+    for s in ("src", "ref"):
+        want_score = GOLD[f"feat_in_score_{s}"]
+        got_score = inp[f"score_{s}"].cpu().numpy()
+        assert np.abs(got_score - want_score).max() < 1e-4
+        clear = np.ones_like(want_score, bool)                       # entries whose rank is not decided by a rounding-level score gap
+        clear[:, 1:] &= (want_score[:, :-1] - want_score[:, 1:]) > 1e-5
+        clear[:, :-1] &= (want_score[:, :-1] - want_score[:, 1:]) > 1e-5
+        assert clear.mean() > 0.8
+        got_xyz, want_xyz = inp[f"xyz_{s}"].cpu().numpy(), GOLD[f"feat_in_xyz_{s}"].transpose(0, 2, 1)
+        assert np.abs(got_xyz - want_xyz)[clear].max() == 0.0        # the same key points in the same order
+        got_f, want_f = inp[f"feat_{s}"].cpu().numpy(), GOLD[f"feat_in_feat_{s}"].transpose(0, 2, 1)
+        assert np.abs(got_f - want_f)[clear].max() < 1e-3
