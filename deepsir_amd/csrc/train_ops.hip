@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <cmath>
+#include <cstdlib>
 
 #include "device_utils.h"
 #include "dsir_train.h"
