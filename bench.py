@@ -295,7 +295,7 @@ def main():
     screened = sstats["screened_searches"] > 0
 
     # ------------------------------------------------------------------ rank-0 extras (outside the timed region)
-    model_only = single = single_ex = companion = latency = None
+    model_only = single = single_ex = companion = latency = training = None
     checks = []
     if a.timed_only:
         a.no_cpu_baseline = a.no_latency = a.no_companion = True
@@ -380,6 +380,36 @@ def main():
             eng.enable_graph(False)
             latency = {"pairs_in_flight": 1, "ms_per_pair": round(ms, 4), "pairs_per_s": round(1e3 / ms, 2), "hipgraph": True,
                        "note": "the reference's own evaluation mode (test.py:56 BATCH_SIZE = 1, BASELINE configs[1] 'batch=1')"}
+
+        # the training step of the same pipeline, reported beside the headline, never as `value`
+        if world == 1 and not a.no_latency and not a.no_companion and N <= 16384:
+            try:
+                from deepsir_amd.train import AlignTrainStep, RandlaTrainer
+                tp = min(8, P)
+                teng = Engine(cfg, dev_index, max_points=N, max_pairs=tp)
+                teng.load_state_dict(sd)
+                ts, trf = src[:tp].contiguous(), ref[:tp].contiguous()
+                tgt = torch.from_numpy(np.ascontiguousarray(batch["transform_gt"][:tp], dtype=np.float32)).to(dev)
+                sx, sn, ss, si = teng.knn_pyramid(ts)
+                tb = {"points_src": ts, "points_ref": trf, "src_xyz": sx, "src_neigh": sn, "src_sub": ss, "src_interp": si}
+                trn = RandlaTrainer(cfg, sd, "inlier_model", 6, 1, dev)
+                stepper = AlignTrainStep(teng, trn, tp, N, N, n_iter)
+                tres = teng.register(ts, trf, n_iter)
+                tl = []
+                for s_ in range(5):
+                    if s_ == 2:
+                        torch.cuda.synchronize(); t1 = time.perf_counter()
+                    tl.append(stepper.step(tb, tres, tgt, lr=1e-3, dropout_seed=s_)["losses"]["total"])
+                torch.cuda.synchronize()
+                tms = (time.perf_counter() - t1) / 3 * 1e3
+                training = {"pipeline": "align", "pairs": tp, "ms_per_step": round(tms, 2), "pairs_per_s": round(tp / tms * 1e3, 1),
+                            "loss_first_last": [round(tl[0], 5), round(tl[-1], 5)],
+                            "note": "one optimisation step of the inlier model without autograd: n_iter training-mode forwards, "
+                                    "ScanAlignmentLoss + gradient, n_iter backwards, Adam (deepsir_amd/train.py; hipGraph replay); "
+                                    "frozen half from one inference pass"}
+                teng.close()
+            except Exception as e:  # the headline must not depend on the companion
+                training = {"error": f"{type(e).__name__}: {e}"[:300]}
 
         # parity of what was just measured: the benchmarked configuration once more with the aux outputs, two pairs
         # (first stream's first, last stream's last) handed to the CPU oracle in cpu_leg
@@ -495,6 +525,8 @@ def main():
             line["model_only"] = model_only
         if latency is not None:
             line["batch1_latency"] = latency
+        if training is not None:
+            line["training_step"] = training
         if world == 1 and not a.no_cpu_baseline:
             base, parity = cpu_leg(cfg, sd, N, n_iter, checks)
             line["cpu_baseline"] = base
