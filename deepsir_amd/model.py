@@ -67,6 +67,7 @@ class Network(nn.Module):
     def load_state_dict(self, state_dict, strict: bool = True):
         r = super().load_state_dict(state_dict, strict=strict)
         self._dirty = True
+        self._trainer = self._frozen_trainers = self._stepper = self._stepper_key = None     # they hold the previous weights
         return r
 
     def _device_index(self) -> int:
@@ -189,7 +190,10 @@ class Network(nn.Module):
             labels = None
             if "matches" in data:
                 labels = torch.from_numpy(T.find_correct_correspondence(data["matches"], res["idx"], J)).to(dev)
-            out = T.train_step_align(eng, tr, batch, res, data["transform_gt"].float().to(dev), labels, lr, dropout_seed, loss_kwargs, dist=dist)
+            key = (id(eng), B, J, ref.shape[1], n_iter)
+            if getattr(self, "_stepper_key", None) != key:                      # hipGraph-replayed halves, fixed batch geometry
+                self._stepper, self._stepper_key = T.AlignTrainStep(eng, tr, B, J, ref.shape[1], n_iter), key
+            out = self._stepper.step(batch, res, data["transform_gt"].float().to(dev), labels, lr, dropout_seed, loss_kwargs, dist=dist)
             out["loss"] = out["losses"]["total"]
         elif self.pipeline == "label":
             out = T.train_step_label(tr, batch, data["labels_src"].to(torch.int32).to(dev), data["labels_ref"].to(torch.int32).to(dev), lr,
