@@ -14,7 +14,6 @@ gradients are keyed by the reference's state-dict names (deepsir_amd/arch.py).
 """
 from __future__ import annotations
 
-import ctypes as C
 from typing import Dict, List, Optional, Sequence
 
 import numpy as np

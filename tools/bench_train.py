@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from deepsir_amd.arch import NetConfig  # noqa: E402
 from deepsir_amd.engine import Engine  # noqa: E402
 from deepsir_amd.synth import make_pair  # noqa: E402
-from deepsir_amd.train import AggregationTrainer, AlignTrainStep, RandlaTrainer, train_step_align, train_step_align_full  # noqa: E402
+from deepsir_amd.train import AggregationTrainer, AlignTrainStep, RandlaTrainer, train_step_align_full  # noqa: E402
 from deepsir_amd.weights import generate_state_dict  # noqa: E402
 
 ap = argparse.ArgumentParser()
