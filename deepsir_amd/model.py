@@ -223,3 +223,40 @@ class Network(nn.Module):
                     own[k].copy_(torch.from_numpy(np.ascontiguousarray(v)).to(own[k].device))
             self._dirty = True
         return out
+
+    # ---- the optimiser's checkpoint entry (CheckPointManager saves optimizer.state_dict(), common/torch_utils.py:62-67)
+    def _param_order(self) -> List[str]:
+        """``my_model.parameters()`` order = the state-dict order without the buffers (train.py:323 hands it to Adam)."""
+        return [sp.name for sp in network_specs(self.cfg) if sp.kind not in ("bn_mean", "bn_var", "bn_count")]
+
+    def optimizer_state_dict(self, lr: float = 1e-3) -> dict:
+        """What ``torch.optim.Adam(my_model.parameters(), lr).state_dict()`` would hold after the steps taken through
+        ``train_step``: state entries (by parameter index) for the tensors that received gradients, one param group."""
+        order = self._param_order()
+        tr = getattr(self, "_trainer", None)
+        named = tr.adam_state() if tr is not None and tr.step_count > 0 else {}
+        state = {i: named[k] for i, k in enumerate(order) if k in named}
+        group = {"lr": lr, "betas": (0.9, 0.999), "eps": 1e-8, "weight_decay": 0, "amsgrad": False, "maximize": False, "foreach": None,
+                 "capturable": False, "differentiable": False, "fused": None, "params": list(range(len(order)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_optimizer_state_dict(self, sd: dict) -> None:
+        """Resume the device optimiser from a reference checkpoint's 'optimizer' entry (call after the first ``train_step`` built
+        the trainer, or after ``prepare_training``)."""
+        tr = getattr(self, "_trainer", None)
+        if tr is None:
+            raise EngineError("no trainer yet: call prepare_training(device) or train_step first")
+        order = self._param_order()
+        tr.load_adam_state({order[int(i)]: st for i, st in sd["state"].items()})
+
+    def prepare_training(self) -> None:
+        """Builds the pipeline's trainer from the current weights (train_step does it lazily)."""
+        from . import train as T
+        dev = next(self.buffers()).device
+        sd = self.state_dict()
+        if self.pipeline == "align":
+            self._trainer = T.RandlaTrainer(self.cfg, sd, "inlier_model", 6, 1, dev)
+        elif self.pipeline == "label":
+            self._trainer = T.RandlaTrainer(self.cfg, sd, "feat_extractor", self.cfg.feat_len, self.cfg.num_classes, dev)
+        else:
+            self._trainer = T.AggregationTrainer(self.cfg, sd, dev)

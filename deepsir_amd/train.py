@@ -282,9 +282,35 @@ class _ParamStore:
         view = lambda flat, k: flat[offsets[k]:offsets[k] + host[k].numel()].view(host[k].shape)
         self.params: Dict[str, torch.Tensor] = {k: view(self.flat_p, k) for k in host}
         self.grads: Dict[str, torch.Tensor] = {k: view(self.flat_g, k) for k in host}
+        self._moments = {k: (view(self.flat_m, k), view(self.flat_v, k)) for k in host}
         for k, t in host.items():
             self.params[k].copy_(t)
         self.step_count = 0
+
+    def adam_state(self) -> Dict[str, dict]:
+        """The optimiser state in torch.optim.Adam's terms, per parameter name: {'step', 'exp_avg', 'exp_avg_sq'} (host tensors
+        in the reference's shapes) - what ``optimizer.state_dict()['state']`` holds after the same steps (train.py:478)."""
+        out = {}
+        for k, (m, v) in self._moments.items():
+            shape = self._shapes[k]
+            out[k] = {"step": torch.tensor(float(self.step_count)), "exp_avg": m.detach().cpu().reshape(shape).clone(),
+                      "exp_avg_sq": v.detach().cpu().reshape(shape).clone()}
+        return out
+
+    def load_adam_state(self, state: Dict[str, dict]) -> None:
+        """Resume from torch.optim.Adam state entries keyed by parameter name (all entries must carry the same step)."""
+        steps = set()
+        for k, st in state.items():
+            if k not in self._moments:
+                continue
+            m, v = self._moments[k]
+            m.copy_(torch.as_tensor(st["exp_avg"]).reshape(m.shape))
+            v.copy_(torch.as_tensor(st["exp_avg_sq"]).reshape(v.shape))
+            steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError(f"parameters at different Adam steps {sorted(steps)}: one launch updates them all with one bias correction")
+        if steps:
+            self.step_count = steps.pop()
 
     def zero_grad(self) -> None:
         self.flat_g.zero_()

@@ -805,3 +805,56 @@ def test_feat_pipeline_front_end_in_training_mode_matches_reference():
         assert np.abs(got_xyz - want_xyz)[clear].max() == 0.0        # the same key points in the same order
         got_f, want_f = inp[f"feat_{s}"].cpu().numpy(), GOLD[f"feat_in_feat_{s}"].transpose(0, 2, 1)
         assert np.abs(got_f - want_f)[clear].max() < 1e-3
+
+
+@pytest.mark.gpu
+def test_optimizer_state_round_trips_with_torch_adam():
+    """The device optimiser's state in torch.optim.Adam's checkpoint format (what CheckPointManager saves): after the same
+    three steps on the same gradients it equals torch's (indices = my_model.parameters() order), and a torch state loaded
+    into the device trainer continues identically."""
+    from types import SimpleNamespace
+    from deepsir_amd.model import Network
+    from deepsir_amd.weights import to_torch_state_dict
+    net = Network(SimpleNamespace(pipeline="feat", feat_len=3, num_sub=256))
+    sd = generate_state_dict(net.cfg, 5, "separated")
+    net.load_state_dict(to_torch_state_dict(sd))
+    net.cuda()
+    net.prepare_training()
+    tr = net._trainer
+    order = net._param_order()
+    ref_params = [torch.nn.Parameter(torch.from_numpy(np.array(sd[k])).clone()) for k in order]
+    opt = torch.optim.Adam(ref_params, lr=2e-3)
+    g = torch.Generator().manual_seed(1)
+    trained = [i for i, k in enumerate(order) if k in tr.params]
+    for step in range(3):
+        tr.zero_grad()
+        for i in trained:
+            gr = torch.randn(ref_params[i].shape, generator=g)
+            ref_params[i].grad = gr.clone()
+            tr.grads[order[i]].copy_(gr.reshape(tr.grads[order[i]].shape).cuda())
+        opt.step()
+        tr.adam_step(2e-3)
+    mine, theirs = net.optimizer_state_dict(2e-3), opt.state_dict()
+    assert sorted(mine["state"]) == sorted(theirs["state"]) == trained
+    for i in trained:
+        for key in ("exp_avg", "exp_avg_sq"):
+            assert torch.allclose(mine["state"][i][key], theirs["state"][i][key], rtol=1e-4, atol=1e-6), (order[i], key)   # lerp vs mul-add rounding
+        assert float(mine["state"][i]["step"]) == float(theirs["state"][i]["step"]) == 3.0
+        assert torch.allclose(tr.params[order[i]].cpu().reshape(ref_params[i].shape), ref_params[i].detach(), rtol=1e-5, atol=2e-6)
+    # resume: a fresh trainer loaded with torch's state takes the same fourth step
+    net2 = Network(SimpleNamespace(pipeline="feat", feat_len=3, num_sub=256))
+    cur = {k: v for k, v in net.state_dict().items()}
+    for i in trained:
+        cur[order[i]] = ref_params[i].detach().clone()
+    net2.load_state_dict(cur)
+    net2.cuda()
+    net2.prepare_training()
+    net2.load_optimizer_state_dict(theirs)
+    for i in trained:
+        gr = torch.randn(ref_params[i].shape, generator=g)
+        ref_params[i].grad = gr.clone()
+        net2._trainer.grads[order[i]].copy_(gr.reshape(net2._trainer.grads[order[i]].shape).cuda())
+    opt.step()
+    net2._trainer.adam_step(2e-3)
+    for i in trained:
+        assert torch.allclose(net2._trainer.params[order[i]].cpu().reshape(ref_params[i].shape), ref_params[i].detach(), rtol=1e-5, atol=2e-6)
