@@ -89,6 +89,8 @@ struct dsir_ctx {
   Arena ws;
   double* stats = nullptr;   // GroupNorm statistics slots
   size_t stats_cap = 0, stats_top = 0;
+  size_t stats_base = 0;          // dsir_register: the passes of one call take consecutive regions of an arena zeroed ONCE
+  bool stats_prezeroed = false;
   // nn_match timing
   bool time_match = false;
   // hipGraph replay of dsir_register (launch-bound small batches)
@@ -459,11 +461,16 @@ int randla_forward(dsir_ctx* c, const RandlaW& w, const Seg& in0, const Seg* in1
   const int L = g.num_layers;
   hipStream_t st = c->stream;
   Sched s{c, st, py.clouds};
-  c->stats_top = 0;
   // 34 GroupNorm layers x clouds x <=8 groups x 2 doubles
   const size_t stats_need = (size_t)40 * py.clouds * 16;
-  if (stats_need > c->stats_cap) return fail(c, "stats arena too small (%zu > %zu)", stats_need, c->stats_cap);
-  HIP_OK(c, hipMemsetAsync(c->stats, 0, stats_need * sizeof(double), st));
+  if (c->stats_prezeroed && c->stats_base + stats_need <= c->stats_cap) {
+    c->stats_top = c->stats_base;               // zeroed by register_enqueue together with the other passes' regions
+    c->stats_base += stats_need;
+  } else {
+    c->stats_top = 0;
+    if (stats_need > c->stats_cap) return fail(c, "stats arena too small (%zu > %zu)", stats_need, c->stats_cap);
+    HIP_OK(c, hipMemsetAsync(c->stats, 0, stats_need * sizeof(double), st));
+  }
 
   const int64_t xyz_cs = (int64_t)py.S * 3, neigh_cs = (int64_t)py.S * kKnn, sub_cs = (int64_t)py.S1 * kKnn, interp_cs = py.S;
   Act x = s.mlp2d(w.pre, in0, in1, py.nl[0], true);
@@ -690,7 +697,7 @@ int dsir_create(int device, const dsir_cfg* cfg, dsir_ctx** out) {
     delete c;
     return fail(nullptr, "cannot allocate %zu MiB of workspace", cap >> 20);
   }
-  c->stats_cap = (size_t)40 * clouds * 16;
+  c->stats_cap = (size_t)40 * clouds * 16 * 6;   // one registration's passes side by side: (2 + n_iter) P clouds for n_iter <= 10
   if (hipMalloc((void**)&c->stats, c->stats_cap * sizeof(double)) != hipSuccess) {
     hipFree(c->ws.base); hipStreamDestroy(c->stream);
     delete c;
@@ -1023,6 +1030,17 @@ static int register_enqueue(dsir_ctx* c, const dsir_pair_batch* in, int n_iter, 
   Arena& ws = c->ws;
   PairStage S;
   if (out->invalid) HIP_OK(c, hipMemsetAsync(out->invalid, 0, sizeof(int32_t) * P, st));
+  // GroupNorm statistics of ALL passes of this call (feature extractor on 2 P clouds, n_iter inlier passes on P) zeroed by one
+  // memset instead of one per pass (a launch each: 22 us of a 3.6 ms single-pair registration)
+  struct StatsGuard { dsir_ctx* c; ~StatsGuard() { c->stats_prezeroed = false; c->stats_base = 0; } } stats_guard{c};
+  {
+    const size_t total = (size_t)40 * 16 * ((size_t)2 * P + (size_t)n_iter * P);
+    if (total <= c->stats_cap) {
+      HIP_OK(c, hipMemsetAsync(c->stats, 0, total * sizeof(double), st));
+      c->stats_prezeroed = true;
+      c->stats_base = 0;
+    }
+  }
   if (int r = forward_pair_stage(c, in, true, false, S, out->invalid)) return r;
   const Pyramid& ps = S.ps; const Pyramid& pr = S.pr;
   float *feat_s = S.feat_s, *feat_r = S.feat_r, *score_s = S.score_s, *score_r = S.score_r, *rxyz = S.rxyz;
