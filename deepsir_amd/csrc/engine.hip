@@ -133,6 +133,8 @@ int fail(dsir_ctx* c, const char* fmt, ...) {
     if (e__ != hipSuccess) return fail((c), "%s: %s", #expr, hipGetErrorString(e__));   \
   } while (0)
 
+static_assert(kMaxLevels == DSIR_MAX_LEVELS, "kernels.h and dsir.h disagree on the level count");
+
 void level_sizes(const dsir_cfg& cfg, int n, int* nl) {
   nl[0] = n;
   for (int l = 0; l < cfg.num_layers; ++l) nl[l + 1] = nl[l] / cfg.sub_sampling_ratio[l];
@@ -594,9 +596,12 @@ int build_pyramid(dsir_ctx* c, const float* points, int stride, int clouds, int 
                 p.nl[g.num_layers - 1], kKnn, kKnn * 64);
   hipStream_t st = c->stream;
   const int64_t xyz_cs = (int64_t)p.S * 3, neigh_cs = (int64_t)p.S * kKnn, sub_cs = (int64_t)p.S1 * kKnn;
+  PyramidLevels lv{};
+  lv.L = g.num_layers; lv.S = p.S; lv.S1 = p.S1;
+  for (int l = 0; l <= g.num_layers; ++l) { lv.nl[l] = p.nl[l]; lv.off[l] = p.off[l]; lv.soff[l] = p.soff[l]; }
+  // every level's points are a prefix of the level above, hence of the input cloud (data_base.py:166-172): one launch for all
+  launch_copy_xyz_levels(points, (int64_t)n * stride, stride, lv, clouds, xyz, xyz_cs, st);
   for (int l = 0; l < g.num_layers; ++l) {
-    // every level's points are a prefix of the level above, hence of the input cloud (data_base.py:166-172)
-    launch_copy_xyz(points, (int64_t)n * stride, stride, p.nl[l], clouds, xyz + (int64_t)p.off[l] * 3, xyz_cs, st);
     static const bool no_grid = getenv("DSIR_NO_GRID") != nullptr;   // A/B switch
     static const int grid_min = getenv("DSIR_GRID_MIN") ? atoi(getenv("DSIR_GRID_MIN")) : 1024;   // tuning hook
     if (p.nl[l] >= grid_min && !no_grid) {
@@ -610,10 +615,10 @@ int build_pyramid(dsir_ctx* c, const float* points, int stride, int clouds, int 
     } else {
       launch_knn16(points, (int64_t)n * stride, stride, p.nl[l], clouds, neigh + (int64_t)p.off[l] * kKnn, neigh_cs, st);
     }
-    launch_copy_rows_i32(neigh + (int64_t)p.off[l] * kKnn, neigh_cs, p.nl[l + 1], kKnn, clouds,
-                         sub + (int64_t)p.soff[l] * kKnn, sub_cs, st);
     launch_nn1(points, (int64_t)n * stride, stride, p.nl[l], p.nl[l + 1], clouds, interp + p.off[l], p.S, st);
   }
+  // sub_idx of level l = the neighbour lists of its first n_{l+1} points: all levels in one launch
+  launch_copy_sub_levels(neigh, neigh_cs, lv, clouds, sub, sub_cs, st);
   return 0;
 }
 

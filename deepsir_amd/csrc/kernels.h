@@ -158,6 +158,14 @@ void launch_nn1(const float* pts, int64_t cloud_stride, int stride, int n_query,
                 int32_t* out, int64_t out_cloud_stride, hipStream_t st);
 void launch_copy_xyz(const float* pts, int64_t cloud_stride, int stride, int n, int clouds, float* out,
                      int64_t out_cloud_stride, hipStream_t st);
+// all levels of a pyramid in one launch each (every level is a prefix of the level above, data_base.py:166-172):
+// xyz[off[l] + i] = points[i], i < nl[l];  sub[soff[l] + i] = neigh[off[l] + i], i < nl[l + 1]
+constexpr int kMaxLevels = 4;   // = DSIR_MAX_LEVELS (include/dsir.h)
+struct PyramidLevels { int L; int nl[kMaxLevels + 1]; int off[kMaxLevels + 1]; int soff[kMaxLevels + 1]; int S, S1; };
+void launch_copy_xyz_levels(const float* pts, int64_t cloud_stride, int stride, const PyramidLevels& lv, int clouds, float* xyz,
+                            int64_t xyz_cs, hipStream_t st);
+void launch_copy_sub_levels(const int32_t* neigh, int64_t neigh_cs, const PyramidLevels& lv, int clouds, int32_t* sub, int64_t sub_cs,
+                            hipStream_t st);
 void launch_copy_rows_i32(const int32_t* src, int64_t src_cloud_stride, int rows, int width, int clouds, int32_t* dst,
                           int64_t dst_cloud_stride, hipStream_t st);
 

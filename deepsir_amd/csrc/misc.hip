@@ -120,6 +120,30 @@ __global__ void copy_xyz_kernel(const float* __restrict__ pts, int64_t cs, int s
     out[cloud * ocs + e] = pts[cloud * cs + (int64_t)(e / 3) * stride + (e % 3)];
 }
 
+__global__ void copy_xyz_levels_kernel(const float* __restrict__ pts, int64_t cs, int stride, const PyramidLevels lv,
+                                       float* __restrict__ out, int64_t ocs) {
+  const int cloud = blockIdx.y;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < lv.S * 3; e += gridDim.x * blockDim.x) {
+    const int p = e / 3;
+    int l = 0;
+#pragma unroll
+    for (int k = 1; k < kMaxLevels; ++k) l += (k < lv.L && p >= lv.off[k]) ? 1 : 0;
+    out[cloud * ocs + e] = pts[cloud * cs + (int64_t)(p - lv.off[l]) * stride + (e % 3)];
+  }
+}
+
+__global__ void copy_sub_levels_kernel(const int32_t* __restrict__ neigh, int64_t ncs, const PyramidLevels lv,
+                                       int32_t* __restrict__ sub, int64_t scs) {
+  const int cloud = blockIdx.y;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < lv.S1 * kKnn; e += gridDim.x * blockDim.x) {
+    const int q = e / kKnn;
+    int l = 0;
+#pragma unroll
+    for (int k = 1; k < kMaxLevels; ++k) l += (k < lv.L && q >= lv.soff[k]) ? 1 : 0;
+    sub[cloud * scs + e] = neigh[cloud * ncs + (int64_t)(lv.off[l] + q - lv.soff[l]) * kKnn + (e % kKnn)];
+  }
+}
+
 __global__ void copy_rows_i32_kernel(const int32_t* __restrict__ src, int64_t scs, int count, int32_t* __restrict__ dst,
                                      int64_t dcs) {
   const int cloud = blockIdx.y;
@@ -201,6 +225,20 @@ void launch_copy_xyz(const float* pts, int64_t cs, int stride, int n, int clouds
                      hipStream_t st) {
   dim3 grid(grid_for((int64_t)n * 3), clouds);
   hipLaunchKernelGGL(copy_xyz_kernel, grid, dim3(256), 0, st, pts, cs, stride, n, out, ocs);
+}
+
+void launch_copy_xyz_levels(const float* pts, int64_t cs, int stride, const PyramidLevels& lv, int clouds, float* xyz, int64_t xyz_cs,
+                            hipStream_t st) {
+  if (clouds <= 0 || lv.S <= 0) return;
+  dim3 grid(grid_for((int64_t)lv.S * 3), clouds);
+  hipLaunchKernelGGL(copy_xyz_levels_kernel, grid, dim3(256), 0, st, pts, cs, stride, lv, xyz, xyz_cs);
+}
+
+void launch_copy_sub_levels(const int32_t* neigh, int64_t ncs, const PyramidLevels& lv, int clouds, int32_t* sub, int64_t scs,
+                            hipStream_t st) {
+  if (clouds <= 0 || lv.S1 <= 0) return;
+  dim3 grid(grid_for((int64_t)lv.S1 * kKnn), clouds);
+  hipLaunchKernelGGL(copy_sub_levels_kernel, grid, dim3(256), 0, st, neigh, ncs, lv, sub, scs);
 }
 
 void launch_copy_rows_i32(const int32_t* src, int64_t scs, int rows, int width, int clouds, int32_t* dst, int64_t dcs,
