@@ -242,11 +242,29 @@ static void launch_core(const float* a, const float* b, const float* sa, const f
   int splits = 1;
   double best_eff = -1.0;
   if (rowlist) { splits = tiles / 8 < 1 ? 1 : (tiles / 8 > 16 ? 16 : tiles / 8); best_eff = 2.0; }
+  // A launch that fits the chip in ONE residency round (a single pair: 79 row blocks) is bound by the CU that gets the most
+  // workgroups: its matrix pipe serves ceil(blocks / 256) of them, each tiles_per tiles long plus ~2 tiles' worth of
+  // prologue / epilogue; one or two workgroups per CU run no faster than three (their load latencies no longer overlap).  (Measured at 1 x 5000 x 5000:
+  // 9 splits 3.595 ms per registration, 10 splits - what the balance formula below picks - 3.627, 12: 3.60, 8: 3.613, 4: 3.69.)
+  int max_nsp = 1;
+  for (int sp = 1; sp <= 16 && sp <= tiles; ++sp) {
+    const int tiles_per = (tiles + sp - 1) / sp;
+    if (sp > 1 && tiles_per < 8) break;
+    max_nsp = (tiles + tiles_per - 1) / tiles_per;
+  }
+  const bool one_round = !rowlist && base * max_nsp <= resident;
+  double best_cost = 1e30;
   for (int sp = 1; sp <= 16 && sp <= tiles && !rowlist; ++sp) {
     const int tiles_per = (tiles + sp - 1) / sp;
     if (sp > 1 && tiles_per < 8) break;                    // keep the A-fragment preload amortised
     const int nsp = (tiles + tiles_per - 1) / tiles_per;
     const int64_t blocks = base * nsp;
+    if (one_round) {
+      const int64_t per_cu = (blocks + 255) / 256;
+      const double cost = (double)(per_cu < 3 ? 3 : per_cu) * (tiles_per + 2);   // < 3 workgroups per CU: no faster than 3
+      if (cost < best_cost - 1e-9) { best_cost = cost; splits = sp; }
+      continue;
+    }
     const int64_t rounds = (blocks + resident - 1) / resident;
     double eff = (double)blocks / (double)(rounds * resident);   // residency balance
     eff *= (double)tiles / (double)(tiles_per * nsp);        // padding of the last split
