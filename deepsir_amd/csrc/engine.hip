@@ -1084,7 +1084,12 @@ static int register_enqueue(dsir_ctx* c, const dsir_pair_batch* in, int n_iter, 
       enc_cache.enc_buf[l] = ws.get<float>(rows * ch);
       enc_cache.enc2_buf[l] = ws.get<float>(rows * ch);
       static const bool no_s2 = getenv("DSIR_NO_S2") != nullptr;   // A/B switch: recompute the enc half of the scores every iteration
-      if (g.d_out[l] >= 64 && !no_s2) {
+      // level 1 (d = 64: a 32-channel contraction) caches its score halves only for a few pairs in flight: with the chip full
+      // re-reading 64 floats per row costs more HBM time than contracting 32 (same bits either way; +1.9 % pairs/s at 128
+      // pairs per launch, -0.02 ms of single-pair latency with the cache)
+      static const int s2_min_d = getenv("DSIR_S2_MIN_D") ? atoi(getenv("DSIR_S2_MIN_D")) : 0;   // tuning hook: 0 = by launch size
+      const int min_d = s2_min_d > 0 ? s2_min_d : (P <= 4 ? 64 : 128);
+      if (g.d_out[l] >= 64 && g.d_out[l] >= min_d && !no_s2) {
         enc_cache.s2_buf[l][0] = ws.get<float>(rows * (size_t)g.d_out[l]);
         enc_cache.s2_buf[l][1] = ws.get<float>(rows * (size_t)g.d_out[l]);
       }
