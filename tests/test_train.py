@@ -606,11 +606,14 @@ def test_data_parallel_step_two_ranks_on_one_gpu():
     """Data-parallel training (`all_reduce_gradients`): two ranks with different pairs (both on the one visible GPU, gloo because
     RCCL refuses two ranks per device), one all_reduce of the flat gradient buffer per step: the reduced gradient is the mean of
     the local ones and both ranks end with bit-identical weights."""
-    import subprocess, sys
+    import socket, subprocess, sys
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
     env["DSIR_BENCH_BACKEND"] = "gloo"
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29733", os.path.join(ROOT, "tools", "train_dp_check.py")], env=env, capture_output=True, text=True,
+                        "--master-port", str(port), os.path.join(ROOT, "tools", "train_dp_check.py")], env=env, capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
