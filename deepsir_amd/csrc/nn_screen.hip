@@ -571,7 +571,9 @@ void launch_nn_screen(const float* a, const float* b, const void* ah, const void
   const int resident = 256 * (DSIR_SCREEN_WPE * 4 / NWV);   // workgroups the chip holds at once
   int splits = 1;
   double best_eff = -1.0;
-  for (int sp = 1; sp <= 16 && sp <= tiles; ++sp) {
+  // at most 8 ref splits: every split emits at least one entry per row (its own best column), and a row holds CAP = 16
+  // before it overflows into the exhaustive kernel (16 splits: measured 2 x slower end to end at 65536 points)
+  for (int sp = 1; sp <= 8 && sp <= tiles; ++sp) {
     const int tiles_per = (tiles + sp - 1) / sp;
     if (sp > 1 && tiles_per < 8) break;
     const int nsp = (tiles + tiles_per - 1) / tiles_per;
@@ -581,6 +583,10 @@ void launch_nn_screen(const float* a, const float* b, const void* ah, const void
     eff *= (double)tiles / (double)(tiles_per * nsp);
     if (eff > best_eff + 1e-9) { best_eff = eff; splits = sp; }
   }
+  // long ref ranges: a second / fourth workgroup per range doubles the lane classes a row's candidates fall into (fewer
+  // class collisions -> fewer rows for the exhaustive kernel) and costs one more prologue + epilogue per >= 128 tiles
+  // (16384 points: +1.4 % pairs/s, 65536: +3.9 %; at 5000 points - 79 tiles - splitting loses 8 % of the kernel)
+  while (splits * 2 <= 4 && tiles / (splits * 2) >= 128) splits *= 2;
   static const int force_splits = getenv("DSIR_SCREEN_SPLITS") ? atoi(getenv("DSIR_SCREEN_SPLITS")) : 0;   // tuning hook
   if (force_splits > 0) splits = force_splits < tiles ? force_splits : tiles;
   const int cols = ((tiles + splits - 1) / splits) * SBC;
