@@ -46,7 +46,7 @@ class dsir_pair_batch(C.Structure):
 class dsir_pair_result(C.Structure):
     _fields_ = [
         ("transforms", C.c_void_p), ("idx", C.c_void_p), ("logits", C.c_void_p), ("pt_ref_new", C.c_void_p),
-        ("invalid", C.c_void_p),
+        ("invalid", C.c_void_p), ("desc_src", C.c_void_p), ("desc_ref", C.c_void_p),
     ]
 
 
@@ -98,6 +98,9 @@ SYMBOLS = {
     "dsir_enable_match_timer": (C.c_int, [C.c_void_p, C.c_int]),
     "dsir_enable_graph": (C.c_int, [C.c_void_p, C.c_int]),
     "dsir_screen_stats": (C.c_int, [C.c_void_p, C.c_int, c_i64_p]),
+    "dsir_screen_bounds": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dsir_screen_cap": (C.c_int, []),
     "dsir_voxel_downsample": (C.c_int, [C.c_void_p, C.c_void_p, c_i64_p, C.c_int, C.c_int, C.c_float, c_float_p, C.c_int,
                                         C.c_void_p, C.c_void_p]),
     "dsir_resample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64,

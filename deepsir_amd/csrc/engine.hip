@@ -904,6 +904,36 @@ int dsir_nn_match_screened(dsir_ctx* c, const float* a, const float* b, int pair
   return post(c);
 }
 
+int dsir_screen_bounds(dsir_ctx* c, const float* a, const float* b, int J, int K, float* lower, float* upper, float* exact,
+                       float* zacc, int32_t* idx, float* thresh, int32_t* cand_count, int32_t* cand_code, float* cand_lower,
+                       int32_t* out_of_domain) {
+  if (!c) return 1;
+  if (!a || !b || !lower || !upper || !exact || !idx || !thresh || !cand_count || !cand_code || !cand_lower || J < 1 || K < 1 ||
+      (int64_t)J * K > ((int64_t)1 << 26))
+    return fail(c, "dsir_screen_bounds: bad arguments (J x K <= 2^26)");
+  HIP_OK(c, hipSetDevice(c->device));
+  c->ws.top = 0; c->ws.overflow = false;
+  Arena& ws = c->ws;
+  void* ah = ws.raw((size_t)J * 128); void* al = ws.raw((size_t)J * 128);
+  void* bh = ws.raw((size_t)K * 128); void* bl = ws.raw((size_t)K * 128);
+  float* sa = ws.get<float>((size_t)J); float* sb = ws.get<float>((size_t)K);
+  void* scratch = ws.raw(nn_screen_scratch_bytes(1, J));
+  int32_t* bad = ws.get<int32_t>(1);
+  if (ws.overflow) return fail(c, "workspace exhausted in dsir_screen_bounds");
+  hipStream_t st = c->stream;
+  HIP_OK(c, hipMemsetAsync(bad, 0, 4, st));
+  launch_split16_norm(a, J, ah, al, sa, st, bad);
+  launch_split16_norm(b, K, bh, bl, sb, st, bad);
+  launch_screen_bounds(a, b, ah, al, bh, bl, sa, sb, J, K, lower, upper, exact, zacc, st);
+  // the product path on the same operands (bad == NULL: the screening runs even outside its domain, so that the flag
+  // and the bound can be looked at independently), then its candidate lists
+  launch_nn_screen(a, b, ah, al, bh, bl, sa, sb, 1, J, K, idx, scratch, st);
+  launch_screen_export(scratch, J, thresh, cand_count, cand_code, cand_lower, st);
+  if (out_of_domain) HIP_OK(c, hipMemcpyAsync(out_of_domain, bad, 4, hipMemcpyDeviceToDevice, st));
+  return post(c);
+}
+int dsir_screen_cap(void) { return nn_screen_cap(); }
+
 int dsir_kabsch(dsir_ctx* c, const float* src, const float* tgt, const float* w, int pairs, int m, float* T,
                 int32_t* invalid) {
   if (!c) return 1;
@@ -1108,6 +1138,7 @@ static int register_enqueue(dsir_ctx* c, const dsir_pair_batch* in, int n_iter, 
     float* F_r = run_mlp_feat(c, feat_r, P, K);
     run_att_proj(c, rxyz, (int64_t)pr.S * 3, score_r, F_r, P, K, desc_r);
     ws.release(mark1);
+    if (out->desc_ref) HIP_OK(c, hipMemcpyAsync(out->desc_ref, desc_r, sizeof(float) * P * K * 64, hipMemcpyDeviceToDevice, st));
     if (screen) {
       launch_split16_norm(desc_r, (int64_t)P * K, sc_bh, sc_bl, sc_sb, st);
     }
@@ -1124,6 +1155,8 @@ static int register_enqueue(dsir_ctx* c, const dsir_pair_batch* in, int n_iter, 
     // aggregation of the (transformed) src cloud
     run_att_proj(c, xyz_cur, (int64_t)J * 3, score_s, F_s, P, J, desc_s);
     ws.release(mark1);
+    if (out->desc_src)
+      HIP_OK(c, hipMemcpyAsync(out->desc_src + (size_t)it * P * J * 64, desc_s, sizeof(float) * P * J * 64, hipMemcpyDeviceToDevice, st));
     // nearest ref descriptor
     if (in->forced_idx) {
       // caller-supplied correspondences: clamped into [0, K), out-of-range entries reported through the pair's flag

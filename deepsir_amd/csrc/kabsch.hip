@@ -158,7 +158,7 @@ __global__ __launch_bounds__(NTHR) void kabsch_kernel(const KabschArgs a) {
     }
     for (int k = 0; k < 12; ++k) { sT[k] = T[k]; a.T[(int64_t)pair * 12 + k] = T[k]; }
     s_bad = bad;
-    if (a.invalid && bad) a.invalid[pair] = 1;
+    if (a.invalid && bad) a.invalid[pair] |= 1;   // one thread per pair; bit 1 (clamped caller index, misc.hip) stays
     if (a.T_cum) {   // concatenate(R_t, T_prev): (R1 R2, R1 t2 + t1)   se3_torch.py:34-57
       float* out = a.T_cum + pair * a.T_stride;
       if (!a.T_prev) {

@@ -203,6 +203,13 @@ void launch_nn_screen(const float* a, const float* b, const void* ah, const void
                       hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, unsigned long long* stats = nullptr,
                       bool keep_gate = false, const int32_t* bad = nullptr, unsigned long long* acc = nullptr,
                       hipEvent_t evk0 = nullptr, hipEvent_t evk1 = nullptr);   // evk0/evk1 bracket screen_kernel alone
+// diagnostics of the screening on ONE small pair (dsir_screen_bounds): lower / upper / exact [J][K]; the candidate lists of the
+// product launch that ran on `scratch` (pairs = 1): thresh [J], count [J], code / lower [J][nn_screen_cap()]
+int nn_screen_cap();
+void launch_screen_bounds(const float* a, const float* b, const void* ah, const void* al, const void* bh, const void* bl,
+                          const float* sa, const float* sb, int J, int K, float* lower, float* upper, float* exact, float* zacc,
+                          hipStream_t st);
+void launch_screen_export(const void* scratch, int J, float* thresh, int32_t* count, int32_t* code, float* lower, hipStream_t st);
 // keep_gate: pairs found not selective by the previous call on this scratch stay exhaustive; bad: launch_split16's flag;
 // acc (device, 4 x u64, optional): running totals {searches, rows, rows left to the exhaustive kernel, pairs searched
 // exhaustively as a whole}

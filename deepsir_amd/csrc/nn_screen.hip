@@ -31,6 +31,15 @@
 // fmaf chain 64 * 2^-24 * 2 |a||b| <= 2^-18 M; final roundings 2^-22 M: 2.8e-5 M against 2^-15 M = 3.05e-5 M (measured on
 // unit descriptors: < 1e-6 against 6e-5).  Elements below 2^-25 lose their low part
 // (fp16 underflow): <= 2^-25 per element, 2^-21 (|a| + |b|) <= 2^-21 (1 + M/2) on the distance: the constant term 2^-20.
+// MEASURED on the matrix core (round 3; tests/test_gpu_screen_bound.py through dsir_screen_bounds, which runs this file's MFMA
+// chain on this file's operands and returns L, U and the exact D of EVERY (row, column)): 19 input regimes chosen against the
+// bound - same-sign components (no cancellation in the accumulator), constant vectors / 64 identical products, components on
+// fp16 rounding ties, |x| = 16, norms 1e-3 .. 30, one-hot, sparse, below the fp16 normal range, near-duplicates, geometric
+// decay - x three shapes, 4.4 M entries: no entry outside [L, U]; worst |D - (L + U) / 2| = 0.066 of the half width (a margin
+// of 15 on d); the accumulation error of the six chained MFMAs against an fp64 sum of the same fp16 products never exceeded
+// 11.9 fp32 roundings of the magnitude sum, against the 198 budgeted above: the v_mfma_f32_16x16x32_f16 adder of gfx950 rounds
+// far less often than once per product (and not by truncation: same-sign inputs err LESS than signed ones).  The bound is
+// kept at its pessimistic width; the test asserts a margin of 2 so that a different stepping would be noticed.
 // Elements with |x| > 16 (the 2^11 pre-scaling of the high part must stay inside fp16: 2^15 < 65504) or not finite: split16_kernel
 // raises a flag and every pair is searched exhaustively (the engine's descriptors are L2-normalised, model.py:232-233,
 // and never take that path).
@@ -509,9 +518,101 @@ __global__ void screen_account_kernel(const int32_t* __restrict__ ovf, int pairs
   if (threadIdx.x == 0) { atomicAdd(acc, 1ull); atomicAdd(acc + 1, (unsigned long long)pairs * (unsigned long long)J); }
 }
 
+// ---- diagnostics (dsir_screen_bounds): the screening's arithmetic laid bare for EVERY (row, column) of one small pair.
+// One wave per 16 x 16 tile runs the SAME chain of six v_mfma_f32_16x16x32_f16 as screen_item (same operands, same
+// order, same seed 2^22 c) and the epilogue's arithmetic for the lower bound L and the upper bound U = L + 2 d, and evaluates the exact
+// distance D beside them, so that a test can assert L <= D <= U entry by entry on adversarial inputs - the
+// property the whole screened path rests on, checked on the matrix core itself rather than derived from an assumed
+// rounding model.  tests/test_gpu_screen_bound.py also ties this kernel to the product: every candidate entry
+// screen_kernel emits must carry the bits of this kernel's L at its (row, column).
+__global__ __launch_bounds__(64) void screen_bounds_kernel(const _Float16* __restrict__ Ah, const _Float16* __restrict__ Al,
+                                                           const _Float16* __restrict__ Bh, const _Float16* __restrict__ Bl,
+                                                           const float* __restrict__ A, const float* __restrict__ B,
+                                                           const float* __restrict__ sa, const float* __restrict__ sb, int J, int K,
+                                                           float* __restrict__ lower, float* __restrict__ upper,
+                                                           float* __restrict__ exact, float* __restrict__ zacc) {
+  const int lane = threadIdx.x & 63, fr = lane & 15, fq = lane >> 4;
+  const int row0 = blockIdx.y * 16, col0 = blockIdx.x * 16;
+  const int arow = min(row0 + fr, J - 1), bcol = min(col0 + fr, K - 1);
+  h8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    ah[c] = *reinterpret_cast<const h8*>(Ah + (int64_t)arow * 64 + 32 * c + 8 * fq);
+    al[c] = *reinterpret_cast<const h8*>(Al + (int64_t)arow * 64 + 32 * c + 8 * fq);
+    bh[c] = *reinterpret_cast<const h8*>(Bh + (int64_t)bcol * 64 + 32 * c + 8 * fq);
+    bl[c] = *reinterpret_cast<const h8*>(Bl + (int64_t)bcol * 64 + 32 * c + 8 * fq);
+  }
+  const float sbk = sb[bcol];
+  const float seed = -2097152.f * (sbk - kC1 * sbk);          // screen_item's gload: 2^22 c, c = -(|b|^2 - d_b) / 2
+  f32x4 z = f32x4{seed, seed, seed, seed};
+  // screen_item's step(), one row tile: (ah0,bh0) (ah1,bh1) (ah0,bl0) (al0,bh0) (ah1,bl1) (al1,bh1)
+  z = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[0], bh[0], z, 0, 0, 0);
+  z = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[1], bh[1], z, 0, 0, 0);
+  z = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[0], bl[0], z, 0, 0, 0);
+  z = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[0], bh[0], z, 0, 0, 0);
+  z = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[1], bl[1], z, 0, 0, 0);
+  z = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[1], bh[1], z, 0, 0, 0);
+  const int col = col0 + fr;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = row0 + 4 * fq + r;
+    if (row >= J || col >= K) continue;
+    const float san = sa[row];
+    const float slo = san - kC1 * san - kC0;                                  // the epilogue of screen_item, verbatim
+    const float l1 = fmaf(z[r], -4.76837158203125e-7f, slo);
+    const float u = l1 + kW * (kC1 * (san + sbk) + kC0);
+    float4 a[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) a[q] = reinterpret_cast<const float4*>(A + (int64_t)row * 64)[q];
+    const int64_t o = (int64_t)row * K + col;
+    lower[o] = l1;
+    upper[o] = u;
+    if (zacc) zacc[o] = z[r];                                                 // the raw accumulator 2^22 (c + a.b)
+    exact[o] = exact_dist(a, B + (int64_t)col * 64, san, sbk);
+  }
+}
+
+// the product's candidate lists of one pair, out of launch_nn_screen's scratch
+__global__ void screen_export_kernel(const unsigned int* __restrict__ umin, const int32_t* __restrict__ cnt,
+                                     const int2* __restrict__ cand, int J, float* __restrict__ thresh,
+                                     int32_t* __restrict__ count, int32_t* __restrict__ code, float* __restrict__ lower) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= J) return;
+  thresh[j] = unorder_bits(umin[j]);
+  const int n = cnt[j];
+  count[j] = n;
+  for (int e = 0; e < CAP; ++e) {
+    const bool live = e < n;
+    code[j * CAP + e] = live ? cand[j * CAP + e].x : 0;
+    lower[j * CAP + e] = live ? __int_as_float(cand[j * CAP + e].y) : 0.f;
+  }
+}
+
 inline int grid_for(int64_t n) { const int64_t g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > 65535 ? 65535 : g)); }
 
 }  // namespace
+
+int nn_screen_cap() { return CAP; }
+
+void launch_screen_bounds(const float* a, const float* b, const void* ah, const void* al, const void* bh, const void* bl,
+                          const float* sa, const float* sb, int J, int K, float* lower, float* upper, float* exact,
+                          float* zacc, hipStream_t st) {
+  hipLaunchKernelGGL(screen_bounds_kernel, dim3((K + 15) / 16, (J + 15) / 16), dim3(64), 0, st,
+                     reinterpret_cast<const _Float16*>(ah), reinterpret_cast<const _Float16*>(al),
+                     reinterpret_cast<const _Float16*>(bh), reinterpret_cast<const _Float16*>(bl), a, b, sa, sb, J, K, lower, upper,
+                     exact, zacc);
+}
+
+// scratch = what launch_nn_screen ran on with pairs = 1 (layout: see nn_screen_scratch_bytes)
+void launch_screen_export(const void* scratch, int J, float* thresh, int32_t* count, int32_t* code, float* lower, hipStream_t st) {
+  const size_t rows = (size_t)J;
+  const char* p = reinterpret_cast<const char*>(scratch);
+  auto take = [&](size_t bytes) { const char* r = p; p += (bytes + 255) & ~(size_t)255; return r; };
+  const unsigned int* umin = reinterpret_cast<const unsigned int*>(take(rows * 4));
+  const int32_t* cnt = reinterpret_cast<const int32_t*>(take(rows * 4));
+  const int2* cand = reinterpret_cast<const int2*>(take(rows * CAP * 8));
+  hipLaunchKernelGGL(screen_export_kernel, dim3((J + 255) / 256), dim3(256), 0, st, umin, cnt, cand, J, thresh, count, code, lower);
+}
 
 // scratch: Umin u32 [rows] | cnt i32 [rows] | cand {col, lower bound} [rows][CAP] | undecidable rows per pair i32 [pairs] |
 //          packed results of the exhaustive fallback u64 [rows] | list of the undecidable rows i32 [rows]

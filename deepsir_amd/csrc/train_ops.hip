@@ -802,8 +802,11 @@ int dsir_t_gemm(void* stream, const float* X, int ldx, const float* W, int wn, i
 }
 
 size_t dsir_t_gemm_dw_scratch(int64_t rows, int N, int K) {
-  const DwPlan p = dw_plan(rows, N, K, true);
-  return (size_t)p.splits * N * p.Kp * sizeof(float);
+  // dsir_t_gemm_dw plans with or without the bias column (db == NULL): one tile column fewer can mean a larger split cap,
+  // i.e. MORE partial matrices than the other plan - size for the larger of the two
+  const DwPlan pb = dw_plan(rows, N, K, true), pn = dw_plan(rows, N, K, false);
+  const size_t a = (size_t)pb.splits * N * pb.Kp, b = (size_t)pn.splits * N * pn.Kp;
+  return (a > b ? a : b) * sizeof(float);
 }
 
 int dsir_t_gemm_dw(void* stream, const float* dY, int ldy, const float* X, int ldx, int64_t rows, int N, int K, float* dW, float* db,

@@ -207,6 +207,23 @@ class Engine:
         self.sync()
         return idx, (int(st[0]), int(st[1]))
 
+    def screen_bounds(self, desc_src, desc_ref):
+        """Diagnostics of the fp16 screening on one pair (include/dsir.h, dsir_screen_bounds): desc_src [J,64], desc_ref [K,64]
+        -> dict(lower, upper, exact, zacc [J,K]; idx, thresh, cand_count [J]; cand_code, cand_lower [J,cap]; out_of_domain)."""
+        a, b = _chk(desc_src, torch.float32, "desc_src"), _chk(desc_ref, torch.float32, "desc_ref")
+        J, K = a.shape[0], b.shape[0]
+        cap = int(self.lib.dsir_screen_cap())
+        out = {"lower": self._empty((J, K)), "upper": self._empty((J, K)), "exact": self._empty((J, K)), "zacc": self._empty((J, K)),
+               "idx": self._empty((J,), torch.int32), "thresh": self._empty((J,)), "cand_count": self._empty((J,), torch.int32),
+               "cand_code": self._empty((J, cap), torch.int32), "cand_lower": self._empty((J, cap)),
+               "out_of_domain": self._empty((1,), torch.int32)}
+        self._pre()
+        self._call(self.lib.dsir_screen_bounds(self.h, _ptr(a), _ptr(b), J, K, _ptr(out["lower"]), _ptr(out["upper"]),
+                                               _ptr(out["exact"]), _ptr(out["zacc"]), _ptr(out["idx"]), _ptr(out["thresh"]), _ptr(out["cand_count"]),
+                                               _ptr(out["cand_code"]), _ptr(out["cand_lower"]), _ptr(out["out_of_domain"])))
+        self.sync()
+        return out
+
     def kabsch(self, src, tgt, w):
         """compute_rigid_transform_2 counterpart -> (T [p,3,4], invalid [p] i32)."""
         src, tgt = _chk(src, torch.float32, "src"), _chk(tgt, torch.float32, "tgt")
@@ -243,7 +260,8 @@ class Engine:
         return b, keep, (P, J, K)
 
     def register(self, points_src, points_ref, n_iter: int = 5, pyramids: Optional[dict] = None,
-                 forced_idx: Optional[torch.Tensor] = None, want_aux: bool = True, sync: bool = True, out: Optional[dict] = None):
+                 forced_idx: Optional[torch.Tensor] = None, want_aux: bool = True, sync: bool = True, out: Optional[dict] = None,
+                 want_desc: bool = False):
         """forward_align_4 counterpart for P pairs.
 
         points_* [P, N, feat_len].  pyramids: optional dict with the reference's
@@ -262,10 +280,14 @@ class Engine:
                 out["logits"] = self._empty((n_iter, P, J))
                 out["pt_ref_new"] = self._empty((P, J, 3))
                 out["invalid"] = self._empty((P,), torch.int32)
+            if want_desc:     # test aid: the descriptors every iteration's search ran on
+                out["desc_src"] = self._empty((n_iter, P, J, 64))
+                out["desc_ref"] = self._empty((P, K, 64))
         r = _lib.dsir_pair_result()
         r.transforms = _ptr(out["transforms"])
         r.idx, r.logits = _ptr(out.get("idx")), _ptr(out.get("logits"))
         r.pt_ref_new, r.invalid = _ptr(out.get("pt_ref_new")), _ptr(out.get("invalid"))
+        r.desc_src, r.desc_ref = _ptr(out.get("desc_src")), _ptr(out.get("desc_ref"))
         self._pre()
         self._call(self.lib.dsir_register(self.h, C.byref(b), n_iter, C.byref(r)))
         if sync:
@@ -500,7 +522,7 @@ class EnginePool:
         return [(a, min(P, a + per)) for a in range(0, P, per)]
 
     def register(self, points_src, points_ref, n_iter: int = 5, want_aux: bool = True, sync: bool = True,
-                 out: Optional[dict] = None, pyramids: Optional[dict] = None):
+                 out: Optional[dict] = None, pyramids: Optional[dict] = None, want_desc: bool = False):
         P = points_src.shape[0]
         if P > self.per * self.streams:
             raise EngineError(f"pairs={P} exceeds the pool's max_pairs={self.per * self.streams}")
@@ -512,7 +534,7 @@ class EnginePool:
             o = {"transforms": out["transforms"][a:b]} if not want_aux else None
             pyr = None if pyramids is None else {k: v[a:b] for k, v in pyramids.items()}
             parts.append(e.register(points_src[a:b], points_ref[a:b], n_iter, want_aux=want_aux, sync=False, out=o,
-                                    pyramids=pyr))
+                                    pyramids=pyr, want_desc=want_desc and want_aux))
         if sync or want_aux:
             self.sync()
         if want_aux:
@@ -521,6 +543,9 @@ class EnginePool:
             out["logits"] = torch.cat([p["logits"] for p in parts], 1)
             out["pt_ref_new"] = torch.cat([p["pt_ref_new"] for p in parts], 0)
             out["invalid"] = torch.cat([p["invalid"] for p in parts], 0)
+            if want_desc:
+                out["desc_src"] = torch.cat([p["desc_src"] for p in parts], 1)
+                out["desc_ref"] = torch.cat([p["desc_ref"] for p in parts], 0)
         out["_parts"] = parts
         return out
 

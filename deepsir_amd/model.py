@@ -174,10 +174,11 @@ class Network(nn.Module):
                                          T.AggregationTrainer(self.cfg, sd, dev))
             fe, ag = self._frozen_trainers
             masks = None
-            if dropout_seed is not None:
-                g = torch.Generator(device=dev).manual_seed(int(dropout_seed))
-                keep = lambda *shape: (torch.rand(*shape, generator=g, device=dev) >= 0.5).to(torch.uint8)
-                masks = {"fe_src": keep(B, J, 64), "fe_ref": keep(B, ref.shape[1], 64), "inlier": keep(n_iter, B, J, 64)}
+            if dropout_seed is not None:     # the inlier model's masks are those of the 'eval' variant (train.dropout_keep_masks)
+                sd_ = int(dropout_seed)
+                masks = {"inlier": T.dropout_keep_masks(sd_, (n_iter, B, J, 64), dev),
+                         "fe_src": T.dropout_keep_masks(3 * sd_ + 1, (B, J, 64), dev),
+                         "fe_ref": T.dropout_keep_masks(3 * sd_ + 2, (B, ref.shape[1], 64), dev)}
             fn = None
             if "matches" in data:
                 fn = lambda idx: torch.from_numpy(T.find_correct_correspondence(data["matches"], idx, J)).to(dev)
@@ -206,22 +207,22 @@ class Network(nn.Module):
                     self._frozen_trainers = (T.RandlaTrainer(self.cfg, sd, "feat_extractor", self.cfg.feat_len, self.cfg.num_classes, dev),)
                 masks = None
                 if dropout_seed is not None:
-                    g = torch.Generator(device=dev).manual_seed(int(dropout_seed))
-                    masks = {f"fe_{s_}": (torch.rand(B, n_, 64, generator=g, device=dev) >= 0.5).to(torch.uint8)
-                             for s_, n_ in (("src", J), ("ref", ref.shape[1]))}
+                    masks = {f"fe_{s_}": T.dropout_keep_masks(3 * int(dropout_seed) + o_, (B, n_, 64), dev)
+                             for s_, n_, o_ in (("src", J, 1), ("ref", ref.shape[1], 2))}
                 inp = T.feat_pipeline_inputs_train(eng, self._frozen_trainers[0], batch, self.cfg.num_sub, masks)
             else:
                 inp = T.feat_pipeline_inputs(eng, batch, self.cfg.num_sub)
             out = T.train_step_feat(tr, inp, data["transform_gt"].float().to(dev), thres_radius, det_loss_weight, lr, dist=dist)
-        if not out.get("skipped", False):
-            new = tr.state_dict()
-            for ft in (getattr(self, "_frozen_trainers", None) or ()):          # frozen weights, moving running statistics
-                new.update({k: v.detach().cpu().numpy().reshape(ft._shapes[k]) for k, v in ft.buffers.items()})
-            with torch.no_grad():
-                own = dict(self.named_buffers())
-                for k, v in new.items():
-                    own[k].copy_(torch.from_numpy(np.ascontiguousarray(v)).to(own[k].device))
-            self._dirty = True
+        # written back on skipped steps too: the parameters are then unchanged, but the BatchNorm running statistics moved in
+        # the forward pass whatever optimizer.step() did afterwards (train.py:401 runs before :437-446)
+        new = tr.state_dict()
+        for ft in (getattr(self, "_frozen_trainers", None) or ()):          # frozen weights, moving running statistics
+            new.update({k: v.detach().cpu().numpy().reshape(ft._shapes[k]) for k, v in ft.buffers.items()})
+        with torch.no_grad():
+            own = dict(self.named_buffers())
+            for k, v in new.items():
+                own[k].copy_(torch.from_numpy(np.ascontiguousarray(v)).to(own[k].device))
+        self._dirty = True
         return out
 
     # ---- the optimiser's checkpoint entry (CheckPointManager saves optimizer.state_dict(), common/torch_utils.py:62-67)

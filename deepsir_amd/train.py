@@ -591,6 +591,37 @@ class RandlaTrainer(_ParamStore):
                 self._mlp2d_bwd(tape, pf + ".mlp_pre", dfeat.reshape(clouds * N, -1), need_dx=False)
 
 
+def dropout_keep_masks(seed: Optional[int], shape, device) -> Optional[torch.Tensor]:
+    """Dropout(0.5) keep flags (RandLANet.py:363-367) of one optimisation step, uint8 ``shape`` on ``device``: ONE draw from a
+    device generator seeded with ``seed``.  Every entry point that takes ``dropout_seed`` (``train_step_align``,
+    ``AlignTrainStep.step``, ``train_step_label``, ``Network.train_step``) draws through this function, so the same seed gives
+    the same masks - hence the same gradients up to the order of the fp32 atomics - on the eager and the hipGraph path.
+    None: dropout off."""
+    if seed is None:
+        return None
+    g = torch.Generator(device=device).manual_seed(int(seed))
+    return (torch.rand(tuple(shape), generator=g, device=device) >= 0.5).to(torch.uint8)
+
+
+def any_pose_invalid(flags, dist=None) -> bool:
+    """The reference skips ``optimizer.step()`` when a gradient is NaN OR ``endpoints['invalid_gradient']`` is set (a
+    degenerate weighted-Kabsch covariance, model.py:61-64; train.py:437-446).  flags: the ``invalid`` outputs of
+    ``Engine.kabsch`` / ``Engine.register`` (bit 0 = degenerate pose); with ``dist`` the verdict is shared by all ranks
+    (they must take the same decision, or their parameters diverge)."""
+    bad = False
+    for f in flags:
+        if f is not None and bool((f.to(torch.int32) & 1).any()):
+            bad = True
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        dev = next((f.device for f in flags if f is not None), torch.device("cpu"))
+        if dist.get_backend() != "nccl":
+            dev = torch.device("cpu")
+        t = torch.tensor([1 if bad else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        bad = bool(t.item())
+    return bad
+
+
 def forward_align_train(engine, inlier: RandlaTrainer, extractor: RandlaTrainer, aggregation: "AggregationTrainer", batch: dict,
                         n_iter: int, masks: Optional[dict] = None) -> dict:
     """``forward_align_4`` (network/model.py:520-607) as the reference's training loop runs it: ``my_model.train()`` (train.py:379)
@@ -614,7 +645,7 @@ def forward_align_train(engine, inlier: RandlaTrainer, extractor: RandlaTrainer,
     xyz0, f_s, sc_s = side["src"]
     xyz_r, f_r, sc_r = side["ref"]
     P, J, _ = xyz0.shape
-    idxs, logits, tapes = [], [], []
+    idxs, logits, tapes, invalid = [], [], [], []
     cur = xyz0
     for it in range(n_iter):
         d_s, _ = aggregation.forward(cur, f_s, sc_s, second_normalize=False)
@@ -624,11 +655,12 @@ def forward_align_train(engine, inlier: RandlaTrainer, extractor: RandlaTrainer,
         m = masks.get("inlier")
         lg, tape = inlier.forward(cat, batch["src_xyz"], batch["src_neigh"], batch["src_sub"], batch["src_interp"], None if m is None else m[it])
         lg = lg.reshape(P, J)
-        T_it, _bad = engine.kabsch(cur, cat[:, :, 3:].contiguous(), o.sigmoid(lg.contiguous()))
+        T_it, bad_it = engine.kabsch(cur, cat[:, :, 3:].contiguous(), o.sigmoid(lg.contiguous()))
+        invalid.append(bad_it)
         cur = o.inlier_input(cur, xyz_r, idx, T_it)[:, :, :3].contiguous()        # xyz_src <- R_t.detach() xyz_src (model.py:587)
         idxs.append(idx); logits.append(lg); tapes.append(tape)
     return {"idx": torch.stack(idxs).contiguous(), "logits": torch.stack(logits).contiguous(), "tapes": tapes, "xyz_src": xyz0,
-            "xyz_ref": xyz_r}
+            "xyz_ref": xyz_r, "invalid": invalid}
 
 
 def train_step_align_full(engine, inlier: RandlaTrainer, extractor: RandlaTrainer, aggregation: "AggregationTrainer", batch: dict,
@@ -645,7 +677,7 @@ def train_step_align_full(engine, inlier: RandlaTrainer, extractor: RandlaTraine
     for it in range(n_iter):
         inlier.backward(fw["tapes"][it], out["grad_logits"][it])
     all_reduce_gradients(inlier, dist)
-    bad = inlier.grads_have_nan()
+    bad = inlier.grads_have_nan() or any_pose_invalid(fw["invalid"], dist)      # train.py:437-446: NaN gradient OR invalid_gradient
     if apply and not bad:
         inlier.adam_step(lr)
     out.update(logits=fw["logits"], idx=fw["idx"], skipped=bad)
@@ -672,16 +704,12 @@ def train_step_align(engine, trainer: RandlaTrainer, batch: dict, result: dict, 
     n_iter, P, N = idx.shape
     trainer.zero_grad()
     logits, tapes = [], []
-    gen = torch.Generator(device="cpu")
-    if dropout_seed is not None:
-        gen.manual_seed(int(dropout_seed))
+    masks = dropout_keep_masks(dropout_seed, (n_iter, P, N, trainer.cfg.out_feat_dim), dev)
     trainer.ops.begin()
     for it in range(n_iter):
         # the src cloud moved by the previous cumulative pose (model.py:587; R_t.detach()) next to its correspondences
         cat = trainer.ops.inlier_input(xyz_s, xyz_r, idx[it], None if it == 0 else T[:, it - 1])
-        mask = None
-        if dropout_seed is not None:
-            mask = (torch.rand(P, N, trainer.cfg.out_feat_dim, generator=gen) >= 0.5).to(torch.uint8).to(dev)
+        mask = None if masks is None else masks[it]
         lg, tape = trainer.forward(cat, batch["src_xyz"], batch["src_neigh"], batch["src_sub"], batch["src_interp"], mask)
         logits.append(lg.reshape(P, N))
         tapes.append(tape)
@@ -691,7 +719,7 @@ def train_step_align(engine, trainer: RandlaTrainer, batch: dict, result: dict, 
     for it in range(n_iter):
         trainer.backward(tapes[it], g[it])
     all_reduce_gradients(trainer, dist)
-    bad = trainer.grads_have_nan()
+    bad = trainer.grads_have_nan() or any_pose_invalid([result.get("invalid")], dist)   # train.py:437-446
     if apply and not bad:
         trainer.adam_step(lr)
     out["logits"] = lg_all
@@ -841,17 +869,12 @@ def train_step_label(trainer: RandlaTrainer, batch: dict, labels_src: torch.Tens
     dev = trainer.device
     cw = torch.tensor(semantic_class_weights(), dtype=torch.float32, device=dev)
     trainer.zero_grad()
-    gen = torch.Generator(device="cpu")
-    if dropout_seed is not None:
-        gen.manual_seed(int(dropout_seed))
     res = {}
     outs = []
-    for side, labels in (("src", labels_src), ("ref", labels_ref)):
+    for si, (side, labels) in enumerate((("src", labels_src), ("ref", labels_ref))):
         pts = batch[f"points_{side}"].contiguous()
         P, N, _ = pts.shape
-        mask = None
-        if dropout_seed is not None:
-            mask = (torch.rand(P, N, trainer.cfg.out_feat_dim, generator=gen) >= 0.5).to(torch.uint8).to(dev)
+        mask = dropout_keep_masks(None if dropout_seed is None else 2 * int(dropout_seed) + si, (P, N, trainer.cfg.out_feat_dim), dev)
         logits, tape = trainer.forward(pts, batch[f"{side}_xyz"], batch[f"{side}_neigh"], batch[f"{side}_sub"], batch[f"{side}_interp"], mask)
         d, out = o.weighted_ce(logits.reshape(P * N, trainer.num_classes), labels.reshape(-1).contiguous(), cw)
         trainer.backward(tape, d)
@@ -878,7 +901,9 @@ class AlignTrainStep:
     backwards.  Between them the loss and its gradient (``Engine.align_loss_backward``, its own launch) and after them ONE
     Adam launch over the flat parameter buffer, whose bias corrections change per step and therefore stay outside.
     The first call runs eagerly (it IS a training step), the second captures, later ones replay.  Inputs are copied into
-    static device buffers; results are those of ``train_step_align`` bit for bit except for the order of the fp32 atomics."""
+    static device buffers; with the same ``dropout_seed`` the masks are those of ``train_step_align`` (``dropout_keep_masks``) and the
+    results equal its results except for the order of the fp32 atomics (tests/test_train.py::test_graph_replayed_step_equals_the_eager_step
+    runs the comparison with dropout on)."""
 
     def __init__(self, engine, trainer: RandlaTrainer, pairs: int, n_src: int, n_ref: int, n_iter: int, dropout: bool = True,
                  use_graph: bool = True):
@@ -922,9 +947,9 @@ class AlignTrainStep:
         self.sub.copy_(batch["src_sub"]); self.interp.copy_(batch["src_interp"])
         self.idx.copy_(result["idx"]); self.T.copy_(result["transforms"])
         if self.masks is not None:
-            if dropout_seed is not None:
-                self.gen.manual_seed(int(dropout_seed))
-            self.masks.copy_(torch.rand(self.masks.shape, generator=self.gen, device=tr.device) >= 0.5)
+            # the same draw as train_step_align's (dropout_keep_masks); without a seed: the stepper's own running generator
+            m = dropout_keep_masks(dropout_seed, self.masks.shape, tr.device)
+            self.masks.copy_(m if m is not None else torch.rand(self.masks.shape, generator=self.gen, device=tr.device) >= 0.5)
         self.calls += 1
         graphs = self.use_graph and self.calls >= 2
         if graphs and self.gf is None:
@@ -950,7 +975,7 @@ class AlignTrainStep:
         else:
             self._backward_all()
         all_reduce_gradients(tr, dist)
-        bad = tr.grads_have_nan()
+        bad = tr.grads_have_nan() or any_pose_invalid([result.get("invalid")], dist)   # train.py:437-446
         if apply and not bad:
             tr.adam_step(lr)
         out["logits"] = self.logits

@@ -27,6 +27,10 @@ def generate_state_dict(cfg: NetConfig, seed: int = 0, variant: str = "plain") -
     and the last ``mlp_feat`` layer are scaled up so that aggregated
     descriptors of distinct points are far apart relative to fp32 rounding —
     a well-conditioned arg-min regime.
+    variant "clustered:<s>" (0 < s < 1; bench.py --cluster-descriptors): the descriptor head's weight scaled DOWN by s
+    under a fixed bias of norm ~1.6, so that all aggregated descriptors sit in a cap of angular radius ~s around one
+    direction and the distances between them shrink by ~s^2 - what the descriptors of large planar regions do under a
+    trained checkpoint; the unfriendly regime for any screening of the arg-min.
     """
     rng = np.random.Generator(np.random.Philox(key=int(seed) + 0x5EED))
     out: "OrderedDict[str, np.ndarray]" = OrderedDict()
@@ -54,6 +58,12 @@ def generate_state_dict(cfg: NetConfig, seed: int = 0, variant: str = "plain") -
     if variant == "separated":
         out["mlp_feat.6.weight"] = out["mlp_feat.6.weight"] * np.float32(4.0)
         out["mlp_proj.0.weight"] = out["mlp_proj.0.weight"] * np.float32(4.0)
+    elif variant.startswith("clustered:"):
+        sc = float(variant.split(":", 1)[1])
+        if not 0.0 < sc < 1.0:
+            raise ValueError("clustered:<s> needs 0 < s < 1")
+        out["mlp_proj.0.weight"] = out["mlp_proj.0.weight"] * np.float32(sc)
+        out["mlp_proj.0.bias"] = (np.sign(out["mlp_proj.0.bias"]) * np.float32(0.2)).astype(np.float32)
     elif variant != "plain":
         raise ValueError(f"unknown weight variant {variant!r}")
     return out

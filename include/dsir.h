@@ -168,6 +168,10 @@ typedef struct dsir_pair_result {
                           *     (endpoints['invalid_gradient'], model.py:61-64; also the outcome of a non-finite
                           *     input point: that pair alone, the other pairs of the batch are unaffected);
                           *     bit 1 = a caller-supplied index was out of range and clamped       or NULL  */
+  /* test aids (parity of the arg-min on the engine's OWN descriptors, tests/test_gpu_large_configs.py): the aggregated,
+   * L2-normalised descriptors Network.aggregation returns (model.py:552) as the search of each iteration saw them */
+  float* desc_src;       /* [n_iter][P][J][64]                                                    or NULL  */
+  float* desc_ref;       /* [P][K][64] (loop invariant)                                           or NULL  */
 } dsir_pair_result;
 
 /* Replaces Network.forward -> forward_align_4 (network/model.py:297-298,
@@ -300,6 +304,22 @@ int dsir_enable_match_timer(dsir_ctx* ctx, int enable);
  * [4] searches that took the exhaustive kernel directly (small problems, forced runs excluded).  Synchronises.
  * Not counted while a hipGraph replays (dsir_enable_graph): [4] is a host-side counter. */
 int dsir_screen_stats(dsir_ctx* ctx, int reset, int64_t* out);
+
+/* Diagnostics of the fp16 screening (csrc/nn_screen.hip) on ONE pair, all pointers DEVICE memory: for every (row, column)
+ * the screening's lower bound L, its upper bound U = L + 2 d and the exact fp32 distance D of dsir_nn_match
+ * (lower / upper / exact [J][K]; zacc [J][K], optional: the raw fp32 accumulator 2^22 (c + a.b) the six chained
+ * v_mfma_f32_16x16x32_f16 leave, for measuring the matrix core's accumulation error against an fp64 sum of the same
+ * fp16 products) - computed by the same MFMA chain on the same fp16 operands as the product kernel -,
+ * plus what the product path did with the same inputs: idx [J] (its arg-min), thresh [J] (the row's final threshold),
+ * cand_count [J] (entries emitted; > dsir_screen_cap() = the list overflowed), cand_code / cand_lower
+ * [J][dsir_screen_cap()] (code >= 0: a column and the bits of its L; code < 0: a lane class), out_of_domain [1]
+ * (non-zero: a component was outside the bound's domain |x| <= 16 - the product path would not screen such input).
+ * The screened search is exact iff L <= D <= U for every entry; tests/test_gpu_screen_bound.py asserts it on
+ * adversarial inputs.  J * K <= 2^26. */
+int dsir_screen_bounds(dsir_ctx* ctx, const float* desc_src, const float* desc_ref, int J, int K, float* lower, float* upper,
+                       float* exact, float* zacc, int32_t* idx, float* thresh, int32_t* cand_count, int32_t* cand_code, float* cand_lower,
+                       int32_t* out_of_domain);
+int dsir_screen_cap(void);
 
 #ifdef __cplusplus
 }

@@ -40,7 +40,46 @@ def test_world_size_mismatch_is_an_error():
     assert r.returncode != 0 and "launched as 1 ranks" in r.stderr
 
 
+def test_strong_scaling_dry_run_8_ranks_1623_pairs():
+    """BASELINE configs[3]: the 3DMatch test set (1623 pairs) sharded over 8 ranks - unequal shards (7 x 203 + 202), one padded
+    all_gather, every pair back in its place.  CPU rehearsal (gloo) of exactly what `bench.py --gpus 8 --total-pairs 1623` does
+    around the engine."""
+    r = _run(["--gpus", "8", "--dry-run", "--total-pairs", "1623"], timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _json_line(r.stdout)
+    assert j["n_gpus"] == 8 and j["world_size"] == 8 and j["gather_ok"] and j["pairs_total"] == 1623 and j["scaling"] == "strong"
+    assert j["shard_sizes"] == [203] * 7 + [202] and j["calls_per_rank"] == [1] * 8
+
+
+def test_strong_scaling_dry_run_more_ranks_than_pairs():
+    j = _json_line(_run(["--gpus", "3", "--dry-run", "--total-pairs", "2"]).stdout)
+    assert j["gather_ok"] and j["shard_sizes"] == [1, 1, 0]
+
+
 import pytest
+
+
+@pytest.mark.gpu
+def test_strong_scaling_two_ranks_with_the_engine_on_one_gpu():
+    """`bench.py --gpus 2 --total-pairs 21 --pairs 8`: a fixed set in unequal shards (11 + 10), each walked in engine calls of
+    at most 8 pairs (8 + 3 / 8 + 2: ragged last calls), one padded all_gather per pass, "scaling": "strong", per-rank rows."""
+    r = _run(["--gpus", "2", "--total-pairs", "21", "--pairs", "8", "--points", "2048", "--steps", "2", "--warmup", "1", "--streams", "2"],
+             {"DSIR_BENCH_BACKEND": "gloo"}, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = _json_line(r.stdout)
+    assert j["scaling"] == "strong" and j["config"]["total_pairs"] == 21 and j["config"]["world_size"] == 2
+    assert [x["pairs_per_step"] for x in j["ranks"]] == [11, 10]
+    assert abs(j["value"] * j["ms_per_step"] / 1e3 - 21) < 0.05          # value = the whole set / the slowest rank's pass time
+
+
+@pytest.mark.gpu
+def test_rccl_needs_one_device_per_rank():
+    """Two ranks over RCCL on a one-GPU box: refused before any GPU call, with a message (never a hang)."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a single-GPU box")
+    r = _run(["--gpus", "2", "--pairs", "2", "--points", "2048", "--steps", "1", "--warmup", "0"], timeout=300)
+    assert r.returncode != 0 and "visible devices" in r.stderr
 
 
 @pytest.mark.gpu

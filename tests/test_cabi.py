@@ -30,7 +30,7 @@ def test_struct_layout_matches_header():
     from deepsir_amd import _lib
     assert ctypes.sizeof(_lib.dsir_cfg) == 4 * (3 + 4 + 4 + 4 + 1)
     assert ctypes.sizeof(_lib.dsir_pair_batch) == 16 + 11 * 8
-    assert ctypes.sizeof(_lib.dsir_pair_result) == 5 * 8
+    assert ctypes.sizeof(_lib.dsir_pair_result) == 7 * 8
     assert ctypes.sizeof(_lib.dsir_cloud_out) == 6 * 8
 
 

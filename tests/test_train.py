@@ -861,3 +861,53 @@ def test_optimizer_state_round_trips_with_torch_adam():
     net2._trainer.adam_step(2e-3)
     for i in trained:
         assert torch.allclose(net2._trainer.params[order[i]].cpu().reshape(ref_params[i].shape), ref_params[i].detach(), rtol=1e-5, atol=2e-6)
+
+
+# --------------------------------------------------------------------------- dW scratch sizing
+def test_dw_scratch_covers_both_plans_host_arithmetic():
+    """dsir_t_gemm_dw plans its row split with or without the bias column; the sizing call must cover whichever needs more
+    partial matrices (N = K = 128 at 319 488 rows, db = NULL, needs 33.5 MB - the round-2 sizing returned 22.4 MB).  Host
+    arithmetic only: callable without a GPU."""
+    from deepsir_amd import _lib
+    lib = _lib.load()
+    TB, TK = 64, 16
+
+    def plan(rows, N, K, bias):
+        Kp = K + (1 if bias else 0)
+        tiles = ((N + TB - 1) // TB) * ((Kp + TB - 1) // TB)
+        sp = min((rows + 511) // 512, 1 if tiles >= 2048 else 2048 // tiles, 1024)
+        sp = max(sp, 1)
+        rps = (((rows + sp - 1) // sp) + TK - 1) // TK * TK
+        return max((rows + rps - 1) // rps, 1) * N * Kp * 4
+
+    for rows, N, K in [(319488, 128, 128), (200000, 128, 128), (1_000_000, 256, 256), (80000, 8, 10), (5000, 64, 64), (1, 1, 1),
+                       (294912, 64, 64), (640000, 128, 64)]:
+        need = max(plan(rows, N, K, True), plan(rows, N, K, False))
+        got = int(lib.dsir_t_gemm_dw_scratch(rows, N, K))
+        assert got >= need, (rows, N, K, got, need)
+
+
+@pytest.mark.gpu
+def test_dw_without_bias_stays_inside_its_scratch():
+    """conv_dw(db = None) at N = K = 128, 319 488 rows: the partial matrices must stay inside dsir_t_gemm_dw_scratch bytes
+    (guard region behind the scratch untouched) and the result must equal dY^T X."""
+    import ctypes as C
+    from deepsir_amd import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda", 0)
+    rows, N, K = 319488, 128, 128
+    g = torch.Generator(device="cpu").manual_seed(3)
+    dy = torch.randn(rows, N, generator=g).to(dev)
+    x = torch.randn(rows, K, generator=g).to(dev)
+    nbytes = int(lib.dsir_t_gemm_dw_scratch(rows, N, K))
+    guard = 1 << 20
+    buf = torch.full(((nbytes + 3) // 4 + guard,), 12345.0, device=dev)
+    dw = torch.zeros(N, K, device=dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    rc = lib.dsir_t_gemm_dw(st, dy.data_ptr(), N, x.data_ptr(), K, rows, N, K, dw.data_ptr(), None, buf.data_ptr())
+    torch.cuda.synchronize()
+    assert rc == 0
+    assert bool((buf[(nbytes + 3) // 4:] == 12345.0).all()), "dsir_t_gemm_dw wrote past dsir_t_gemm_dw_scratch bytes"
+    ref = dy.double().t() @ x.double()
+    err = float((dw.double() - ref).abs().max() / ref.abs().max())
+    assert err < 1e-5, err
