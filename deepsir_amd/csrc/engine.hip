@@ -84,6 +84,8 @@ struct dsir_ctx {
   std::vector<HostParam> params;
   std::unordered_map<std::string, int> index;
   float* dweights = nullptr;
+  uint16_t* dweights16 = nullptr;        // fp16 split (high | low) of mlp_att[1..4] and mlp_proj for agg_chain_h.hip
+  const void* agg_wh[5] = {}; const void* agg_wl[5] = {};
   bool finalized = false;
   NetW net;
   Arena ws;
@@ -104,6 +106,8 @@ struct dsir_ctx {
   int64_t match_launches = 0;
   // arg-min path of dsir_register: 1 = screened (nn_screen.hip) for large problems, 0 = always the exhaustive kernel
   int screen_mode = 1;
+  // aggregation chain: 1 = fp16-split products on the fp16 matrix pipe (agg_chain_h.hip), 0 = exact-fp32 chain (agg_chain.hip)
+  int agg_split = 1;
   // device-clock brackets {first wave start, last wave end} of the timed nn_match launches
   unsigned long long* match_ts = nullptr;    // [kMatchSlots][2]
   size_t match_ts_used = 0;
@@ -576,6 +580,12 @@ void run_att_proj(dsir_ctx* c, const float* xyz, int64_t xyz_cs, const float* sc
     a.W1 = m[0].W; a.b1 = m[0].b; a.W2 = m[1].W; a.b2 = m[1].b; a.W3 = m[2].W; a.b3 = m[2].b;
     a.W4 = m[3].W; a.b4 = m[3].b; a.W5 = m[4].W; a.b5 = m[4].b; a.W6 = w.mlp_proj.W; a.b6 = w.mlp_proj.b;
     a.desc = desc; a.n = n; a.clouds = clouds;
+    // default: the chain's wide layers as fp16-split products on the fp16 matrix pipe (agg_chain_h.hip: fp32 accuracy, not the
+    // fp32 kernel's bits); dsir_enable_agg_split(0) / DSIR_AGG_F32: the exact-fp32 chain, bit-identical to the unfused launches below
+    if (c->agg_split) {
+      for (int k = 0; k < 5; ++k) { a.Wh[k] = c->agg_wh[k]; a.Wl[k] = c->agg_wl[k]; }
+      if (launch_agg_chain_h(a, c->stream)) return;
+    }
     if (launch_agg_chain(a, c->stream)) return;
   }
   const Seg sx = plain_seg(xyz, xyz_cs, 3, 3);
@@ -670,6 +680,7 @@ int dsir_create(int device, const dsir_cfg* cfg, dsir_ctx** out) {
   dsir_ctx* c = new dsir_ctx();
   c->device = device; c->cfg = *cfg;
   c->screen_mode = getenv("DSIR_NO_SCREEN") ? 0 : 1;
+  c->agg_split = getenv("DSIR_AGG_F32") ? 0 : 1;
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
     delete c;
     return fail(nullptr, "cannot initialise device %d", device);
@@ -725,6 +736,7 @@ void dsir_destroy(dsir_ctx* c) {
   for (auto& e : c->match_events) { hipEventDestroy(e.op0); hipEventDestroy(e.op1); hipEventDestroy(e.k0); hipEventDestroy(e.k1); }
   if (c->graph_exec) hipGraphExecDestroy(c->graph_exec);
   if (c->dweights) hipFree(c->dweights);
+  if (c->dweights16) hipFree(c->dweights16);
   if (c->match_ts) hipFree(c->match_ts);
   if (c->screen_acc) hipFree(c->screen_acc);
   if (c->stats) hipFree(c->stats);
@@ -790,10 +802,22 @@ int dsir_finalize_weights(dsir_ctx* c) {
   const float* b = c->dweights;
   c->net.feat = bind_randla(b, fo, c->cfg);
   if (has_inl) c->net.inl = bind_randla(b, io, c->cfg);
+  if (c->dweights16) { hipFree(c->dweights16); c->dweights16 = nullptr; }
+  for (int k = 0; k < 5; ++k) c->agg_wh[k] = c->agg_wl[k] = nullptr;
   if (has_agg) {
     for (int k = 0; k < 3; ++k) c->net.mlp_feat[k] = bind_lin(b, mf[k]);
     for (int k = 0; k < 5; ++k) c->net.mlp_att[k] = bind_lin(b, ma[k]);
     c->net.mlp_proj = bind_lin(b, mp);
+    // fp16 split of the five wide layers of the aggregation chain (BatchNorm already folded), agg_chain_h.hip
+    const LinOff* lay[5] = {&ma[1], &ma[2], &ma[3], &ma[4], &mp};
+    size_t total = 0, off[5];
+    for (int k = 0; k < 5; ++k) { off[k] = total; total += ((size_t)lay[k]->cin * lay[k]->cout + 63) & ~(size_t)63; }
+    std::vector<uint16_t> h16(2 * total, 0);
+    for (int k = 0; k < 5; ++k)
+      split_weights_f16(u.blob.data() + lay[k]->W, (size_t)lay[k]->cin * lay[k]->cout, h16.data() + off[k], h16.data() + total + off[k]);
+    HIP_OK(c, hipMalloc((void**)&c->dweights16, h16.size() * sizeof(uint16_t)));
+    HIP_OK(c, hipMemcpy(c->dweights16, h16.data(), h16.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    for (int k = 0; k < 5; ++k) { c->agg_wh[k] = c->dweights16 + off[k]; c->agg_wl[k] = c->dweights16 + total + off[k]; }
   }
   c->finalized = true;
   return 0;
@@ -1492,6 +1516,15 @@ int dsir_match_timer2(dsir_ctx* c, int reset, double* op_ms, double* kernel_ms, 
   if (kernel_ms) *kernel_ms = c->match_kernel_ms;
   if (launches) *launches = c->match_launches;
   if (reset) { c->match_ms = 0.0; c->match_kernel_ms = 0.0; c->match_launches = 0; }
+  return 0;
+}
+
+int dsir_enable_agg_split(dsir_ctx* c, int enable) {
+  if (!c) return 1;
+  c->agg_split = enable != 0;
+  // a captured registration has the choice baked in
+  if (c->graph_exec) { hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
+  c->graph_key.clear();
   return 0;
 }
 

@@ -108,8 +108,15 @@ struct AggArgs {
   const float *W6 = nullptr, *b6 = nullptr;         // mlp_proj [64][64]
   float* desc = nullptr;                            // [clouds][n][64]
   int n = 0, clouds = 0;
+  // agg_chain_h.hip only: the fp16 split (high, low part; same [Cout][Cin] layout) of W2 .. W6, made at weight load
+  const void* Wh[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  const void* Wl[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 bool launch_agg_chain(const AggArgs& a, hipStream_t st);
+// the same chain with its five wide layers as three fp16 MFMAs per product (fp32 accuracy, 3/16 of the fp32 MFMA time);
+// false => split weights missing
+bool launch_agg_chain_h(const AggArgs& a, hipStream_t st);
+void split_weights_f16(const float* w, size_t n, uint16_t* hi, uint16_t* lo);   // host: x -> fp16(x), fp16(x - fp16(x))
 
 // select.hip — feat / label pipelines (model.py:650-651, :682-697)
 size_t topk_scratch_bytes(int clouds, int n);

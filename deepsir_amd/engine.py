@@ -476,6 +476,10 @@ class Engine:
         """A/B switch: off = the exhaustive exact-fp32 arg-min kernel throughout (same bits, include/dsir.h)."""
         self._call(self.lib.dsir_enable_screen(self.h, 1 if on else 0))
 
+    def enable_agg_split(self, on=True):
+        """A/B switch: fp16-split aggregation chain (default) vs the exact-fp32 chain (include/dsir.h, dsir_enable_agg_split)."""
+        self._call(self.lib.dsir_enable_agg_split(self.h, 1 if on else 0))
+
     SCREEN_STAT_NAMES = ("screened_searches", "rows_searched", "rows_undecided", "pairs_exhaustive", "exhaustive_searches")
 
     def screen_stats(self, reset=True) -> Dict[str, int]:
@@ -581,6 +585,10 @@ class EnginePool:
     def enable_screen(self, on=True):
         for e in self.engines:
             e.enable_screen(on)
+
+    def enable_agg_split(self, on=True):
+        for e in self.engines:
+            e.enable_agg_split(on)
 
     def screen_stats(self, reset=True) -> Dict[str, int]:
         tot: Dict[str, int] = {}

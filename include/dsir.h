@@ -293,6 +293,12 @@ int dsir_match_timer2(dsir_ctx* ctx, int reset, double* op_ms, double* kernel_ms
 /* A/B switch (measurement): 0 = dsir_register always takes the exhaustive exact-fp32 arg-min kernel, 1 (default) = the
  * fp16-screened path for large problems.  Both return the same bits.  Initialised from DSIR_NO_SCREEN. */
 int dsir_enable_screen(dsir_ctx* ctx, int enable);
+/* A/B switch (measurement / test): 1 (default) = the five wide layers of the aggregation chain (mlp_att 32 -> 64 -> 128 -> 256 ->
+ * 64, mlp_proj; network/model.py:223-233) run as fp16-split products on the fp16 matrix pipe (csrc/agg_chain_h.hip: each fp32
+ * operand = two fp16 numbers, three MFMAs per product, fp32 accumulation - fp32 accuracy, descriptors within ~1e-7 of the
+ * fp32 kernel's); 0 = the exact-fp32 chain (csrc/agg_chain.hip), bit-identical to the unfused layer-by-layer launches.
+ * Initialised from DSIR_AGG_F32 (set => 0). */
+int dsir_enable_agg_split(dsir_ctx* ctx, int enable);
 /* Same launches, bracketed on the DEVICE's constant-rate clock inside the kernel (first wave start .. last wave end,
  * the quantity a kernel trace reports): unlike the HIP-event bracket it does not include time the launch spends
  * queued behind other streams' kernels when several engines share the GPU. */

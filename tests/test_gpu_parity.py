@@ -694,3 +694,35 @@ def test_screened_argmin_shapes(P, J, K):
     scr, _ = eng.nn_match_screened(ta, tb)
     assert np.array_equal(scr.cpu().numpy(), exact)
     eng.close()
+
+
+@pytest.mark.parametrize("n,clouds,extent,wseed,variant", [(5000, 6, 3.0, 0, "plain"), (1357, 2, 3.0, 2, "separated"), (16384, 2, 50.0, 1, "plain"),
+                                                           (700, 1, 3.0, 3, "plain")])
+def test_agg_chain_split_matches_fp32_chain(n, clouds, extent, wseed, variant):
+    """csrc/agg_chain_h.hip (the aggregation chain's wide layers as fp16-split products: three fp16 MFMAs per fp32 product,
+    fp32 accumulation) against csrc/agg_chain.hip (exact-fp32 MFMA, bit-identical to the layer-by-layer launches) on the same
+    inputs through dsir_aggregate: unit descriptors within 2e-6 (measured ~1e-7: the size of fp32's own summation-order noise
+    on these 64..256-term sums, and 10 x below the 2e-5 at which the descriptors are compared with the reference's,
+    test_stages_vs_oracle_and_golden).  Both large (128 points per block) and small launches, ragged n."""
+    from deepsir_amd.arch import NetConfig
+    from deepsir_amd.engine import Engine
+    from deepsir_amd.weights import generate_state_dict
+    cfg = NetConfig(feat_len=3)
+    eng = Engine(cfg, 0, max_points=max(n, 1024), max_pairs=max(1, (clouds + 1) // 2))
+    eng.load_state_dict(generate_state_dict(cfg, wseed, variant))
+    rng = np.random.Generator(np.random.Philox(key=n + clouds))
+    xyz = cu(rng.uniform(-extent if extent > 3 else 0.0, extent, (clouds, n, 3)).astype(np.float32))
+    feat = cu(rng.standard_normal((clouds, n, 64)).astype(np.float32))
+    score = cu(rng.uniform(0, 1, (clouds, n)).astype(np.float32))
+    eng.enable_agg_split(False)
+    ref = eng.aggregate(xyz, feat, score).clone()
+    eng.enable_agg_split(True)
+    got = eng.aggregate(xyz, feat, score)
+    d = (got.double() - ref.double()).abs()
+    norms = got.double().norm(dim=2)
+    print(f"[agg-split] n {n} x {clouds} clouds ({variant}): max |d desc| {float(d.max()):.2e}, mean {float(d.mean()):.2e}, "
+          f"row-L2 max {float((got.double() - ref.double()).norm(dim=2).max()):.2e}; |desc| in [{float(norms.min()):.7f}, {float(norms.max()):.7f}]")
+    assert torch.isfinite(got).all()
+    assert float(d.max()) <= 2e-6
+    assert not torch.equal(got, ref)          # different arithmetic: identical bits would mean the switch is dead
+    eng.close()
