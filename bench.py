@@ -365,7 +365,7 @@ def main():
     screened = sstats["screened_searches"] > 0
 
     # ------------------------------------------------------------------ rank-0 extras (outside the timed region)
-    model_only = single = single_ex = companion = latency = training = None
+    model_only = single = single_ex = companion = latency = training = line_stress = None
     checks = []
     if a.timed_only:
         a.no_cpu_baseline = a.no_latency = a.no_companion = True
@@ -438,6 +438,34 @@ def main():
                          "note": "dsir_enable_screen(0): every arg-min by the exhaustive exact-fp32 MFMA kernel (csrc/nn_match.hip); "
                                  "same results bit for bit"}
             eng.enable_screen(True)
+
+        # the screening under descriptor distributions it cannot thin out as well: the same step with other seeded weight
+        # variants (companions, never `value`): 'separated' (descriptor head scaled up) and 'clustered:S' (all descriptors in a
+        # cap of angular radius ~S: what large planar regions do under a trained checkpoint).  exhaustive_argmin is the floor.
+        if screened and not a.no_companion and variant == "plain":
+            stress = {}
+            for var in ("separated", "clustered:0.3", "clustered:0.1", "clustered:0.03"):
+                eng.load_state_dict(generate_state_dict(cfg, 0, var))
+                step(); eng.sync()
+                eng.screen_stats(reset=True)
+                reps = max(2, min(a.steps, 3))
+                t1 = time.perf_counter()
+                for _ in range(reps):
+                    step()
+                eng.sync()
+                t1 = time.perf_counter() - t1
+                st_ = eng.screen_stats(reset=True)
+                stress[var] = {"value": round(P * reps / t1, 1), "unit": "pairs/s",
+                               "undecided_row_rate": round(st_["rows_undecided"] / max(st_["rows_searched"], 1), 5),
+                               "pairs_searched_exhaustively": st_["pairs_exhaustive"], "pair_searches": st_["screened_searches"] * P_launch}
+            eng.load_state_dict(sd)
+            step(); eng.sync()          # out_buf holds the headline configuration's results again (parity_check compares with them)
+            stress["note"] = ("same step, other seeded weight variants (deepsir_amd/weights.py): how far `value` falls towards "
+                              "`exhaustive_argmin` as descriptors cluster; results stay exact in every case (undecided rows go to the "
+                              "exact fp32 kernel)")
+            line_stress = stress
+        else:
+            line_stress = None
 
         # batch-1 latency (the reference's own evaluation mode, test.py:56 BATCH_SIZE = 1): one pair in flight,
         # launch sequence replayed from a hipGraph.  Reported beside the throughput number, not as `value`.
@@ -606,6 +634,8 @@ def main():
                                          "the timed region; workload dependent (random weights here, checkpoint absent)"}
         if companion is not None:
             line["exhaustive_argmin"] = companion
+        if line_stress is not None:
+            line["screening_stress"] = line_stress
         if model_only is not None:
             line["model_only"] = model_only
         if latency is not None:

@@ -20,6 +20,15 @@ __device__ __forceinline__ void st_f32(float* base, uint32_t byte_off, float v) 
   *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byte_off) = v;
 }
 
+// XCD-aware work mapping: the hardware deals workgroups round-robin over the 8 XCDs (id & 7), each with its own L2.  This
+// bijection of [0, nwg) hands every XCD a CONTIGUOUS range of logical work items, so that items ordered (cloud, block) keep
+// a cloud's gathered rows in ONE L2 instead of replicating them through eight.  Speed only: which workgroup computes an
+// item never changes its result.
+__device__ __forceinline__ int xcd_contiguous(int id, int nwg) {
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = id & 7;
+  return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3);
+}
+
 // index half of a packed (order-preserving distance bits << 32 | column) arg-min slot.  A slot still at its preset
 // (all ones: every distance of the row was NaN, nothing ever won) yields 0, never -1: consumers gather by it.
 __device__ __forceinline__ int32_t packed_index(unsigned long long p) {

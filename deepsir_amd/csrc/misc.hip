@@ -52,13 +52,15 @@ __global__ __launch_bounds__(256) void residual_combine_kernel(const float* __re
 // out[i][c] = max over the 16 pooled neighbours ("random sampling", RandLANet.py:374-391)
 __global__ __launch_bounds__(256) void gather_max_kernel(const float* __restrict__ in, int64_t in_cs,
                                                          const int32_t* __restrict__ idx, int64_t idx_cs, int C,
-                                                         int rows_out, float* __restrict__ out) {
-  const int cloud = blockIdx.y;
+                                                         int rows_out, float* __restrict__ out, int bpc) {
+  // 1-D grid of bpc workgroups per cloud, XCD-aware: a cloud's workgroups share one L2 (every input row is gathered ~4 times)
+  const int wi = xcd_contiguous(blockIdx.x, gridDim.x);
+  const int cloud = wi / bpc, bx = wi % bpc;
   const int C4 = C >> 2;
   const int64_t total4 = (int64_t)rows_out * C4;
   const float* src = in + cloud * in_cs;
   float4* o4 = reinterpret_cast<float4*>(out + (int64_t)cloud * rows_out * C);
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total4; e += (int64_t)gridDim.x * blockDim.x) {
+  for (int64_t e = (int64_t)bx * blockDim.x + threadIdx.x; e < total4; e += (int64_t)bpc * blockDim.x) {
     const int i = (int)(e / C4), c = (int)(e % C4) * 4;
     const int32_t* nb = idx + cloud * idx_cs + (int64_t)i * kKnn;
     float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
@@ -76,9 +78,11 @@ __global__ __launch_bounds__(256) void gather_max_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void gather_max_combine_kernel(const float* __restrict__ a, GnRef ga,
                                                                  const float* __restrict__ b, GnRef gb, int rows_in,
                                                                  const int32_t* __restrict__ idx, int64_t idx_cs, int C,
-                                                                 int rows_out, float* __restrict__ out) {
+                                                                 int rows_out, float* __restrict__ out, int bpc) {
   __shared__ float sa[512], ha[512], sb[512], hb[512];
-  const int cloud = blockIdx.y;
+  // 1-D grid of bpc workgroups per cloud, XCD-aware: a cloud's workgroups share one L2 (every input row is gathered ~4 times)
+  const int wi = xcd_contiguous(blockIdx.x, gridDim.x);
+  const int cloud = wi / bpc, bx = wi % bpc;
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     gn_scale_shift(ga, cloud, c, C, sa[c], ha[c]);
     gn_scale_shift(gb, cloud, c, C, sb[c], hb[c]);
@@ -89,7 +93,7 @@ __global__ __launch_bounds__(256) void gather_max_combine_kernel(const float* __
   const float* pa = a + (int64_t)cloud * rows_in * C;
   const float* pb = b + (int64_t)cloud * rows_in * C;
   float4* o4 = reinterpret_cast<float4*>(out + (int64_t)cloud * rows_out * C);
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total4; e += (int64_t)gridDim.x * blockDim.x) {
+  for (int64_t e = (int64_t)bx * blockDim.x + threadIdx.x; e < total4; e += (int64_t)bpc * blockDim.x) {
     const int i = (int)(e / C4), c = (int)(e % C4) * 4;
     const int32_t* nb = idx + cloud * idx_cs + (int64_t)i * kKnn;
     const float4 s1 = *reinterpret_cast<const float4*>(&sa[c]), h1 = *reinterpret_cast<const float4*>(&ha[c]);
@@ -205,15 +209,17 @@ void launch_residual_combine(const float* a, GnRef ga, const float* b, GnRef gb,
 void launch_gather_max(const float* in, int64_t in_cs, const int32_t* idx, int64_t idx_cs, int C, int rows_out,
                        int clouds, float* out, hipStream_t st) {
   if (rows_out <= 0) return;
-  dim3 grid(grid_for((int64_t)rows_out * C / 4), clouds);
-  hipLaunchKernelGGL(gather_max_kernel, grid, dim3(256), 0, st, in, in_cs, idx, idx_cs, C, rows_out, out);
+  const int bpc = grid_for((int64_t)rows_out * C / 4);
+  hipLaunchKernelGGL(gather_max_kernel, dim3((unsigned)((int64_t)bpc * clouds)), dim3(256), 0, st, in, in_cs, idx, idx_cs, C, rows_out, out,
+                     bpc);
 }
 
 void launch_gather_max_combine(const float* a, GnRef ga, const float* b, GnRef gb, int rows_in, const int32_t* idx,
                                int64_t idx_cs, int C, int rows_out, int clouds, float* out, hipStream_t st) {
   if (rows_out <= 0) return;
-  dim3 grid(grid_for((int64_t)rows_out * C / 4), clouds);
-  hipLaunchKernelGGL(gather_max_combine_kernel, grid, dim3(256), 0, st, a, ga, b, gb, rows_in, idx, idx_cs, C, rows_out, out);
+  const int bpc = grid_for((int64_t)rows_out * C / 4);
+  hipLaunchKernelGGL(gather_max_combine_kernel, dim3((unsigned)((int64_t)bpc * clouds)), dim3(256), 0, st, a, ga, b, gb, rows_in, idx,
+                     idx_cs, C, rows_out, out, bpc);
 }
 
 void launch_narrow_i64(const int64_t* src, int32_t* dst, int64_t n, hipStream_t st) {
