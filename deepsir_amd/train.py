@@ -436,19 +436,29 @@ class RandlaTrainer(_ParamStore):
         self.ops.conv_dw(ds, cat, self.grads[name + ".fc.weight"], None)
         return self.ops.conv_dx(ds, self.params[name + ".fc.weight"], into=dcat)
 
-    def _res_block(self, tape: RandlaTape, p: str, feat: torch.Tensor, xyz: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
-        """Dilated_res_block + Building_block (RandLANet.py:160-230); feat [clouds][n][Cin] -> [clouds][n][2 d]."""
+    def _res_block(self, tape: RandlaTape, p: str, feat: torch.Tensor, xyz: torch.Tensor, idx: torch.Tensor,
+                   shared: Optional[dict] = None) -> torch.Tensor:
+        """Dilated_res_block + Building_block (RandLANet.py:160-230); feat [clouds][n][Cin] -> [clouds][n][2 d].
+        ``shared`` (see ``forward``): the position-encoding branch (lfa.mlp1 on the relative position code, lfa.mlp2 on top)
+        computed by the first pass that carries this dict and re-used by the later ones."""
         clouds, n, cin = feat.shape
         d = self.params[p + ".mlp2.conv.weight"].shape[1]
         h = d // 2
         flat_idx = idx.reshape(clouds, n * K_NN)
         f = self._mlp2d(tape, p + ".mlp1", feat.reshape(clouds * n, cin), clouds)                    # [clouds n][h]
-        enc = self._mlp2d(tape, p + ".lfa.mlp1", self.ops.relpos(xyz, idx), clouds)                 # [clouds n 16][h]
+        sh = None if shared is None else shared.get(p)
+        if sh is None:
+            stape = tape if shared is None else RandlaTape()
+            enc = self._mlp2d(stape, p + ".lfa.mlp1", self.ops.relpos(xyz, idx), clouds)            # [clouds n 16][h]
+            enc2 = self._mlp2d(stape, p + ".lfa.mlp2", enc, clouds)
+            if shared is not None:
+                shared[p] = {"tape": stape, "enc": enc, "enc2": enc2, "denc": None, "denc2": None, "clouds": clouds}
+        else:
+            enc, enc2 = sh["enc"], sh["enc2"]
         cat1 = self.ops.empty(clouds * n * K_NN, d)
         self.ops.gather(f.reshape(clouds, n, h), flat_idx, cat1, 0)
         cat1[:, h:] = enc
         agg1 = self._att(tape, p + ".lfa.att_pooling_1", cat1, clouds, n)                           # [clouds n][h]
-        enc2 = self._mlp2d(tape, p + ".lfa.mlp2", enc, clouds)
         cat2 = self.ops.empty(clouds * n * K_NN, d)
         self.ops.gather(agg1.reshape(clouds, n, h), flat_idx, cat2, 0)
         cat2[:, h:] = enc2
@@ -459,7 +469,8 @@ class RandlaTrainer(_ParamStore):
         tape.misc[p] = (out, flat_idx, clouds, n, h, d, cin)
         return out.reshape(clouds, n, 2 * d)
 
-    def _res_block_bwd(self, tape: RandlaTape, p: str, dout: torch.Tensor, need_dx: bool = True) -> Optional[torch.Tensor]:
+    def _res_block_bwd(self, tape: RandlaTape, p: str, dout: torch.Tensor, need_dx: bool = True,
+                       shared: Optional[dict] = None) -> Optional[torch.Tensor]:
         out, flat_idx, clouds, n, h, d, cin = tape.misc[p]
         o = self.ops
         dsum = o.add_leaky_bwd(dout.reshape(clouds * n, 2 * d), out)
@@ -467,24 +478,55 @@ class RandlaTrainer(_ParamStore):
         dagg2 = self._mlp2d_bwd(tape, p + ".mlp2", dsum)
         dcat2 = self._att_bwd(tape, p + ".lfa.att_pooling_2", dagg2, clouds, n)
         dagg1 = o.scatter_add(dcat2, 0, h, flat_idx, n)                                               # [clouds][n][h]
-        denc = self._mlp2d_bwd(tape, p + ".lfa.mlp2", dcat2[:, h:].contiguous())                      # w.r.t. enc
-        dcat1 = self._att_bwd(tape, p + ".lfa.att_pooling_1", dagg1.reshape(clouds * n, h), clouds, n)
-        df = o.scatter_add(dcat1, 0, h, flat_idx, n)
-        o.axpy(1.0, dcat1[:, h:].contiguous(), denc)
-        self._mlp2d_bwd(tape, p + ".lfa.mlp1", denc, need_dx=False)                                   # its input is data
+        if shared is None:
+            denc = self._mlp2d_bwd(tape, p + ".lfa.mlp2", dcat2[:, h:].contiguous())                  # w.r.t. enc
+            dcat1 = self._att_bwd(tape, p + ".lfa.att_pooling_1", dagg1.reshape(clouds * n, h), clouds, n)
+            df = o.scatter_add(dcat1, 0, h, flat_idx, n)
+            o.axpy(1.0, dcat1[:, h:].contiguous(), denc)
+            self._mlp2d_bwd(tape, p + ".lfa.mlp1", denc, need_dx=False)                               # its input is data
+        else:
+            # shared position-encoding branch: only the upstream gradients are collected here (d enc2 from the second pooling,
+            # d enc from the first); the branch itself is walked back once, by backward_shared
+            sh = shared[p]
+            sh["denc2"] = o.acc(sh["denc2"], dcat2[:, h:])
+            dcat1 = self._att_bwd(tape, p + ".lfa.att_pooling_1", dagg1.reshape(clouds * n, h), clouds, n)
+            df = o.scatter_add(dcat1, 0, h, flat_idx, n)
+            sh["denc"] = o.acc(sh["denc"], dcat1[:, h:])
         d1 = self._mlp2d_bwd(tape, p + ".mlp1", df.reshape(clouds * n, h), need_dx)
         if not need_dx:
             return None
         o.axpy(1.0, d1, dfeat)
         return dfeat.reshape(clouds, n, cin)
 
+    def backward_shared(self, shared: dict) -> None:
+        """The backward of the position-encoding branches ``shared`` holds, ONCE for all the passes that used them: the
+        upstream gradients of those passes were summed by ``backward`` (every operator on the way back is linear in the
+        incoming gradient - convolution, GroupNorm for fixed forward values, LeakyReLU - so the sum of the passes' gradients
+        is the gradient of the summed upstream, in real arithmetic; the reference's autograd walks the branch once per
+        registration iteration and adds the results)."""
+        o = self.ops
+        o.begin()
+        for p, sh in shared.items():
+            if sh["denc2"] is None and sh["denc"] is None:
+                continue
+            denc = self._mlp2d_bwd(sh["tape"], p + ".lfa.mlp2", sh["denc2"])
+            o.axpy(1.0, sh["denc"], denc)
+            self._mlp2d_bwd(sh["tape"], p + ".lfa.mlp1", denc, need_dx=False)                         # its input is data
+            sh["denc"] = sh["denc2"] = None
+
     # ------------------------------------------------------------------ the network
     def forward(self, features: torch.Tensor, xyz_multi: torch.Tensor, neigh_idx: torch.Tensor, sub_idx: torch.Tensor,
-                interp_idx: torch.Tensor, dropout_mask: Optional[torch.Tensor] = None, update_running_stats: bool = True):
+                interp_idx: torch.Tensor, dropout_mask: Optional[torch.Tensor] = None, update_running_stats: bool = True,
+                shared: Optional[dict] = None):
         """RandLA.forward in TRAINING mode (RandLANet.py:311-372; train.py:379 ``my_model.train()``): GroupNorm as always,
         the two BatchNorm1d of ``fc_label`` on batch statistics (running statistics updated with momentum 0.1), Dropout(0.5)
         with ``dropout_mask`` ([clouds][N][64] uint8 keep flags; None = keep everything, i.e. dropout off).
         features [clouds][N][feat_in]; pyramids as ``Engine.knn_pyramid`` returns them (int32).
+        shared: a dict the caller keeps across SEVERAL forward passes on the SAME pyramid with the SAME weights (the
+        registration iterations of one `align` step, model.py:575: the inlier model always runs on the src pyramid): the
+        position-encoding branch of every level - lfa.mlp1 on the relative position code and lfa.mlp2 on top, the two
+        heaviest layers of a block (n x 16 rows) - depends on nothing else, so the first pass computes it and the later
+        ones re-use its outputs; hand the same dict to every ``backward`` and finish with ``backward_shared``.
         -> logits [clouds][N][num_classes], tape."""
         o = self.ops
         o.begin()
@@ -500,7 +542,8 @@ class RandlaTrainer(_ParamStore):
         args: List[torch.Tensor] = []
         for l in range(L):
             a, b = off[l], off[l + 1]
-            enc = self._res_block(tape, f"{pf}.dilated_res_blocks.{l}", x, xyz_multi[:, a:b].contiguous(), neigh_idx[:, a:b].contiguous())
+            enc = self._res_block(tape, f"{pf}.dilated_res_blocks.{l}", x, xyz_multi[:, a:b].contiguous(), neigh_idx[:, a:b].contiguous(),
+                                  shared)
             x, arg = o.maxpool_fwd(enc, sub_idx[:, soff[l]:soff[l + 1]].contiguous())                  # random_sample (:374-391)
             args.append(arg)
             if l == 0:
@@ -546,7 +589,7 @@ class RandlaTrainer(_ParamStore):
         tape.misc["feat"] = feat.reshape(clouds, N, -1)            # RandLA.forward's first output (before the dropout)
         return h.reshape(clouds, N, self.num_classes), tape
 
-    def backward(self, tape: RandlaTape, dlogits: torch.Tensor, dfeat: Optional[torch.Tensor] = None) -> None:
+    def backward(self, tape: RandlaTape, dlogits: torch.Tensor, dfeat: Optional[torch.Tensor] = None, shared: Optional[dict] = None) -> None:
         """Accumulates d loss / d parameter into ``self.grads`` (call ``zero_grad`` between steps, not between the
         registration iterations of one step: their gradients add up, as autograd's do).  dlogits [clouds][N][num_classes];
         dfeat [clouds][N][out_feat_dim] (optional): gradient w.r.t. the feature output ``tape.misc['feat']``."""
@@ -584,7 +627,7 @@ class RandlaTrainer(_ParamStore):
             denc = o.maxpool_bwd(dskips[l + 1].contiguous(), net["args"][l], n[l])                   # [clouds][n_l][2 d_l]
             if l == 0 and dskips[0] is not None:
                 o.axpy(1.0, dskips[0].contiguous(), denc)
-            dfeat = self._res_block_bwd(tape, f"{pf}.dilated_res_blocks.{l}", denc, need_dx=True)
+            dfeat = self._res_block_bwd(tape, f"{pf}.dilated_res_blocks.{l}", denc, need_dx=True, shared=shared)
             if l > 0:
                 dskips[l] = o.acc(dskips[l], dfeat).reshape(shapes[l])
             else:
@@ -646,6 +689,7 @@ def forward_align_train(engine, inlier: RandlaTrainer, extractor: RandlaTrainer,
     xyz_r, f_r, sc_r = side["ref"]
     P, J, _ = xyz0.shape
     idxs, logits, tapes, invalid = [], [], [], []
+    shared: dict = {}                       # the inlier model's position-encoding branch: once per step (RandlaTrainer.forward)
     cur = xyz0
     for it in range(n_iter):
         d_s, _ = aggregation.forward(cur, f_s, sc_s, second_normalize=False)
@@ -653,14 +697,15 @@ def forward_align_train(engine, inlier: RandlaTrainer, extractor: RandlaTrainer,
         idx = engine.nn_match(d_s.contiguous(), d_r.contiguous())
         cat = o.inlier_input(cur, xyz_r, idx, None)
         m = masks.get("inlier")
-        lg, tape = inlier.forward(cat, batch["src_xyz"], batch["src_neigh"], batch["src_sub"], batch["src_interp"], None if m is None else m[it])
+        lg, tape = inlier.forward(cat, batch["src_xyz"], batch["src_neigh"], batch["src_sub"], batch["src_interp"], None if m is None else m[it],
+                                  shared=shared)
         lg = lg.reshape(P, J)
         T_it, bad_it = engine.kabsch(cur, cat[:, :, 3:].contiguous(), o.sigmoid(lg.contiguous()))
         invalid.append(bad_it)
         cur = o.inlier_input(cur, xyz_r, idx, T_it)[:, :, :3].contiguous()        # xyz_src <- R_t.detach() xyz_src (model.py:587)
         idxs.append(idx); logits.append(lg); tapes.append(tape)
     return {"idx": torch.stack(idxs).contiguous(), "logits": torch.stack(logits).contiguous(), "tapes": tapes, "xyz_src": xyz0,
-            "xyz_ref": xyz_r, "invalid": invalid}
+            "xyz_ref": xyz_r, "invalid": invalid, "shared": shared}
 
 
 def train_step_align_full(engine, inlier: RandlaTrainer, extractor: RandlaTrainer, aggregation: "AggregationTrainer", batch: dict,
@@ -675,7 +720,8 @@ def train_step_align_full(engine, inlier: RandlaTrainer, extractor: RandlaTraine
     labels = None if labels_fn is None else labels_fn(fw["idx"])
     out = engine.align_loss_backward(fw["xyz_src"], fw["xyz_ref"], fw["idx"], fw["logits"], labels, transform_gt, **(loss_kwargs or {}))
     for it in range(n_iter):
-        inlier.backward(fw["tapes"][it], out["grad_logits"][it])
+        inlier.backward(fw["tapes"][it], out["grad_logits"][it], shared=fw["shared"])
+    inlier.backward_shared(fw["shared"])
     all_reduce_gradients(inlier, dist)
     bad = inlier.grads_have_nan() or any_pose_invalid(fw["invalid"], dist)      # train.py:437-446: NaN gradient OR invalid_gradient
     if apply and not bad:
@@ -705,19 +751,21 @@ def train_step_align(engine, trainer: RandlaTrainer, batch: dict, result: dict, 
     trainer.zero_grad()
     logits, tapes = [], []
     masks = dropout_keep_masks(dropout_seed, (n_iter, P, N, trainer.cfg.out_feat_dim), dev)
+    shared: dict = {}                       # position-encoding branch of the inlier model: once per step (RandlaTrainer.forward)
     trainer.ops.begin()
     for it in range(n_iter):
         # the src cloud moved by the previous cumulative pose (model.py:587; R_t.detach()) next to its correspondences
         cat = trainer.ops.inlier_input(xyz_s, xyz_r, idx[it], None if it == 0 else T[:, it - 1])
         mask = None if masks is None else masks[it]
-        lg, tape = trainer.forward(cat, batch["src_xyz"], batch["src_neigh"], batch["src_sub"], batch["src_interp"], mask)
+        lg, tape = trainer.forward(cat, batch["src_xyz"], batch["src_neigh"], batch["src_sub"], batch["src_interp"], mask, shared=shared)
         logits.append(lg.reshape(P, N))
         tapes.append(tape)
     lg_all = torch.stack(logits).contiguous()
     out = engine.align_loss_backward(xyz_s, xyz_r, idx, lg_all, labels, transform_gt, **(loss_kwargs or {}))
     g = out["grad_logits"]
     for it in range(n_iter):
-        trainer.backward(tapes[it], g[it])
+        trainer.backward(tapes[it], g[it], shared=shared)
+    trainer.backward_shared(shared)
     all_reduce_gradients(trainer, dist)
     bad = trainer.grads_have_nan() or any_pose_invalid([result.get("invalid")], dist)   # train.py:437-446
     if apply and not bad:
@@ -928,16 +976,19 @@ class AlignTrainStep:
         tr = self.tr
         tr.ops.begin()
         self.tapes = []
+        self.shared = {}                    # position-encoding branch: computed by iteration 0, re-used by the others
         for it in range(self.n_iter):
             cat = tr.ops.inlier_input(self.xyz_s, self.xyz_r, self.idx[it], None if it == 0 else self.T[:, it - 1])
-            lg, tape = tr.forward(cat, self.src_xyz, self.neigh, self.sub, self.interp, None if self.masks is None else self.masks[it])
+            lg, tape = tr.forward(cat, self.src_xyz, self.neigh, self.sub, self.interp, None if self.masks is None else self.masks[it],
+                                  shared=self.shared)
             self.logits[it].copy_(lg.reshape(self.P, self.N))
             self.tapes.append(tape)
 
     def _backward_all(self) -> None:
         self.tr.zero_grad()
         for it in range(self.n_iter):
-            self.tr.backward(self.tapes[it], self.grad[it])
+            self.tr.backward(self.tapes[it], self.grad[it], shared=self.shared)
+        self.tr.backward_shared(self.shared)
 
     def step(self, batch: dict, result: dict, transform_gt, labels=None, lr: float = 1e-3, dropout_seed: Optional[int] = None,
              loss_kwargs: Optional[dict] = None, apply: bool = True, dist=None) -> dict:

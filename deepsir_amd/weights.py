@@ -28,9 +28,10 @@ def generate_state_dict(cfg: NetConfig, seed: int = 0, variant: str = "plain") -
     descriptors of distinct points are far apart relative to fp32 rounding —
     a well-conditioned arg-min regime.
     variant "clustered:<s>" (0 < s < 1; bench.py --cluster-descriptors): the descriptor head's weight scaled DOWN by s
-    under a fixed bias of norm ~1.6, so that all aggregated descriptors sit in a cap of angular radius ~s around one
-    direction and the distances between them shrink by ~s^2 - what the descriptors of large planar regions do under a
-    trained checkpoint; the unfriendly regime for any screening of the arg-min.
+    under a fixed bias of norm 1.6, so that all aggregated descriptors crowd around one direction and the distances
+    between them shrink by ~s^2 (median top-2 gap of a 2048-point pair: 9e-3 plain, 1.5e-3 at s = 0.03, 1.9e-5 at
+    s = 0.003) - what the descriptors of large planar regions do under a trained checkpoint; the unfriendly regime for
+    any screening of the arg-min.
     """
     rng = np.random.Generator(np.random.Philox(key=int(seed) + 0x5EED))
     out: "OrderedDict[str, np.ndarray]" = OrderedDict()
