@@ -34,7 +34,8 @@ struct Mlp2dW { const float *W = nullptr, *b = nullptr, *gamma = nullptr, *beta 
 struct AttW { const float* fc = nullptr; const float* fc_g = nullptr; int d = 0; Mlp2dW mlp; };   // fc_g: see up_fc_g
 struct BlockW { Mlp2dW mlp1, lfa1, lfa2, mlp2, skip; AttW att1, att2; int d_in = 0, d = 0; };
 struct LinW { const float *W = nullptr, *b = nullptr; int cin = 0, cout = 0; };
-struct RandlaW { Mlp2dW pre; BlockW blk[4]; Mlp2dW mid; Mlp2dW dec[4]; const float* out_w = nullptr; int dec_out = 0; LinW fc[3]; int cin = 0, ncls = 0; };
+struct RandlaW { Mlp2dW pre; BlockW blk[4]; Mlp2dW mid; Mlp2dW dec[4]; const float* out_w = nullptr; int dec_out = 0; LinW fc[3]; int cin = 0, ncls = 0;
+                 const void* head_wh[4] = {}; const void* head_wl[4] = {}; };   // fp16 split of mlp_out + fc_label (head_mlp_h.hip)
 struct NetW { RandlaW feat, inl; LinW mlp_feat[3], mlp_att[5], mlp_proj; };
 
 // ------------------------------------------------------------------ workspace
@@ -542,7 +543,13 @@ int randla_forward(dsir_ctx* c, const RandlaW& w, const Seg& in0, const Seg* in1
     h.W1 = w.out_w; h.W2 = w.fc[0].W; h.b2 = w.fc[0].b; h.W3 = w.fc[1].W; h.b3 = w.fc[1].b; h.W4 = w.fc[2].W; h.b4 = w.fc[2].b;
     h.ncls = w.ncls; h.M = n0; h.clouds = py.clouds; h.feat_out = feat_out; h.logits_out = logits_out;
     if (c->ws.overflow) return fail(c, "workspace exhausted in randla_forward (raise max_points / max_pairs)");
-    fused = launch_head_mlp(h, st);
+    // default: the head's four layers as fp16-split products (head_mlp_h.hip; fp32 accuracy); dsir_enable_agg_split(0) /
+    // DSIR_AGG_F32: the exact-fp32 head, bit-identical to the four separate launches
+    if (c->agg_split) {
+      for (int k = 0; k < 4; ++k) { h.Wh[k] = w.head_wh[k]; h.Wl[k] = w.head_wl[k]; }
+      fused = launch_head_mlp_h(h, st);
+    }
+    if (!fused) fused = launch_head_mlp(h, st);
   }
   LinW ow; ow.W = w.out_w; ow.b = nullptr; ow.cin = w.dec_out; ow.cout = g.out_feat_dim;
   Act feat;
@@ -808,16 +815,32 @@ int dsir_finalize_weights(dsir_ctx* c) {
     for (int k = 0; k < 3; ++k) c->net.mlp_feat[k] = bind_lin(b, mf[k]);
     for (int k = 0; k < 5; ++k) c->net.mlp_att[k] = bind_lin(b, ma[k]);
     c->net.mlp_proj = bind_lin(b, mp);
-    // fp16 split of the five wide layers of the aggregation chain (BatchNorm already folded), agg_chain_h.hip
-    const LinOff* lay[5] = {&ma[1], &ma[2], &ma[3], &ma[4], &mp};
-    size_t total = 0, off[5];
-    for (int k = 0; k < 5; ++k) { off[k] = total; total += ((size_t)lay[k]->cin * lay[k]->cout + 63) & ~(size_t)63; }
+  }
+  {
+    // fp16 split (x -> fp16(x), fp16(x - fp16(x))) of the matrices the fp16-split kernels contract (BatchNorm already folded):
+    // the five wide layers of the aggregation chain (agg_chain_h.hip) and the per-point heads of both RandLA models
+    // (head_mlp_h.hip).  One blob: all high parts, then all low parts.
+    struct Req { size_t woff, n; const void** hi; const void** lo; };
+    std::vector<Req> reqs;
+    if (has_agg) {
+      const LinOff* lay[5] = {&ma[1], &ma[2], &ma[3], &ma[4], &mp};
+      for (int k = 0; k < 5; ++k) reqs.push_back({lay[k]->W, (size_t)lay[k]->cin * lay[k]->cout, &c->agg_wh[k], &c->agg_wl[k]});
+    }
+    auto head = [&](const RandlaOff& o, RandlaW& w) {
+      reqs.push_back({o.out_w, (size_t)c->cfg.out_feat_dim * o.dec_out, &w.head_wh[0], &w.head_wl[0]});
+      for (int k = 0; k < 3; ++k) reqs.push_back({o.fc[k].W, (size_t)o.fc[k].cin * o.fc[k].cout, &w.head_wh[k + 1], &w.head_wl[k + 1]});
+    };
+    head(fo, c->net.feat);
+    if (has_inl) head(io, c->net.inl);
+    size_t total = 0;
+    std::vector<size_t> off(reqs.size());
+    for (size_t k = 0; k < reqs.size(); ++k) { off[k] = total; total += (reqs[k].n + 63) & ~(size_t)63; }
     std::vector<uint16_t> h16(2 * total, 0);
-    for (int k = 0; k < 5; ++k)
-      split_weights_f16(u.blob.data() + lay[k]->W, (size_t)lay[k]->cin * lay[k]->cout, h16.data() + off[k], h16.data() + total + off[k]);
+    for (size_t k = 0; k < reqs.size(); ++k)
+      split_weights_f16(u.blob.data() + reqs[k].woff, reqs[k].n, h16.data() + off[k], h16.data() + total + off[k]);
     HIP_OK(c, hipMalloc((void**)&c->dweights16, h16.size() * sizeof(uint16_t)));
     HIP_OK(c, hipMemcpy(c->dweights16, h16.data(), h16.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-    for (int k = 0; k < 5; ++k) { c->agg_wh[k] = c->dweights16 + off[k]; c->agg_wl[k] = c->dweights16 + total + off[k]; }
+    for (size_t k = 0; k < reqs.size(); ++k) { *reqs[k].hi = c->dweights16 + off[k]; *reqs[k].lo = c->dweights16 + total + off[k]; }
   }
   c->finalized = true;
   return 0;

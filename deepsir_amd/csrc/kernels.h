@@ -92,8 +92,13 @@ struct HeadArgs {
   int ncls = 0, M = 0, clouds = 1;
   float* feat_out = nullptr;    // [clouds][M][64] or nullptr
   float* logits_out = nullptr;  // [clouds][M][ncls]
+  // head_mlp_h.hip only: the fp16 split (high, low; same [Cout][Cin] layout) of W1 .. W4, made at weight load
+  const void* Wh[4] = {nullptr, nullptr, nullptr, nullptr};
+  const void* Wl[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 bool launch_head_mlp(const HeadArgs& a, hipStream_t st);   // false => shape outside the fused envelope
+// the same head as fp16-split products on the fp16 matrix pipe (fp32 accuracy); false => split weights missing / outside the envelope
+bool launch_head_mlp_h(const HeadArgs& a, hipStream_t st);
 
 // agg_chain.hip — mlp_att chain + residual + mlp_proj + L2 normalise in one launch (model.py:223-233)
 struct AggArgs {

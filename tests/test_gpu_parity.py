@@ -726,3 +726,34 @@ def test_agg_chain_split_matches_fp32_chain(n, clouds, extent, wseed, variant):
     assert float(d.max()) <= 2e-6
     assert not torch.equal(got, ref)          # different arithmetic: identical bits would mean the switch is dead
     eng.close()
+
+
+@pytest.mark.parametrize("name,which", [("stage_n1024_s1", "feat_extractor"), ("e2e_n5000_s5", "feat_extractor"), ("e2e_n2048_s6_f4", "inlier_model")])
+def test_head_split_matches_fp32_head(name, which):
+    """csrc/head_mlp_h.hip (mlp_out + fc_label as fp16-split products, three fp16 MFMAs per fp32 product) against
+    csrc/head_mlp.hip (exact fp32, bit-identical to the four separate launches) through dsir_randla_forward: the 64-d
+    feature and the logits within 1e-5 of their scale (measured ~1e-6), for the feature extractor (19 classes) and the
+    inlier model (1 logit)."""
+    g, m, cfg, sd, data = build_case(name)
+    eng = engine_for(cfg, sd, name + "_head", max_points=max(8192, m["n"]))
+    n = m["n"]
+    if which == "feat_extractor":
+        feats = cu(np.concatenate([data["points_src"], data["points_ref"]], 0))
+    else:
+        rng = np.random.Generator(np.random.Philox(key=n))
+        feats = cu(rng.uniform(0, 3, (2, n, 6)).astype(np.float32))
+    xyz = cu(np.concatenate([data["points_src_xyz"], data["points_ref_xyz"]], 0))
+    neigh = cu(np.concatenate([data["points_src_neigh_idx"], data["points_ref_neigh_idx"]], 0), torch.int32)
+    sub = cu(np.concatenate([data["points_src_sub_idx"], data["points_ref_sub_idx"]], 0), torch.int32)
+    interp = cu(np.concatenate([data["points_src_interp_idx"], data["points_ref_interp_idx"]], 0), torch.int32)
+    eng.enable_agg_split(False)
+    f0, l0 = eng.randla_forward(which, feats, xyz, neigh, sub, interp)
+    f0, l0 = f0.clone(), l0.clone()
+    eng.enable_agg_split(True)
+    f1, l1 = eng.randla_forward(which, feats, xyz, neigh, sub, interp)
+    ef = float((f1.double() - f0.double()).abs().max() / f0.double().abs().max())
+    el = float((l1.double() - l0.double()).abs().max() / l0.double().abs().max())
+    print(f"[head-split] {name} {which}: feat rel err {ef:.2e} (scale {float(f0.abs().max()):.2f}), logits rel err {el:.2e} (scale {float(l0.abs().max()):.2f})")
+    assert torch.isfinite(f1).all() and torch.isfinite(l1).all()
+    assert ef <= 1e-5 and el <= 1e-5
+    assert not torch.equal(l0, l1)            # different arithmetic: identical bits would mean the switch is dead
