@@ -52,9 +52,28 @@ __device__ __forceinline__ int src_row(const Seg& s, int cloud, int row) {
   return s.idx ? s.idx[cloud * s.idx_cloud_stride + row] : row;
 }
 
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+// x[0..8) -> fp16(x), fp16(x - fp16(x)): the operand split of agg_chain_h.hip (three fp16 MFMAs per fp32 product)
+__device__ __forceinline__ void split8(const float* x, h8& h, h8& l) {
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const _Float16 t = (_Float16)x[k];
+    h[k] = t;
+    l[k] = (_Float16)(x[k] - (float)t);
+  }
+}
+
 template <int KQ, int NT, int EPI, int MODE, int SC = 0>   // SC: GemmArgs::s2_mode (EPI_ATT2 only)
 __global__ __launch_bounds__(256) void pw_stream_kernel(const GemmArgs p) {
   constexpr int BN = NT * 16;
+  // Attentive pooling (round 3): the score contraction of a 16-neighbour tile runs on the fp16 matrix pipe at fp32 accuracy -
+  // a lane's 8 or 16 contiguous channels ARE the A fragment of v_mfma_f32_16x16x32_f16 (k = 8 fq + j per 32-channel step, the
+  // same re-ordered k index as the fp32 form), each operand split into two fp16 numbers, three MFMAs per product: 12 / 24 fp16
+  // MFMAs (192 / 384 matrix-pipe cycles) per tile instead of 32 / 64 fp32 ones (1024 / 2048), which two waves per SIMD
+  // contend for.  Scores differ from the fp32 form's by ~1e-7 of their scale; the cached enc halves (SC 1 / 2) come from
+  // this same arithmetic, so hoisted and recomputed iterations still agree bit for bit.
+  constexpr bool kSplit = (EPI == EPI_ATT || EPI == EPI_ATT2) && (KQ == 8 || KQ == 16) && MODE == S_VEC;
+  constexpr int NS = kSplit ? KQ / 8 : 1;
   constexpr int CP = KQ * 4;  // padded Cin
   __shared__ float s_sc[CP];
   __shared__ float s_sh[CP];
@@ -156,6 +175,13 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const GemmArgs p) {
       }
     }
     bv[t] = (p.bias && col < p.Cout) ? p.bias[col] : 0.f;
+  }
+  h8 wh[kSplit ? NT : 1][NS], wl[kSplit ? NT : 1][NS];   // kSplit: the weight fragments as fp16 pairs (wf is dead after this)
+  if (kSplit) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int u = 0; u < NS; ++u) split8(&wf[t][8 * u], wh[t][u], wl[t][u]);
   }
   // vector mode: the chunk lies inside one segment
   const int C0 = p.seg[0].C;
@@ -311,10 +337,24 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const GemmArgs p) {
     } else {
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (kSplit) {
 #pragma unroll
-      for (int s = 0; s < KQ; ++s)
+        for (int u = 0; u < NS; ++u) {
+          h8 ah, al;
+          split8(&cur.v[8 * u], ah, al);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.v[s], wf[t][s], acc[t], 0, 0, 0);
+          for (int t = 0; t < NT; ++t) {
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wh[t][u], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wl[t][u], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wh[t][u], acc[t], 0, 0, 0);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int s = 0; s < KQ; ++s)
+#pragma unroll
+          for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.v[s], wf[t][s], acc[t], 0, 0, 0);
+      }
       if (SC == 1) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) s2p[t * 64] = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
