@@ -85,7 +85,8 @@ struct dsir_ctx {
   std::vector<HostParam> params;
   std::unordered_map<std::string, int> index;
   float* dweights = nullptr;
-  uint16_t* dweights16 = nullptr;        // fp16 split (high | low) of mlp_att[1..4] and mlp_proj for agg_chain_h.hip
+  uint16_t* dweights16 = nullptr;        // fp16 split of the WHOLE weight blob: high parts [0, n), low parts [n, 2 n), same offsets
+  size_t nweights = 0;                   // floats in dweights
   const void* agg_wh[5] = {}; const void* agg_wl[5] = {};
   bool finalized = false;
   NetW net;
@@ -352,6 +353,13 @@ struct Sched {
     c->stats_top += (size_t)clouds * groups * 2;
     return p;
   }
+  // the fp16 split of a weight matrix inside the context's blob (dsir_finalize_weights); off unless the split layers are on
+  void split_of(GemmArgs& a) const {
+    if (!c->agg_split || !c->dweights16 || a.W < c->dweights || a.W >= c->dweights + c->nweights) return;
+    const size_t off = (size_t)(a.W - c->dweights);
+    a.Wh = c->dweights16 + off;
+    a.Wl = c->dweights16 + c->nweights + off;
+  }
   static Seg seg_of(const Act& a, const int32_t* idx = nullptr, int64_t idx_cs = 0) {
     Seg s{};
     s.x = a.p; s.cloud_stride = (int64_t)a.rows * a.C; s.C = a.C; s.ld = a.C;
@@ -371,6 +379,7 @@ struct Sched {
     a.amode = A_SEGS; a.nseg = s1 ? 2 : 1; a.seg[0] = s0; if (s1) a.seg[1] = *s1;
     a.W = w.W; a.bias = w.b; a.Cin = w.cin; a.Cout = w.cout; a.M = M; a.clouds = clouds; a.epi = EPI_GN;
     a.Y = y.p; a.y_cloud_stride = (int64_t)M * w.cout; a.ldy = w.cout; a.stats_out = st_out; a.groups_out = w.groups;
+    split_of(a);
     if (!c->ws.overflow) launch_pw_gemm(a, st);   // an exhausted arena hands out its base: nothing may run on it
     return y;
   }
@@ -386,6 +395,7 @@ struct Sched {
     a.amode = A_LSE; a.xyz = xyz; a.xyz_cloud_stride = xyz_cs; a.neigh = neigh; a.neigh_cloud_stride = neigh_cs;
     a.W = w.W; a.bias = w.b; a.Cin = 10; a.Cout = w.cout; a.M = M; a.clouds = clouds; a.epi = EPI_GN;
     a.Y = y.p; a.y_cloud_stride = (int64_t)M * w.cout; a.ldy = w.cout; a.stats_out = st_out; a.groups_out = w.groups;
+    split_of(a);
     if (!c->ws.overflow) launch_pw_gemm(a, st);   // an exhausted arena hands out its base: nothing may run on it
     return y;
   }
@@ -406,6 +416,7 @@ struct Sched {
       g.W = w.fc_g; g.ldw = w.d / 2; g.bias = nullptr; g.Cin = w.d / 2; g.Cout = w.d; g.M = n; g.clouds = clouds;   // G in the consumer's column order (up_fc_g)
       g.epi = EPI_LINEAR; g.Y = G; g.y_cloud_stride = (int64_t)n * w.d; g.ldy = w.d;
       if (c->ws.overflow) return y;
+      split_of(g);
       launch_pw_gemm(g, st);
       GemmArgs a2;
       a2.amode = A_SEGS; a2.nseg = 1; a2.seg[0] = seg_of(enc);
@@ -413,6 +424,7 @@ struct Sched {
       a2.clouds = clouds; a2.epi = EPI_ATT2; a2.Y = y.p; a2.y_cloud_stride = (int64_t)n * w.d; a2.ldy = w.d;
       a2.g = G; a2.g_cloud_stride = (int64_t)n * w.d; a2.fseg = seg_of(f, neigh, neigh_cs);
       a2.s2 = s2; a2.s2_mode = s2 ? s2_mode : 0; a2.s2_cloud_stride = (int64_t)n * kKnn * w.d;
+      split_of(a2);
       // G's column order is the consumer's (up_fc_g): d <= 128 belongs to pw_stream.hip, d = 256 to pw_tile.hip
       if (w.d <= 128 ? launch_pw_stream(a2, st) : launch_pw_tile(a2, st)) return y;
     }
@@ -422,6 +434,7 @@ struct Sched {
     a.seg[1] = seg_of(enc);
     a.W = w.fc; a.bias = nullptr; a.Cin = w.d; a.Cout = w.d; a.M = n * kKnn; a.clouds = clouds; a.epi = EPI_ATT;
     a.Y = y.p; a.y_cloud_stride = (int64_t)n * w.d; a.ldy = w.d;
+    split_of(a);
     if (!c->ws.overflow) launch_pw_gemm(a, st);   // an exhausted arena hands out its base: nothing may run on it
     return y;
   }
@@ -435,6 +448,7 @@ struct Sched {
     a.W = w.W; a.bias = w.b; a.Cin = w.cin; a.Cout = w.cout; a.M = M; a.clouds = clouds; a.epi = epi;
     a.Y = y.p; a.y_cloud_stride = (int64_t)M * w.cout; a.ldy = w.cout;
     a.residual = residual; a.res_cloud_stride = (int64_t)M * w.cout; a.ldres = w.cout;
+    split_of(a);
     if (!c->ws.overflow) launch_pw_gemm(a, st);   // an exhausted arena hands out its base: nothing may run on it
     return y;
   }
@@ -817,30 +831,27 @@ int dsir_finalize_weights(dsir_ctx* c) {
     c->net.mlp_proj = bind_lin(b, mp);
   }
   {
-    // fp16 split (x -> fp16(x), fp16(x - fp16(x))) of the matrices the fp16-split kernels contract (BatchNorm already folded):
-    // the five wide layers of the aggregation chain (agg_chain_h.hip) and the per-point heads of both RandLA models
-    // (head_mlp_h.hip).  One blob: all high parts, then all low parts.
-    struct Req { size_t woff, n; const void** hi; const void** lo; };
-    std::vector<Req> reqs;
+    // fp16 split (x -> fp16(x), fp16(x - fp16(x))) of the WHOLE blob (BatchNorm already folded), at the same offsets: the kernels
+    // with an fp16-split contraction (agg_chain_h.hip, head_mlp_h.hip, pw_tile.hip) find the two parts of any matrix W at
+    // dweights16 + (W - dweights) and dweights16 + nweights + (W - dweights).  20 MB for the align pipeline.
+    const size_t total = u.blob.size();
+    std::vector<uint16_t> h16(2 * total, 0);
+    split_weights_f16(u.blob.data(), total, h16.data(), h16.data() + total);
+    HIP_OK(c, hipMalloc((void**)&c->dweights16, h16.size() * sizeof(uint16_t)));
+    HIP_OK(c, hipMemcpy(c->dweights16, h16.data(), h16.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    c->nweights = total;
+    auto hi = [&](size_t off) -> const void* { return c->dweights16 + off; };
+    auto lo = [&](size_t off) -> const void* { return c->dweights16 + total + off; };
     if (has_agg) {
       const LinOff* lay[5] = {&ma[1], &ma[2], &ma[3], &ma[4], &mp};
-      for (int k = 0; k < 5; ++k) reqs.push_back({lay[k]->W, (size_t)lay[k]->cin * lay[k]->cout, &c->agg_wh[k], &c->agg_wl[k]});
+      for (int k = 0; k < 5; ++k) { c->agg_wh[k] = hi(lay[k]->W); c->agg_wl[k] = lo(lay[k]->W); }
     }
     auto head = [&](const RandlaOff& o, RandlaW& w) {
-      reqs.push_back({o.out_w, (size_t)c->cfg.out_feat_dim * o.dec_out, &w.head_wh[0], &w.head_wl[0]});
-      for (int k = 0; k < 3; ++k) reqs.push_back({o.fc[k].W, (size_t)o.fc[k].cin * o.fc[k].cout, &w.head_wh[k + 1], &w.head_wl[k + 1]});
+      w.head_wh[0] = hi(o.out_w); w.head_wl[0] = lo(o.out_w);
+      for (int k = 0; k < 3; ++k) { w.head_wh[k + 1] = hi(o.fc[k].W); w.head_wl[k + 1] = lo(o.fc[k].W); }
     };
     head(fo, c->net.feat);
     if (has_inl) head(io, c->net.inl);
-    size_t total = 0;
-    std::vector<size_t> off(reqs.size());
-    for (size_t k = 0; k < reqs.size(); ++k) { off[k] = total; total += (reqs[k].n + 63) & ~(size_t)63; }
-    std::vector<uint16_t> h16(2 * total, 0);
-    for (size_t k = 0; k < reqs.size(); ++k)
-      split_weights_f16(u.blob.data() + reqs[k].woff, reqs[k].n, h16.data() + off[k], h16.data() + total + off[k]);
-    HIP_OK(c, hipMalloc((void**)&c->dweights16, h16.size() * sizeof(uint16_t)));
-    HIP_OK(c, hipMemcpy(c->dweights16, h16.data(), h16.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-    for (size_t k = 0; k < reqs.size(); ++k) { *reqs[k].hi = c->dweights16 + off[k]; *reqs[k].lo = c->dweights16 + total + off[k]; }
   }
   c->finalized = true;
   return 0;

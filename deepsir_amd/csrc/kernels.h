@@ -49,6 +49,10 @@ struct GemmArgs {
 
   const float* W = nullptr;     // [Cout][ldw] row-major, Cin columns used
   int ldw = 0;                  // weight row stride in floats (0 => Cin)
+  // optional fp16 split of W (x -> fp16(x), fp16(x - fp16(x)); same layout and strides, made at weight load): kernels with an
+  // fp16-split form (pw_tile.hip) take it when both are set
+  const void* Wh = nullptr;
+  const void* Wl = nullptr;
   const float* bias = nullptr;  // [Cout] or nullptr
   int Cin = 0, Cout = 0;
   // EPI_ATT2 only: G = W1 f  [clouds][n][Cout] and the gathered-feature half of the pooled operand

@@ -23,6 +23,32 @@ namespace {
 
 constexpr int BK = 32;
 constexpr int LDS_LD = BK + 2;
+// H = true (round 3): the contraction on the fp16 matrix pipe at fp32 accuracy, by the operand split of agg_chain_h.hip
+// (x = fp16(x) + fp16(x - fp16(x)); a.b = ah.bh + ah.bl + al.bh: three v_mfma_f32_16x16x32_f16).  A values are split when
+// they are staged (after GroupNorm + LeakyReLU), weights were split at load (GemmArgs::Wh / Wl); the LDS tiles hold the two
+// fp16 parts in rows of 32 + 8 halfs (80 bytes: 16-byte aligned, conflict-free ds_read_b128 fragment reads), and a
+// 32-channel chunk is ONE k-step: 3 RT NT MFMAs of 16 cycles instead of 8 RT NT of 32.  These layers ran the fp32 pipe
+// 31 - 40 % busy with two waves per SIMD contending for it.  Results differ from the H = false kernels (exact fp32,
+// k-ordered fmaf chains; DSIR_TILE_F32=1) by ~1e-7 of the layer's scale.
+constexpr int LDH = BK + 8;
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split4f(const float4 v, h4& h, h4& l) {
+  const float f[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const _Float16 t = (_Float16)f[k];
+    h[k] = t;
+    l[k] = (_Float16)(f[k] - (float)t);
+  }
+}
+#define DSIR_MMA3H(acc, ah, al, bh, bl)                                      \
+  do {                                                                        \
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc, 0, 0, 0);       \
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc, 0, 0, 0);       \
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc, 0, 0, 0);       \
+  } while (0)
 constexpr int BN = 64;
 constexpr int NT = 4;
 constexpr int MAXC = 768;
@@ -45,12 +71,14 @@ __device__ __forceinline__ RowOff row_off(const GemmArgs& p, int cloud, int row)
   return r;
 }
 
-template <int RT, int EPI, int SC = 0>   // SC: GemmArgs::s2_mode (EPI_ATT2 only)
+template <int RT, int EPI, int SC = 0, bool H = false>   // SC: GemmArgs::s2_mode (EPI_ATT2 only); H: fp16-split contraction
 __global__ __launch_bounds__(256) void pw_tile_kernel(const GemmArgs p) {
   constexpr int BM = 64 * RT;
   constexpr int AV = BM / 32;     // float4 A loads per thread per chunk (BM*32/4/256)
-  __shared__ float As[2][BM * LDS_LD];
-  __shared__ float Ws[2][BN * LDS_LD];
+  __shared__ float As[H ? 1 : 2][H ? 4 : BM * LDS_LD];
+  __shared__ float Ws[H ? 1 : 2][H ? 4 : BN * LDS_LD];
+  __shared__ _Float16 AsH[H ? 2 : 1][2][H ? BM * LDH : 8];      // [buffer][high | low]
+  __shared__ _Float16 WsH[H ? 2 : 1][2][H ? BN * LDH : 8];
   __shared__ float s_sc[MAXC];
   __shared__ float s_sh[MAXC];
   __shared__ float s_fsc[EPI == EPI_ATT2 ? 128 : 1];   // EPI_ATT2: GroupNorm scale/shift of the gathered-feature half
@@ -110,16 +138,21 @@ __global__ __launch_bounds__(256) void pw_tile_kernel(const GemmArgs p) {
   // and unconditional loads keep exec-mask juggling out of the K loop
   for (int i = 0; i < AV; ++i) ro[i] = row_off(p, cloud, min(m0 + sr0 + 32 * i, p.M - 1));
   const float* wrow[2];
+  const _Float16 *wrowh[2], *wrowl[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int col = min(n0 + sr0 + 32 * i, p.Cout - 1);
-    wrow[i] = p.W + (int64_t)col * (p.ldw ? p.ldw : p.Cin) + c4;
+    const int64_t wo = (int64_t)col * (p.ldw ? p.ldw : p.Cin) + c4;
+    wrow[i] = p.W + wo;
+    wrowh[i] = reinterpret_cast<const _Float16*>(p.Wh) + wo;
+    wrowl[i] = reinterpret_cast<const _Float16*>(p.Wl) + wo;
   }
   const int C0 = p.seg[0].C;
   const int act0 = p.seg[0].act, act1 = p.nseg > 1 ? p.seg[1].act : 0;
   __syncthreads();   // s_sc / s_sh ready
 
-  float4 ra[AV], rw[2];
+  float4 ra[AV], rw[H ? 1 : 2];
+  h4 rwh[H ? 2 : 1], rwl[H ? 2 : 1];
   auto gload = [&](int k0) {
     const int c = k0 + c4;
     const bool s1 = c >= C0;
@@ -131,7 +164,10 @@ __global__ __launch_bounds__(256) void pw_tile_kernel(const GemmArgs p) {
       ra[i] = *reinterpret_cast<const float4*>(base + o + lc);
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) rw[i] = *reinterpret_cast<const float4*>(wrow[i] + k0);
+    for (int i = 0; i < 2; ++i) {
+      if (H) { rwh[i] = *reinterpret_cast<const h4*>(wrowh[i] + k0); rwl[i] = *reinterpret_cast<const h4*>(wrowl[i] + k0); }
+      else rw[H ? 0 : i] = *reinterpret_cast<const float4*>(wrow[i] + k0);
+    }
   };
   auto lstore = [&](int k0, int buf) {
     const int c = k0 + c4;
@@ -144,15 +180,27 @@ __global__ __launch_bounds__(256) void pw_tile_kernel(const GemmArgs p) {
       v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y); v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
       v.x = fmaxf(v.x, slope * v.x); v.y = fmaxf(v.y, slope * v.y);
       v.z = fmaxf(v.z, slope * v.z); v.w = fmaxf(v.w, slope * v.w);
-      float2* d = reinterpret_cast<float2*>(&As[buf][(sr0 + 32 * i) * LDS_LD + c4]);
-      d[0] = make_float2(v.x, v.y);
-      d[1] = make_float2(v.z, v.w);
+      if (H) {
+        h4 hh, ll;
+        split4f(v, hh, ll);
+        *reinterpret_cast<h4*>(&AsH[buf][0][(sr0 + 32 * i) * LDH + c4]) = hh;
+        *reinterpret_cast<h4*>(&AsH[buf][1][(sr0 + 32 * i) * LDH + c4]) = ll;
+      } else {
+        float2* d = reinterpret_cast<float2*>(&As[H ? 0 : buf][(sr0 + 32 * i) * LDS_LD + c4]);
+        d[0] = make_float2(v.x, v.y);
+        d[1] = make_float2(v.z, v.w);
+      }
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      float2* d = reinterpret_cast<float2*>(&Ws[buf][(sr0 + 32 * i) * LDS_LD + c4]);
-      d[0] = make_float2(rw[i].x, rw[i].y);
-      d[1] = make_float2(rw[i].z, rw[i].w);
+      if (H) {
+        *reinterpret_cast<h4*>(&WsH[buf][0][(sr0 + 32 * i) * LDH + c4]) = rwh[i];
+        *reinterpret_cast<h4*>(&WsH[buf][1][(sr0 + 32 * i) * LDH + c4]) = rwl[i];
+      } else {
+        float2* d = reinterpret_cast<float2*>(&Ws[H ? 0 : buf][(sr0 + 32 * i) * LDS_LD + c4]);
+        d[0] = make_float2(rw[H ? 0 : i].x, rw[H ? 0 : i].y);
+        d[1] = make_float2(rw[H ? 0 : i].z, rw[H ? 0 : i].w);
+      }
     }
   };
 
@@ -214,19 +262,35 @@ __global__ __launch_bounds__(256) void pw_tile_kernel(const GemmArgs p) {
   for (int kc = 0; kc < nchunks; ++kc) {
     const bool more = kc + 1 < nchunks;
     if (more) gload((kc + 1) * BK);
-    const float* At = As[buf];
-    const float* Wt = Ws[buf];
+    if (H) {
+      h8 ah[RT], al[RT];
 #pragma unroll
-    for (int s = 0; s < BK / 4; ++s) {
-      float a[RT], b[NT];
+      for (int rt = 0; rt < RT; ++rt) {
+        ah[rt] = *reinterpret_cast<const h8*>(&AsH[buf][0][(16 * RT * w + 16 * rt + fr) * LDH + 8 * fq]);
+        al[rt] = *reinterpret_cast<const h8*>(&AsH[buf][1][(16 * RT * w + 16 * rt + fr) * LDH + 8 * fq]);
+      }
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt) a[rt] = At[(16 * RT * w + 16 * rt + fr) * LDS_LD + 4 * s + fq];
+      for (int t = 0; t < NT; ++t) {
+        const h8 bh = *reinterpret_cast<const h8*>(&WsH[buf][0][(16 * t + fr) * LDH + 8 * fq]);
+        const h8 bl = *reinterpret_cast<const h8*>(&WsH[buf][1][(16 * t + fr) * LDH + 8 * fq]);
 #pragma unroll
-      for (int t = 0; t < NT; ++t) b[t] = Wt[(16 * t + fr) * LDS_LD + 4 * s + fq];
+        for (int rt = 0; rt < RT; ++rt) DSIR_MMA3H(acc[rt][t], ah[rt], al[rt], bh, bl);
+      }
+    } else {
+      const float* At = As[H ? 0 : buf];
+      const float* Wt = Ws[H ? 0 : buf];
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt)
+      for (int s = 0; s < BK / 4; ++s) {
+        float a[RT], b[NT];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt], b[t], acc[rt][t], 0, 0, 0);
+        for (int rt = 0; rt < RT; ++rt) a[rt] = At[(16 * RT * w + 16 * rt + fr) * LDS_LD + 4 * s + fq];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) b[t] = Wt[(16 * t + fr) * LDS_LD + 4 * s + fq];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int t = 0; t < NT; ++t) acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt], b[t], acc[rt][t], 0, 0, 0);
+      }
     }
     if (more) lstore((kc + 1) * BK, buf ^ 1);
     __syncthreads();
@@ -380,11 +444,13 @@ __global__ __launch_bounds__(256) void pw_tile_kernel(const GemmArgs p) {
 // chain is 4 x shorter (K/2 instead of 2 K for RT = 2), a cloud spreads over 4-8 x more workgroups, and the row padding
 // drops from 64-128 to 32 rows (M = 78: 64 % -> 23 %; M = 19: 237 % -> 68 %).  Price: a weight tile is re-read from L2
 // once per 32 rows.  GroupNorm statistics: fp32 per column tile and wave, fp64 atomics.
-template <int RTS, int EPI>
+template <int RTS, int EPI, bool H = false>
 __global__ __launch_bounds__(256) void pw_tile_small_kernel(const GemmArgs p) {
   constexpr int BM = 32 * RTS, NTW = 2;         // RTS row tiles per wave: 32- or 64-row blocks
-  __shared__ float As[2][BM * LDS_LD];
-  __shared__ float Ws[2][BN * LDS_LD];
+  __shared__ float As[H ? 1 : 2][H ? 4 : BM * LDS_LD];
+  __shared__ float Ws[H ? 1 : 2][H ? 4 : BN * LDS_LD];
+  __shared__ _Float16 AsH[H ? 2 : 1][2][H ? BM * LDH : 8];      // [buffer][high | low]
+  __shared__ _Float16 WsH[H ? 2 : 1][2][H ? BN * LDH : 8];
   __shared__ float s_sc[MAXC];
   __shared__ float s_sh[MAXC];
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -419,10 +485,14 @@ __global__ __launch_bounds__(256) void pw_tile_small_kernel(const GemmArgs p) {
 #pragma unroll
   for (int i = 0; i < RTS; ++i) ro[i] = row_off(p, cloud, min(m0 + sr0 + 32 * i, p.M - 1));
   const float* wrow[2];
+  const _Float16 *wrowh[2], *wrowl[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int col = min(n0 + sr0 + 32 * i, p.Cout - 1);
-    wrow[i] = p.W + (int64_t)col * (p.ldw ? p.ldw : p.Cin) + c4;
+    const int64_t wo = (int64_t)col * (p.ldw ? p.ldw : p.Cin) + c4;
+    wrow[i] = p.W + wo;
+    wrowh[i] = reinterpret_cast<const _Float16*>(p.Wh) + wo;
+    wrowl[i] = reinterpret_cast<const _Float16*>(p.Wl) + wo;
   }
   const int C0 = p.seg[0].C;
   const int act0 = p.seg[0].act, act1 = p.nseg > 1 ? p.seg[1].act : 0;
@@ -430,7 +500,7 @@ __global__ __launch_bounds__(256) void pw_tile_small_kernel(const GemmArgs p) {
 
   // two register sets: a chunk is fetched two iterations before it is stored to LDS (a chunk's 8 MFMA steps hide only a
   // fraction of one L2 round trip; with a single launch on the chip - batch 1 - the K loop runs at load latency)
-  struct Pre { float4 a[RTS], w[2]; };
+  struct Pre { float4 a[RTS], w[H ? 1 : 2]; h4 wh[H ? 2 : 1], wl[H ? 2 : 1]; };
   Pre preA, preB;
   const int nchunks = p.Cin / BK;
   auto gload = [&](Pre& pre, int kc) {
@@ -441,7 +511,10 @@ __global__ __launch_bounds__(256) void pw_tile_small_kernel(const GemmArgs p) {
 #pragma unroll
     for (int i = 0; i < RTS; ++i) pre.a[i] = *reinterpret_cast<const float4*>(base + (s1 ? ro[i].o1 : ro[i].o0) + (s1 ? c - C0 : c));
 #pragma unroll
-    for (int i = 0; i < 2; ++i) pre.w[i] = *reinterpret_cast<const float4*>(wrow[i] + k0);
+    for (int i = 0; i < 2; ++i) {
+      if (H) { pre.wh[i] = *reinterpret_cast<const h4*>(wrowh[i] + k0); pre.wl[i] = *reinterpret_cast<const h4*>(wrowl[i] + k0); }
+      else pre.w[H ? 0 : i] = *reinterpret_cast<const float4*>(wrow[i] + k0);
+    }
   };
   auto lstore = [&](const Pre& pre, int k0, int buf) {
     const int c = k0 + c4;
@@ -454,15 +527,27 @@ __global__ __launch_bounds__(256) void pw_tile_small_kernel(const GemmArgs p) {
       v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y); v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
       v.x = fmaxf(v.x, slope * v.x); v.y = fmaxf(v.y, slope * v.y);
       v.z = fmaxf(v.z, slope * v.z); v.w = fmaxf(v.w, slope * v.w);
-      float2* d = reinterpret_cast<float2*>(&As[buf][(sr0 + 32 * i) * LDS_LD + c4]);
-      d[0] = make_float2(v.x, v.y);
-      d[1] = make_float2(v.z, v.w);
+      if (H) {
+        h4 hh, ll;
+        split4f(v, hh, ll);
+        *reinterpret_cast<h4*>(&AsH[buf][0][(sr0 + 32 * i) * LDH + c4]) = hh;
+        *reinterpret_cast<h4*>(&AsH[buf][1][(sr0 + 32 * i) * LDH + c4]) = ll;
+      } else {
+        float2* d = reinterpret_cast<float2*>(&As[H ? 0 : buf][(sr0 + 32 * i) * LDS_LD + c4]);
+        d[0] = make_float2(v.x, v.y);
+        d[1] = make_float2(v.z, v.w);
+      }
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      float2* dw = reinterpret_cast<float2*>(&Ws[buf][(sr0 + 32 * i) * LDS_LD + c4]);
-      dw[0] = make_float2(pre.w[i].x, pre.w[i].y);
-      dw[1] = make_float2(pre.w[i].z, pre.w[i].w);
+      if (H) {
+        *reinterpret_cast<h4*>(&WsH[buf][0][(sr0 + 32 * i) * LDH + c4]) = pre.wh[i];
+        *reinterpret_cast<h4*>(&WsH[buf][1][(sr0 + 32 * i) * LDH + c4]) = pre.wl[i];
+      } else {
+        float2* dw = reinterpret_cast<float2*>(&Ws[H ? 0 : buf][(sr0 + 32 * i) * LDS_LD + c4]);
+        dw[0] = make_float2(pre.w[H ? 0 : i].x, pre.w[H ? 0 : i].y);
+        dw[1] = make_float2(pre.w[H ? 0 : i].z, pre.w[H ? 0 : i].w);
+      }
     }
   };
   f32x4 acc[RTS][NTW];
@@ -472,19 +557,35 @@ __global__ __launch_bounds__(256) void pw_tile_small_kernel(const GemmArgs p) {
     for (int t = 0; t < NTW; ++t) acc[rt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
   // chunk kc from LDS buffer `buf`; `pre` holds chunk kc + 1 (stored to the other buffer) and is refilled with kc + 3
   auto chunk = [&](int kc, int buf, Pre& pre) {
-    const float* At = As[buf];
-    const float* Wt = Ws[buf];
+    if (H) {
+      h8 ah[RTS], al[RTS];
 #pragma unroll
-    for (int s = 0; s < BK / 4; ++s) {
-      float a[RTS], b[NTW];
+      for (int rt = 0; rt < RTS; ++rt) {
+        ah[rt] = *reinterpret_cast<const h8*>(&AsH[buf][0][(16 * (RTS * wr + rt) + fr) * LDH + 8 * fq]);
+        al[rt] = *reinterpret_cast<const h8*>(&AsH[buf][1][(16 * (RTS * wr + rt) + fr) * LDH + 8 * fq]);
+      }
 #pragma unroll
-      for (int rt = 0; rt < RTS; ++rt) a[rt] = At[(16 * (RTS * wr + rt) + fr) * LDS_LD + 4 * s + fq];
+      for (int t = 0; t < NTW; ++t) {
+        const h8 bh = *reinterpret_cast<const h8*>(&WsH[buf][0][(16 * (NTW * wc + t) + fr) * LDH + 8 * fq]);
+        const h8 bl = *reinterpret_cast<const h8*>(&WsH[buf][1][(16 * (NTW * wc + t) + fr) * LDH + 8 * fq]);
 #pragma unroll
-      for (int t = 0; t < NTW; ++t) b[t] = Wt[(16 * (NTW * wc + t) + fr) * LDS_LD + 4 * s + fq];
+        for (int rt = 0; rt < RTS; ++rt) DSIR_MMA3H(acc[rt][t], ah[rt], al[rt], bh, bl);
+      }
+    } else {
+      const float* At = As[H ? 0 : buf];
+      const float* Wt = Ws[H ? 0 : buf];
 #pragma unroll
-      for (int rt = 0; rt < RTS; ++rt)
+      for (int s = 0; s < BK / 4; ++s) {
+        float a[RTS], b[NTW];
 #pragma unroll
-        for (int t = 0; t < NTW; ++t) acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt], b[t], acc[rt][t], 0, 0, 0);
+        for (int rt = 0; rt < RTS; ++rt) a[rt] = At[(16 * (RTS * wr + rt) + fr) * LDS_LD + 4 * s + fq];
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) b[t] = Wt[(16 * (NTW * wc + t) + fr) * LDS_LD + 4 * s + fq];
+#pragma unroll
+        for (int rt = 0; rt < RTS; ++rt)
+#pragma unroll
+          for (int t = 0; t < NTW; ++t) acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt], b[t], acc[rt][t], 0, 0, 0);
+      }
     }
     if (kc + 1 < nchunks) {
       lstore(pre, (kc + 1) * BK, buf ^ 1);
@@ -539,10 +640,17 @@ __global__ __launch_bounds__(256) void pw_tile_small_kernel(const GemmArgs p) {
   }
 }
 
+// fp16-split contraction when the caller supplied split weights (GemmArgs::Wh / Wl); DSIR_TILE_F32: the exact-fp32 kernels
+inline bool use_split(const GemmArgs& a) {
+  static const bool f32 = getenv("DSIR_TILE_F32") != nullptr;   // A/B switch
+  return !f32 && a.Wh && a.Wl;
+}
+
 template <int RTS, int EPI>
 void launch_small(const GemmArgs& a, hipStream_t st) {
   dim3 grid((a.M + 32 * RTS - 1) / (32 * RTS), (a.Cout + BN - 1) / BN, a.clouds);
-  hipLaunchKernelGGL((pw_tile_small_kernel<RTS, EPI>), grid, dim3(256), 0, st, a);
+  if (use_split(a)) hipLaunchKernelGGL((pw_tile_small_kernel<RTS, EPI, true>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((pw_tile_small_kernel<RTS, EPI, false>), grid, dim3(256), 0, st, a);
 }
 
 template <int RTS>
@@ -557,7 +665,8 @@ bool launch_small_e(const GemmArgs& a, hipStream_t st) {
 template <int RT, int EPI, int SC = 0>
 void launch_t(const GemmArgs& a, hipStream_t st) {
   dim3 grid((a.M + 64 * RT - 1) / (64 * RT), (a.Cout + BN - 1) / BN, a.clouds);
-  hipLaunchKernelGGL((pw_tile_kernel<RT, EPI, SC>), grid, dim3(256), 0, st, a);
+  if (use_split(a)) hipLaunchKernelGGL((pw_tile_kernel<RT, EPI, SC, true>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((pw_tile_kernel<RT, EPI, SC, false>), grid, dim3(256), 0, st, a);
 }
 
 template <int RT>
