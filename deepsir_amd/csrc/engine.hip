@@ -1177,7 +1177,9 @@ static int register_enqueue(dsir_ctx* c, const dsir_pair_batch* in, int n_iter, 
       // re-reading 64 floats per row costs more HBM time than contracting 32 (same bits either way; +1.9 % pairs/s at 128
       // pairs per launch, -0.02 ms of single-pair latency with the cache)
       static const int s2_min_d = getenv("DSIR_S2_MIN_D") ? atoi(getenv("DSIR_S2_MIN_D")) : 0;   // tuning hook: 0 = by launch size
-      const int min_d = s2_min_d > 0 ? s2_min_d : (P <= 4 ? 64 : 128);
+      // round 3: with the score contraction on the fp16 pipe, re-reading level 2's halves (2 x 5000 x 128 floats per cloud) also
+      // costs more than contracting them when the chip is full: only level 3 keeps its cache there (+0.7 % pairs/s; 64: -0.7 %)
+      const int min_d = s2_min_d > 0 ? s2_min_d : (P <= 4 ? 64 : 256);
       if (g.d_out[l] >= 64 && g.d_out[l] >= min_d && !no_s2) {
         enc_cache.s2_buf[l][0] = ws.get<float>(rows * (size_t)g.d_out[l]);
         enc_cache.s2_buf[l][1] = ws.get<float>(rows * (size_t)g.d_out[l]);
