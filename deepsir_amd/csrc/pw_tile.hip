@@ -694,7 +694,10 @@ bool seg_ok(const Seg& s) {
 
 // Returns false when the layer is outside this kernel's envelope (caller falls back to pw_gemm.hip).
 bool launch_pw_tile(const GemmArgs& a, hipStream_t st) {
-  if (a.amode != A_SEGS || a.Cin < 64 || a.Cin > MAXC || (a.Cin % BK) != 0 || a.Cout < 64) return false;
+  // Cout >= 64 - or >= 32 with the fp16-split contraction, where the unused half of the 64-column tile costs next to nothing
+  // (the level-0 decoder layer 160 -> 32, otherwise left to the generic pw_gemm.hip kernel)
+  static const int min_cout_h = getenv("DSIR_TILE_MIN_COUT") ? atoi(getenv("DSIR_TILE_MIN_COUT")) : 32;   // A/B hook
+  if (a.amode != A_SEGS || a.Cin < 64 || a.Cin > MAXC || (a.Cin % BK) != 0 || a.Cout < (use_split(a) ? min_cout_h : 64)) return false;
   if (!seg_ok(a.seg[0]) || (a.nseg > 1 && (!seg_ok(a.seg[1]) || (a.seg[0].C % 4) != 0))) return false;
   if ((reinterpret_cast<uintptr_t>(a.W) % 16) != 0) return false;
   if (a.epi == EPI_GN && ((a.Cout / a.groups_out) % 8) != 0) return false;
