@@ -9,6 +9,12 @@ export TMPDIR=/tmp
 echo "== default bench"; python3 bench.py > $out/${tag}_bench_default.json 2> $out/${tag}_bench_default.err || { tail -5 $out/${tag}_bench_default.err; exit 1; }
 echo "== kernel trace + PMC passes of the bench command"; bash tools/profile_bench.sh $tag || exit 1
 python3 tools/step_hbm.py $out/${tag}_pmc_fetch.csv $out/${tag}_pmc_write.csv 5 256 5000 2 5 $out/${tag}_step_hbm.json > /dev/null || exit 1
+echo "== one engine (the launches of the roofline pass), timeline statistics, one pair in flight"
+rm -rf /tmp/prof_single; rocprofv3 --kernel-trace --stats -d /tmp/prof_single --output-format csv -- python3 bench.py --pairs 128 --streams 1 --steps 5 --warmup 1 --timed-only > $out/${tag}_single.json 2> $out/${tag}_single.err || exit 1
+cp "$(find /tmp/prof_single -name '*kernel_stats.csv' | head -1)" $out/${tag}_kernel_stats_single_engine.csv
+python3 tools/trace_gaps.py /tmp/prof_trace $out/${tag}_trace_gaps.json > /dev/null || exit 1
+rm -rf /tmp/prof_b1; rocprofv3 --kernel-trace --stats -d /tmp/prof_b1 --output-format csv -- python3 bench.py --pairs 1 --streams 1 --steps 20 --warmup 2 --timed-only > $out/${tag}_b1.json 2> $out/${tag}_b1.err || exit 1
+cp "$(find /tmp/prof_b1 -name '*kernel_stats.csv' | head -1)" $out/${tag}_batch1_kernel_stats.csv
 echo "== HBM traffic of one screened arg-min launch (128 pairs)"
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/nm_$c
