@@ -64,6 +64,7 @@ SYMBOLS = {
     "dsir_last_error": (C.c_char_p, [C.c_void_p]),
     "dsir_stream": (C.c_void_p, [C.c_void_p]),
     "dsir_sync": (C.c_int, [C.c_void_p]),
+    "dsir_set_stream": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "dsir_num_weights": (C.c_int, [C.c_void_p]),
     "dsir_weight_name": (C.c_char_p, [C.c_void_p, C.c_int, c_i64_p]),
     "dsir_load_weight": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, c_i64_p, C.c_int]),

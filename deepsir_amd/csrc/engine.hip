@@ -80,7 +80,8 @@ struct Act {
 struct dsir_ctx {
   int device = 0;
   dsir_cfg cfg{};
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;        // where every launch of this context goes: own_stream, or a caller's (dsir_set_stream)
+  hipStream_t own_stream = nullptr;
   std::string err;
   std::vector<HostParam> params;
   std::unordered_map<std::string, int> index;
@@ -706,6 +707,7 @@ int dsir_create(int device, const dsir_cfg* cfg, dsir_ctx** out) {
     delete c;
     return fail(nullptr, "cannot initialise device %d", device);
   }
+  c->own_stream = c->stream;
   // which sub-networks exist follows args.pipeline (model.py:131-193)
   add_randla(c, "feat_extractor", cfg->feat_len, cfg->num_classes);
   if (cfg->pipeline != DSIR_PIPELINE_LABEL) {
@@ -762,12 +764,21 @@ void dsir_destroy(dsir_ctx* c) {
   if (c->screen_acc) hipFree(c->screen_acc);
   if (c->stats) hipFree(c->stats);
   if (c->ws.base) hipFree(c->ws.base);
-  hipStreamDestroy(c->stream);
+  hipStreamDestroy(c->own_stream);     // a caller's stream (dsir_set_stream) is the caller's to destroy
   delete c;
 }
 
 const char* dsir_last_error(const dsir_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
 void* dsir_stream(dsir_ctx* c) { return c ? (void*)c->stream : nullptr; }
+int dsir_set_stream(dsir_ctx* c, void* stream, int restore_own) {
+  if (!c) return 1;
+  HIP_OK(c, hipSetDevice(c->device));
+  // work already enqueued stays ordered on the stream it was enqueued on; a captured registration belongs to the old stream
+  if (c->graph_exec) { hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
+  c->graph_key.clear();
+  c->stream = restore_own ? c->own_stream : (hipStream_t)stream;     // NULL is a valid caller stream: the legacy default stream
+  return 0;
+}
 int dsir_sync(dsir_ctx* c) {
   if (!c) return 1;
   HIP_OK(c, hipStreamSynchronize(c->stream));

@@ -55,6 +55,8 @@ class Engine:
             raise EngineError("dsir_create: " + self.lib.dsir_last_error(None).decode())
         self.h = h
         self.weights_loaded = False
+        self._shared_stream = False
+        self._bound_stream = None
 
     def close(self):
         if getattr(self, "h", None):
@@ -73,10 +75,34 @@ class Engine:
             raise EngineError(self.lib.dsir_last_error(self.h).decode())
 
     def _pre(self):
-        torch.cuda.current_stream(self.device).synchronize()
+        if not self._shared_stream:
+            torch.cuda.current_stream(self.device).synchronize()
+            return
+        # shared mode follows torch's current stream (torch.cuda.graph captures on a side stream): re-bind when it changed
+        cur = torch.cuda.current_stream(self.device).cuda_stream
+        if cur != self._bound_stream:
+            self._call(self.lib.dsir_set_stream(self.h, C.c_void_p(cur), 0))
+            self._bound_stream = cur
 
     def sync(self):
-        self._call(self.lib.dsir_sync(self.h))
+        if not self._shared_stream:     # on the caller's stream the results are stream-ordered with the caller's own kernels
+            self._call(self.lib.dsir_sync(self.h))
+
+    def use_torch_stream(self, on: bool = True):
+        """Order the engine's operators on torch's CURRENT stream (include/dsir.h, dsir_set_stream) instead of the context's
+        own: no host synchronisation around a call any more (results are stream-ordered with torch's kernels), which also makes
+        the operators capturable by ``torch.cuda.graph``.  ``on=False``: back to the context's own stream (after a device
+        synchronisation, so that nothing enqueued on torch's stream is overtaken)."""
+        if on:
+            self._call(self.lib.dsir_sync(self.h))
+            self._bound_stream = torch.cuda.current_stream(self.device).cuda_stream
+            self._call(self.lib.dsir_set_stream(self.h, C.c_void_p(self._bound_stream), 0))
+            self._shared_stream = True
+        else:
+            torch.cuda.synchronize(self.device)
+            self._call(self.lib.dsir_set_stream(self.h, None, 1))
+            self._shared_stream = False
+            self._bound_stream = None
 
     def _empty(self, shape, dtype=torch.float32):
         return torch.empty(shape, dtype=dtype, device=self.device)

@@ -66,6 +66,12 @@ const char* dsir_last_error(const dsir_ctx* ctx);   /* ctx may be NULL: creation
 /* The HIP stream (hipStream_t) every call is ordered on. */
 void* dsir_stream(dsir_ctx* ctx);
 int dsir_sync(dsir_ctx* ctx);
+/* Order every later call of this context on a CALLER-OWNED hipStream_t instead (restore_own != 0: back to the context's own
+ * stream; a NULL hip_stream with restore_own == 0 is the legacy default stream, which is what torch's default stream is) - e.g.
+ * the host framework's current stream, so that the engine's operators interleave with the caller's kernels without host
+ * synchronisation and can be captured into the caller's hipGraph.  The context never destroys a caller's stream; work enqueued earlier stays
+ * on the stream it was enqueued on (synchronise before switching if the two must be ordered). */
+int dsir_set_stream(dsir_ctx* ctx, void* hip_stream, int restore_own);
 int dsir_num_weights(const dsir_ctx* ctx);
 /* i-th expected state-dict key and its element count (for host-side validation). */
 const char* dsir_weight_name(const dsir_ctx* ctx, int i, int64_t* numel);

@@ -222,3 +222,34 @@ def test_hoisted_loop_invariants_are_bit_identical(tmp_path):
     for other in ("no_s2", "no_hoist"):
         for k in ("idx", "logits", "transforms"):
             assert np.array_equal(outs["hoisted"][k], outs[other][k]), f"{k} differs between hoisted and {other}"
+
+
+def test_engine_on_the_callers_stream_gives_the_same_bits():
+    """dsir_set_stream (include/dsir.h): the engine's launches ordered on torch's current stream instead of the context's own
+    - no host synchronisation around a call - must not change a bit, on the default stream and on a side stream, and the
+    context goes back to its own stream afterwards."""
+    from deepsir_amd.arch import NetConfig
+    from deepsir_amd.engine import Engine
+    from deepsir_amd.synth import make_batch
+    from deepsir_amd.weights import generate_state_dict
+    cfg = NetConfig(feat_len=3)
+    eng = Engine(cfg, 0, max_points=2048, max_pairs=2)
+    eng.load_state_dict(generate_state_dict(cfg, 4))
+    b = make_batch(2048, [31, 32], 3)
+    src, ref = torch.from_numpy(b["points_src"]).cuda(), torch.from_numpy(b["points_ref"]).cuda()
+    want = eng.register(src, ref, 3)
+    eng.use_torch_stream(True)
+    got = eng.register(src, ref, 3)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        got2 = eng.register(src, ref, 3)
+        desc = eng.aggregate(got2["pt_ref_new"], torch.zeros(2, 2048, 64, device="cuda"), torch.ones(2, 2048, device="cuda"))
+    side.synchronize()
+    torch.cuda.synchronize()
+    eng.use_torch_stream(False)
+    again = eng.register(src, ref, 3)
+    for k in ("transforms", "idx", "logits"):
+        assert torch.equal(want[k], got[k]) and torch.equal(want[k], got2[k]) and torch.equal(want[k], again[k]), k
+    assert torch.isfinite(desc).all()
+    eng.close()
