@@ -96,6 +96,7 @@ SYMBOLS = {
     "dsir_match_timer2": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), c_i64_p]),
     "dsir_enable_screen": (C.c_int, [C.c_void_p, C.c_int]),
     "dsir_enable_agg_split": (C.c_int, [C.c_void_p, C.c_int]),
+    "dsir_split_f16": (None, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "dsir_match_timer_device": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), c_i64_p]),
     "dsir_enable_match_timer": (C.c_int, [C.c_void_p, C.c_int]),
     "dsir_enable_graph": (C.c_int, [C.c_void_p, C.c_int]),

@@ -1567,6 +1567,10 @@ int dsir_match_timer2(dsir_ctx* c, int reset, double* op_ms, double* kernel_ms, 
   return 0;
 }
 
+void dsir_split_f16(const float* x, int64_t n, uint16_t* hi, uint16_t* lo) {
+  if (x && hi && lo && n > 0) split_weights_f16(x, (size_t)n, hi, lo);
+}
+
 int dsir_enable_agg_split(dsir_ctx* c, int enable) {
   if (!c) return 1;
   c->agg_split = enable != 0;

@@ -305,6 +305,10 @@ int dsir_enable_screen(dsir_ctx* ctx, int enable);
  * fp32 kernel's); 0 = the exact-fp32 chain (csrc/agg_chain.hip), bit-identical to the unfused layer-by-layer launches.
  * Initialised from DSIR_AGG_F32 (set => 0). */
 int dsir_enable_agg_split(dsir_ctx* ctx, int enable);
+/* The operand split those layers rest on, HOST buffers, no context, no GPU: hi[i] = fp16(x[i]) and lo[i] = fp16(x[i] - hi[i])
+ * as IEEE binary16 bit patterns, both rounded to nearest even - what dsir_finalize_weights applies to every weight matrix (the
+ * kernels apply the same rule to activations).  x = hi + lo + r with |r| <= max(2^-22 |x|, 2^-25) for |x| <= 65504. */
+void dsir_split_f16(const float* x, int64_t n, uint16_t* hi, uint16_t* lo);
 /* Same launches, bracketed on the DEVICE's constant-rate clock inside the kernel (first wave start .. last wave end,
  * the quantity a kernel trace reports): unlike the HIP-event bracket it does not include time the launch spends
  * queued behind other streams' kernels when several engines share the GPU. */

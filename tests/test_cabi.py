@@ -57,3 +57,24 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f"{f} imports the oracle"
+
+
+def test_fp16_operand_split_is_exact_to_2_pow_minus_22():
+    """dsir_split_f16 (host, no GPU): the split the fp16-matrix-pipe layers rest on (csrc/agg_chain_h.hip, head_mlp_h.hip,
+    pw_tile.hip, pw_stream.hip).  hi = fp16(x) and lo = fp16(x - hi), both round-to-nearest-even (numpy's conversion is the
+    oracle here), and x = hi + lo + r with |r| <= max(2^-22 |x|, 2^-25) over the whole fp16 range, sub-normals included."""
+    import numpy as np
+    from deepsir_amd import _lib
+    lib = _lib.load()
+    rng = np.random.Generator(np.random.Philox(key=16))
+    x = np.concatenate([rng.standard_normal(200000) * 10.0 ** rng.uniform(-9, 4.5, 200000),
+                        [0.0, -0.0, 6.1e-5, -6.0e-5, 5.96e-8, 65504.0, -65504.0, 1.0, 1.0 + 2.0 ** -11, 1.0 + 2.0 ** -12]]).astype(np.float32)
+    x = x[np.abs(x) <= 65504.0]
+    hi = np.zeros(x.size, np.uint16)
+    lo = np.zeros(x.size, np.uint16)
+    lib.dsir_split_f16(x.ctypes.data, x.size, hi.ctypes.data, lo.ctypes.data)
+    h = x.astype(np.float16)
+    l = (x - h.astype(np.float32)).astype(np.float16)
+    assert np.array_equal(hi, h.view(np.uint16)) and np.array_equal(lo, l.view(np.uint16))
+    r = np.abs(x.astype(np.float64) - h.astype(np.float64) - l.astype(np.float64))
+    assert (r <= np.maximum(2.0 ** -22 * np.abs(x.astype(np.float64)), 2.0 ** -25)).all()
