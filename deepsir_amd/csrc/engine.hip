@@ -109,6 +109,7 @@ struct dsir_ctx {
   int64_t match_launches = 0;
   // arg-min path of dsir_register: 1 = screened (nn_screen.hip) for large problems, 0 = always the exhaustive kernel
   int screen_mode = 1;
+  int prune_min_points = 8192;          // pruned search (nn_prune.hip) for ref clouds of that many points and more; 0 = off
   // aggregation chain: 1 = fp16-split products on the fp16 matrix pipe (agg_chain_h.hip), 0 = exact-fp32 chain (agg_chain.hip)
   int agg_split = 1;
   // device-clock brackets {first wave start, last wave end} of the timed nn_match launches
@@ -117,7 +118,7 @@ struct dsir_ctx {
   double match_dev_ms = 0.0;
   int64_t match_dev_launches = 0;
   // running totals of the screened arg-min inside dsir_register (dsir_screen_stats)
-  unsigned long long* screen_acc = nullptr;   // device, 4 x u64
+  unsigned long long* screen_acc = nullptr;   // device, 4 x u64 (+ 2 x u64: tile products kept / in all by the pruned search)
   int64_t exhaustive_searches = 0;            // searches that took the exhaustive kernel directly (small problems)
 };
 constexpr size_t kMatchSlots = 4096;
@@ -702,6 +703,7 @@ int dsir_create(int device, const dsir_cfg* cfg, dsir_ctx** out) {
   dsir_ctx* c = new dsir_ctx();
   c->device = device; c->cfg = *cfg;
   c->screen_mode = getenv("DSIR_NO_SCREEN") ? 0 : 1;
+  if (const char* e = getenv("DSIR_PRUNE_MIN_K")) c->prune_min_points = atoi(e) > 0 ? atoi(e) : 0;   // A/B hook; 0 = off
   c->agg_split = getenv("DSIR_AGG_F32") ? 0 : 1;
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
     delete c;
@@ -742,8 +744,8 @@ int dsir_create(int device, const dsir_cfg* cfg, dsir_ctx** out) {
     delete c;
     return fail(nullptr, "cannot allocate the statistics arena");
   }
-  if (hipMalloc((void**)&c->screen_acc, 4 * sizeof(unsigned long long)) != hipSuccess ||
-      hipMemset(c->screen_acc, 0, 4 * sizeof(unsigned long long)) != hipSuccess) {
+  if (hipMalloc((void**)&c->screen_acc, 6 * sizeof(unsigned long long)) != hipSuccess ||
+      hipMemset(c->screen_acc, 0, 6 * sizeof(unsigned long long)) != hipSuccess) {
     hipFree(c->stats); hipFree(c->ws.base); hipStreamDestroy(c->stream);
     delete c;
     return fail(nullptr, "cannot allocate the screening counters");
@@ -1173,6 +1175,9 @@ static int register_enqueue(dsir_ctx* c, const dsir_pair_batch* in, int n_iter, 
     sc_sa = ws.get<float>((size_t)P * J); sc_sb = ws.get<float>((size_t)P * K);
     sc_scratch = ws.raw(nn_screen_scratch_bytes(P, J));
   }
+  // pruned search (nn_prune.hip) for long ref ranges: column order + tile bounds once, row order + tile lists per iteration
+  const bool prune = screen && c->prune_min_points > 0 && K >= c->prune_min_points && n_iter > 1 && nn_prune_supported(P, J, K);
+  void* pr_scratch = prune ? ws.raw(nn_prune_scratch_bytes(P, J, K)) : nullptr;
   // persistent storage of the inlier model's position-encoding branch (EncCache), alive across the iterations
   EncCache enc_cache;
   static const bool no_hoist = getenv("DSIR_NO_HOIST") != nullptr;   // A/B switch
@@ -1214,6 +1219,7 @@ static int register_enqueue(dsir_ctx* c, const dsir_pair_batch* in, int n_iter, 
     if (screen) {
       launch_split16_norm(desc_r, (int64_t)P * K, sc_bh, sc_bl, sc_sb, st);
     }
+    if (prune && launch_prune_ref(rxyz, (int64_t)pr.S * 3, desc_r, sc_bh, sc_bl, sc_sb, P, J, K, pr_scratch, st)) return fail(c, "pruned search: sorting the ref side failed");
     float* F_tmp = run_mlp_feat(c, feat_s, P, J);
     HIP_OK(c, hipMemcpyAsync(F_s, F_tmp, sizeof(float) * P * J * 64, hipMemcpyDeviceToDevice, st));
     ws.release(mark1);
@@ -1240,8 +1246,15 @@ static int register_enqueue(dsir_ctx* c, const dsir_pair_batch* in, int n_iter, 
       if (ev) hipEventRecord(ev->op0, st);
       if (screen) {
         launch_split16_norm(desc_s, (int64_t)P * J, sc_ah, sc_al, sc_sa, st);
+        ScreenOrder ord;
+        if (prune && it > 0) {
+          // the previous iteration's matches bound every row's minimum from above: skip the tiles that cannot beat them
+          const int32_t* idx_prev = out->idx ? out->idx + (size_t)(it - 1) * P * J : idx_it;
+          if (launch_prune_rows(desc_s, desc_r, sc_ah, sc_al, sc_sa, sc_sb, idx_prev, P, J, K, pr_scratch, st, &ord, c->screen_acc + 4))
+            return fail(c, "pruned search: sorting the rows failed");
+        }
         launch_nn_screen(desc_s, desc_r, sc_ah, sc_al, sc_bh, sc_bl, sc_sa, sc_sb, P, J, K, idx_out, sc_scratch, st, nullptr, nullptr, nullptr,
-                         /*keep_gate=*/it > 0, nullptr, c->screen_acc, ev ? ev->k0 : nullptr, ev ? ev->k1 : nullptr);
+                         /*keep_gate=*/it > 0, nullptr, c->screen_acc, ev ? ev->k0 : nullptr, ev ? ev->k1 : nullptr, ord);
       } else {
         ++c->exhaustive_searches;
         launch_nn_match_ws(desc_s, desc_r, P, J, K, idx_out, match_scratch, st, ev ? ev->k0 : nullptr, ev ? ev->k1 : nullptr,
@@ -1520,6 +1533,17 @@ int dsir_match_timer_device(dsir_ctx* c, int reset, double* total_ms, int64_t* l
   return 0;
 }
 
+int dsir_prune_stats(dsir_ctx* c, int reset, int64_t* out) {
+  if (!c || !out) return 1;
+  HIP_OK(c, hipSetDevice(c->device));
+  HIP_OK(c, hipStreamSynchronize(c->stream));
+  unsigned long long h[2];
+  HIP_OK(c, hipMemcpy(h, c->screen_acc + 4, sizeof h, hipMemcpyDeviceToHost));
+  out[0] = (int64_t)h[0]; out[1] = (int64_t)h[1];
+  if (reset) HIP_OK(c, hipMemset(c->screen_acc + 4, 0, sizeof h));
+  return 0;
+}
+
 int dsir_screen_stats(dsir_ctx* c, int reset, int64_t* out) {
   if (!c || !out) return 1;
   HIP_OK(c, hipSetDevice(c->device));
@@ -1574,6 +1598,15 @@ void dsir_split_f16(const float* x, int64_t n, uint16_t* hi, uint16_t* lo) {
 int dsir_enable_agg_split(dsir_ctx* c, int enable) {
   if (!c) return 1;
   c->agg_split = enable != 0;
+  // a captured registration has the choice baked in
+  if (c->graph_exec) { hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
+  c->graph_key.clear();
+  return 0;
+}
+
+int dsir_set_prune_min_points(dsir_ctx* c, int min_points) {
+  if (!c) return 1;
+  c->prune_min_points = min_points > 0 ? min_points : 0;
   // a captured registration has the choice baked in
   if (c->graph_exec) { hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
   c->graph_key.clear();

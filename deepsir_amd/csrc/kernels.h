@@ -210,6 +210,34 @@ void launch_sqnorm(const float* x, int64_t rows, float* out, hipStream_t st);   
 
 // nn_screen.hip — the same arg-min, screened with fp16 MFMAs under a rigorous bound and decided in exact fp32
 size_t nn_screen_scratch_bytes(int pairs, int J);
+// Pruned search (nn_prune.hip): the screening may walk the src rows and the ref columns in a given ORDER and, per row block, only
+// a LIST of column tiles.  launch_prune_rows fills the fields (all of them); default-constructed: the dense search.  Results are
+// reported in original indices.
+struct ScreenOrder {
+  const int32_t* rows = nullptr;     // [pairs][J]: row order (position -> src row)
+  const int32_t* cols = nullptr;     // [pairs][K]: column order (position -> ref row)
+  const void* bh = nullptr;          // with cols: the ref side's fp16 pairs and seeds ALREADY in column order (rows of 64 halves / floats
+  const void* bl = nullptr;          //   per position): the search streams contiguous tiles, `cols` only names the winners
+  const float* sbp = nullptr;
+  const int32_t* tlist = nullptr;    // [pairs][row blocks][tl_stride]: tiles (of 64 positions of the column order) a row block must visit
+  const int32_t* tcount = nullptr;   // [pairs][row blocks]
+  int tl_stride = 0;
+  const int32_t* rborder = nullptr;  // [pairs][row blocks]: the row blocks by descending tile count (the order items are taken in)
+  int32_t* queue = nullptr;          // [8], zeroed before every launch: the XCDs' item counters (with tlist)
+};
+int nn_screen_rows_per_block(int J);   // rows a workgroup of the screening owns for this J (what tile lists are built for)
+int nn_screen_max_bound_tiles();
+void launch_tile_bound(const void* ah, const void* al, const float* sa, const int32_t* rows, const float* T, const void* ch, const void* cl,
+                       const float* cn2, const float* rad, int pairs, int J, int nt, int32_t* tlist, int32_t* tcount, int tl_stride,
+                       int32_t* rborder, hipStream_t st);
+// nn_prune.hip: column order (Morton order of the ref points) + tile bounds once per registration; row order, upper bounds and
+// tile lists per iteration (acc, optional: device 2 x u64 running totals {tile products kept, tile products in all})
+bool nn_prune_supported(int pairs, int J, int K);
+size_t nn_prune_scratch_bytes(int pairs, int J, int K);
+int launch_prune_ref(const float* ref_xyz, int64_t xyz_cloud_stride, const float* desc_ref, const void* bh, const void* bl, const float* sb,
+                     int pairs, int J, int K, void* scratch, hipStream_t st);
+int launch_prune_rows(const float* desc_src, const float* desc_ref, const void* ah, const void* al, const float* sa, const float* sb,
+                      const int32_t* idx_prev, int pairs, int J, int K, void* scratch, hipStream_t st, ScreenOrder* ord, unsigned long long* acc);
 // fp32 [rows][64] -> fp16 hi / lo; `bad` (optional device flag) is set when an element is outside the screening's domain
 void launch_split16(const float* x, int64_t rows, void* hi, void* lo, hipStream_t st, int32_t* bad = nullptr);
 // the same split plus launch_sqnorm's |x|^2 per row, one pass
@@ -218,7 +246,8 @@ void launch_nn_screen(const float* a, const float* b, const void* ah, const void
                       const float* sa, const float* sb, int pairs, int J, int K, int32_t* idx, void* scratch, hipStream_t st,
                       hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, unsigned long long* stats = nullptr,
                       bool keep_gate = false, const int32_t* bad = nullptr, unsigned long long* acc = nullptr,
-                      hipEvent_t evk0 = nullptr, hipEvent_t evk1 = nullptr);   // evk0/evk1 bracket screen_kernel alone
+                      hipEvent_t evk0 = nullptr, hipEvent_t evk1 = nullptr,    // evk0/evk1 bracket screen_kernel alone
+                      const ScreenOrder& ord = ScreenOrder());
 // diagnostics of the screening on ONE small pair (dsir_screen_bounds): lower / upper / exact [J][K]; the candidate lists of the
 // product launch that ran on `scratch` (pairs = 1): thresh [J], count [J], code / lower [J][nn_screen_cap()]
 int nn_screen_cap();

@@ -28,7 +28,6 @@ namespace dsir {
 namespace {
 
 constexpr int TILE = 64;            // = the screening's column tile (DSIR_SCREEN_BC)
-constexpr int MAX_TILES = 4096;     // LDS flags of tile_list_kernel
 
 inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 inline int grid_for(int64_t n) { const int64_t g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > 65535 ? 65535 : g)); }
@@ -65,8 +64,8 @@ __device__ __forceinline__ uint32_t spread3(uint32_t v) {
   return v;
 }
 
-// 30-bit Morton code of every point inside its cloud's box (non-finite coordinates: key 0 - any order is a valid order)
-__global__ void morton_kernel(const float* __restrict__ xyz, int64_t cs, int n, const float* __restrict__ box, int64_t total,
+// Morton code (up to 30 bits) of every point inside its cloud's box (non-finite coordinates: key 0 - any order is a valid order)
+__global__ void morton_kernel(const float* __restrict__ xyz, int64_t cs, int n, const float* __restrict__ box, int64_t total, int mbits,
                               uint32_t* __restrict__ key, uint32_t* __restrict__ val) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int cloud = (int)(i / n), j = (int)(i % n);
@@ -80,20 +79,18 @@ __global__ void morton_kernel(const float* __restrict__ xyz, int64_t cs, int n, 
       t = t == t ? fminf(fmaxf(t, 0.f), 1023.f) : 0.f;
       q[k] = (uint32_t)t;
     }
-    key[i] = spread3(q[0]) | (spread3(q[1]) << 1) | (spread3(q[2]) << 2);
+    // (cloud, code) in one 32-bit key - the code's low bits go when the cloud index needs them -: one device-wide sort
+    const uint32_t m = spread3(q[0]) | (spread3(q[1]) << 1) | (spread3(q[2]) << 2);
+    key[i] = ((uint32_t)cloud << mbits) | (m >> (30 - mbits));
     val[i] = (uint32_t)j;
   }
 }
 
-__global__ void seg_offsets_kernel(int* seg, int clouds, int n) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i <= clouds; i += gridDim.x * blockDim.x) seg[i] = i * n;
-}
-
 // order (position -> element) as int32, and its inverse (element -> position)
-__global__ void order_kernel(const uint32_t* __restrict__ sorted_val, int n, int64_t total, int32_t* __restrict__ order,
+__global__ void order_kernel(const uint32_t* __restrict__ sorted_val, int n, int64_t total, bool identity, int32_t* __restrict__ order,
                              int32_t* __restrict__ inverse) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int v = (int)sorted_val[i];
+    const int v = identity ? (int)(i % n) : (int)sorted_val[i];
     order[i] = v;
     if (inverse) inverse[(i / n) * n + v] = (int)(i % n);
   }
@@ -131,7 +128,7 @@ __global__ __launch_bounds__(256) void tile_stats_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void row_prep_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                        const float* __restrict__ sa, const float* __restrict__ sb,
                                                        const int32_t* __restrict__ idx_prev, const int32_t* __restrict__ inv, int J, int K,
-                                                       int64_t total, uint32_t* __restrict__ key, uint32_t* __restrict__ val,
+                                                       int kbits, int64_t total, bool keep_all, uint32_t* __restrict__ key, uint32_t* __restrict__ val,
                                                        float* __restrict__ T) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int pair = (int)(i / J);
@@ -148,63 +145,23 @@ __global__ __launch_bounds__(256) void row_prep_kernel(const float* __restrict__
     const float san = sa[i], sbn = sb[(int64_t)pair * K + k];
     const float d = __fadd_rn(__fmaf_rn(acc, -2.f, san), sbn);
     // non-finite rows get an infinite bound (they visit every tile)
-    T[i] = d == d ? d + 2e-5f * (1.f + san + sbn) : INFINITY;
-    key[i] = (uint32_t)inv[(int64_t)pair * K + k];
+    T[i] = (d == d && !keep_all) ? d + 2e-5f * (1.f + san + sbn) : INFINITY;
+    key[i] = ((uint32_t)pair << kbits) | (uint32_t)inv[(int64_t)pair * K + k];
     val[i] = (uint32_t)(i % J);
   }
 }
 
-// one block per (row block, pair), one thread per row of the block (rows in the given order): the tiles some row of the block
-// must visit, compacted into a list.  Per (row, tile): 64 FMAs against the tile's centroid (wave-uniform: scalar loads).
-__global__ __launch_bounds__(512) void tile_list_kernel(const float* __restrict__ a, const float* __restrict__ sa,
-                                                        const int32_t* __restrict__ rows, const float* __restrict__ T,
-                                                        const float* __restrict__ cen, const float* __restrict__ cn2,
-                                                        const float* __restrict__ rad, int J, int nt, int rpb, int32_t* __restrict__ tlist,
-                                                        int32_t* __restrict__ tcount, int tl_stride) {
-  __shared__ int flags[MAX_TILES];
-  const int rb = blockIdx.x, pair = blockIdx.y, nrb = gridDim.x;
-  const int pos = rb * rpb + threadIdx.x;
-  const bool live = threadIdx.x < rpb && pos < J;
-  for (int t = threadIdx.x; t < nt; t += blockDim.x) flags[t] = 0;
-  float x[64];
-  float san = 0.f, Tj = -INFINITY;
-  if (live) {
-    const int64_t row = (int64_t)pair * J + rows[(int64_t)pair * J + pos];
-    const float4* ap = reinterpret_cast<const float4*>(a + row * 64);
-#pragma unroll
-    for (int q = 0; q < 16; ++q) { const float4 v = ap[q]; x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w; }
-    san = sa[row];
-    Tj = T[row];
-  } else {
-#pragma unroll
-    for (int q = 0; q < 64; ++q) x[q] = 0.f;
-  }
-  __syncthreads();
-  const float* C = cen + (int64_t)pair * nt * 64;
-  for (int t = 0; t < nt; ++t) {
-    const float* c = C + (int64_t)t * 64;
-    float dot = 0.f;
-#pragma unroll
-    for (int q = 0; q < 64; ++q) dot = fmaf(x[q], c[q], dot);
-    const float c2 = cn2[(int64_t)pair * nt + t];
-    // |a - c|^2 in fp32 (error below 1e-5 (1 + |a|^2 + |c|^2)), pushed DOWN by that margin; the radius was rounded up
-    const float d2 = fmaxf((san + c2) - 2.f * dot - 1e-5f * (1.f + san + c2), 0.f);
-    const float gap = fmaxf(sqrtf(d2) * 0.99999f - rad[(int64_t)pair * nt + t], 0.f);
-    const bool need = live && !(gap * gap > Tj);          // NaN anywhere: visit
-    if (__ballot(need) != 0ull && (threadIdx.x & 63) == 0) flags[t] = 1;
-  }
-  __syncthreads();
-  if (threadIdx.x < 64) {
-    int32_t* out = tlist + ((int64_t)pair * nrb + rb) * tl_stride;
-    int cnt = 0;
-    for (int base = 0; base < nt; base += 64) {
-      const int t = base + (int)threadIdx.x;
-      const bool f = t < nt && flags[t] != 0;
-      const unsigned long long m = __ballot(f);
-      if (f) out[cnt + __popcll(m & ((1ull << threadIdx.x) - 1ull))] = t;
-      cnt += __popcll(m);
-    }
-    if (threadIdx.x == 0) tcount[pair * nrb + rb] = cnt;
+// the ref side's screening operands in column order: 16 bytes per thread (a row of 64 halves = 8 pieces, hi and lo), + the seeds
+__global__ __launch_bounds__(256) void permute_ref_kernel(const uint4* __restrict__ bh, const uint4* __restrict__ bl, const float* __restrict__ sb,
+                                                          const int32_t* __restrict__ cols, int K, int64_t total, uint4* __restrict__ ph,
+                                                          uint4* __restrict__ pl, float* __restrict__ psb) {
+  for (int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; f < total * 8; f += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = f >> 3;
+    const int piece = (int)(f & 7);
+    const int64_t src = (i / K) * K + cols[i];
+    ph[f] = bh[src * 8 + piece];
+    pl[f] = bl[src * 8 + piece];
+    if (piece == 0) psb[i] = sb[src];
   }
 }
 
@@ -217,10 +174,12 @@ __global__ void prune_account_kernel(const int32_t* __restrict__ tcount, int n, 
 }
 
 struct Layout {
-  int32_t *cols, *inv, *rows, *tlist, *tcount;
+  int32_t *cols, *inv, *rows, *tlist, *tcount, *queue, *rborder;
   float *cen, *cn2, *rad, *T, *box;
+  void *ch, *cl;                       // the centroids as the screening's fp16 pairs
+  void *pbh, *pbl;                     // the ref side's fp16 pairs in column order
+  float* psb;
   uint32_t *k0, *k1, *v0, *v1;
-  int* seg;
   void* cub;
   size_t cub_bytes, total;
 };
@@ -238,7 +197,11 @@ Layout carve(void* scratch, int pairs, int J, int K) {
   L.rows = reinterpret_cast<int32_t*>(take((size_t)pairs * J * 4));
   L.tlist = reinterpret_cast<int32_t*>(take((size_t)pairs * nrb * nt * 4));
   L.tcount = reinterpret_cast<int32_t*>(take((size_t)pairs * nrb * 4));
+  L.queue = reinterpret_cast<int32_t*>(take(8 * 4));
+  L.rborder = reinterpret_cast<int32_t*>(take((size_t)pairs * nrb * 4));
   L.cen = reinterpret_cast<float*>(take((size_t)pairs * nt * 64 * 4));
+  L.ch = take((size_t)pairs * nt * 64 * 2);
+  L.cl = take((size_t)pairs * nt * 64 * 2);
   L.cn2 = reinterpret_cast<float*>(take((size_t)pairs * nt * 4));
   L.rad = reinterpret_cast<float*>(take((size_t)pairs * nt * 4));
   L.T = reinterpret_cast<float*>(take((size_t)pairs * J * 4));
@@ -247,67 +210,82 @@ Layout carve(void* scratch, int pairs, int J, int K) {
   L.k1 = reinterpret_cast<uint32_t*>(take(nmax * 4));
   L.v0 = reinterpret_cast<uint32_t*>(take(nmax * 4));
   L.v1 = reinterpret_cast<uint32_t*>(take(nmax * 4));
-  L.seg = reinterpret_cast<int*>(take((size_t)(pairs + 1) * 4));
+  L.pbh = take((size_t)pairs * K * 64 * 2);
+  L.pbl = take((size_t)pairs * K * 64 * 2);
+  L.psb = reinterpret_cast<float*>(take((size_t)pairs * K * 4));
   size_t tmp = 0;
-  hipcub::DeviceSegmentedRadixSort::SortPairs(nullptr, tmp, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr,
-                                              (uint32_t*)nullptr, (int)nmax, pairs, (const int*)nullptr, (const int*)nullptr);
+  hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr,
+                                     (int)nmax, 0, 32);
   L.cub = take(tmp);
   L.cub_bytes = tmp;
   L.total = (size_t)(p - reinterpret_cast<char*>(scratch));
   return L;
 }
 
+inline int bits_for(int n) { int b = 0; while ((1ll << b) < n) ++b; return b; }   // smallest b with 2^b >= n
+
 }  // namespace
 
 bool nn_prune_supported(int pairs, int J, int K) {
-  return (K + TILE - 1) / TILE <= MAX_TILES && (int64_t)pairs * (J > K ? J : K) <= 0x7fffffffll && nn_screen_rows_per_block(J) <= 512;
+  if (bits_for(pairs) + bits_for(K) > 32 || bits_for(pairs) > 12) return false;     // the sorts' composite 32-bit keys
+  return (K + TILE - 1) / TILE <= nn_screen_max_bound_tiles() && (int64_t)pairs * (J > K ? J : K) <= 0x7fffffffll && nn_screen_rows_per_block(J) <= 512;
 }
 
 size_t nn_prune_scratch_bytes(int pairs, int J, int K) { return carve(nullptr, pairs, J, K).total; }
 
 // once per registration: the column order (Morton order of the ref points) and the tiles' centroids / radii
-int launch_prune_ref(const float* ref_xyz, int64_t xyz_cs, const float* desc_r, int pairs, int J, int K, void* scratch, hipStream_t st) {
+int launch_prune_ref(const float* ref_xyz, int64_t xyz_cs, const float* desc_r, const void* bh, const void* bl, const float* sb, int pairs, int J,
+                     int K, void* scratch, hipStream_t st) {
   const Layout L = carve(scratch, pairs, J, K);
   const int nt = (K + TILE - 1) / TILE;
   const int64_t total = (int64_t)pairs * K;
+  const int pbits = bits_for(pairs);
+  const int mbits = 32 - pbits < 30 ? 32 - pbits : 30;
   hipLaunchKernelGGL(bbox_kernel, dim3(pairs), dim3(1024), 0, st, ref_xyz, xyz_cs, K, L.box);
-  hipLaunchKernelGGL(morton_kernel, dim3(grid_for(total)), dim3(256), 0, st, ref_xyz, xyz_cs, K, L.box, total, L.k0, L.v0);
-  hipLaunchKernelGGL(seg_offsets_kernel, dim3(1), dim3(256), 0, st, L.seg, pairs, K);
+  hipLaunchKernelGGL(morton_kernel, dim3(grid_for(total)), dim3(256), 0, st, ref_xyz, xyz_cs, K, L.box, total, mbits, L.k0, L.v0);
   size_t tmp = L.cub_bytes;
-  if (hipcub::DeviceSegmentedRadixSort::SortPairs(L.cub, tmp, L.k0, L.k1, L.v0, L.v1, (int)total, pairs, L.seg, L.seg + 1, 0, 30, st) != hipSuccess)
-    return 1;
-  hipLaunchKernelGGL(order_kernel, dim3(grid_for(total)), dim3(256), 0, st, L.v1, K, total, L.cols, L.inv);
+  if (hipcub::DeviceRadixSort::SortPairs(L.cub, tmp, L.k0, L.k1, L.v0, L.v1, (int)total, 0, mbits + pbits, st) != hipSuccess) return 1;
+  hipLaunchKernelGGL(order_kernel, dim3(grid_for(total)), dim3(256), 0, st, L.v1, K, total, false, L.cols, L.inv);
   const int64_t tiles_total = (int64_t)pairs * nt;
   hipLaunchKernelGGL(tile_stats_kernel, dim3((unsigned)((tiles_total + 3) / 4)), dim3(256), 0, st, desc_r, L.cols, K, nt, tiles_total, L.cen, L.cn2,
                      L.rad);
+  // the centroids in the screening's operand format (and |c|^2 in its summation order): the bound pass runs its MFMA chain
+  launch_split16_norm(L.cen, tiles_total, L.ch, L.cl, L.cn2, st);
+  hipLaunchKernelGGL(permute_ref_kernel, dim3(grid_for(total * 8)), dim3(256), 0, st, reinterpret_cast<const uint4*>(bh),
+                     reinterpret_cast<const uint4*>(bl), sb, L.cols, K, total, reinterpret_cast<uint4*>(L.pbh), reinterpret_cast<uint4*>(L.pbl), L.psb);
   return 0;
 }
 
 // per iteration (>= 1): the row order, the rows' upper bounds and the tile lists of every row block -> ord
-int launch_prune_rows(const float* desc_s, const float* desc_r, const float* sa, const float* sb, const int32_t* idx_prev, int pairs, int J,
-                      int K, void* scratch, hipStream_t st, ScreenOrder* ord, unsigned long long* acc) {
+int launch_prune_rows(const float* desc_s, const float* desc_r, const void* ah, const void* al, const float* sa, const float* sb,
+                      const int32_t* idx_prev, int pairs, int J, int K, void* scratch, hipStream_t st, ScreenOrder* ord, unsigned long long* acc) {
   const Layout L = carve(scratch, pairs, J, K);
   const int nt = (K + TILE - 1) / TILE;
   const int rpb = nn_screen_rows_per_block(J);
   const int nrb = (J + rpb - 1) / rpb;
   const int64_t total = (int64_t)pairs * J;
-  hipLaunchKernelGGL(row_prep_kernel, dim3(grid_for(total)), dim3(256), 0, st, desc_s, desc_r, sa, sb, idx_prev, L.inv, J, K, total, L.k0, L.v0,
-                     L.T);
-  hipLaunchKernelGGL(seg_offsets_kernel, dim3(1), dim3(256), 0, st, L.seg, pairs, J);
+  const int kbits = bits_for(K);
+  static const bool id_rows = getenv("DSIR_PRUNE_ID_ROWS") != nullptr;     // measurement hook: rows in their natural order
+  static const bool no_lpt = getenv("DSIR_PRUNE_NO_LPT") != nullptr;       // A/B hook: items in row-block order
+  static const bool keep_all = getenv("DSIR_PRUNE_KEEP_ALL") != nullptr;   // measurement hook: every tile on every list (the mechanism's own cost)
+  hipLaunchKernelGGL(row_prep_kernel, dim3(grid_for(total)), dim3(256), 0, st, desc_s, desc_r, sa, sb, idx_prev, L.inv, J, K, kbits, total, keep_all, L.k0,
+                     L.v0, L.T);
   size_t tmp = L.cub_bytes;
-  int bits = 1;
-  while ((1 << bits) < K && bits < 31) ++bits;
-  if (hipcub::DeviceSegmentedRadixSort::SortPairs(L.cub, tmp, L.k0, L.k1, L.v0, L.v1, (int)total, pairs, L.seg, L.seg + 1, 0, bits, st) != hipSuccess)
-    return 1;
-  hipLaunchKernelGGL(order_kernel, dim3(grid_for(total)), dim3(256), 0, st, L.v1, J, total, L.rows, (int32_t*)nullptr);
-  hipLaunchKernelGGL(tile_list_kernel, dim3(nrb, pairs), dim3(512), 0, st, desc_s, sa, L.rows, L.T, L.cen, L.cn2, L.rad, J, nt, rpb, L.tlist,
-                     L.tcount, nt);
+  if (hipcub::DeviceRadixSort::SortPairs(L.cub, tmp, L.k0, L.k1, L.v0, L.v1, (int)total, 0, kbits + bits_for(pairs), st) != hipSuccess) return 1;
+  hipLaunchKernelGGL(order_kernel, dim3(grid_for(total)), dim3(256), 0, st, L.v1, J, total, id_rows, L.rows, (int32_t*)nullptr);
+  launch_tile_bound(ah, al, sa, L.rows, L.T, L.ch, L.cl, L.cn2, L.rad, pairs, J, nt, L.tlist, L.tcount, nt, no_lpt ? nullptr : L.rborder, st);
   if (acc) hipLaunchKernelGGL(prune_account_kernel, dim3(1), dim3(256), 0, st, L.tcount, pairs * nrb, nt, acc);
   ord->rows = L.rows;
   ord->cols = L.cols;
+  ord->bh = L.pbh;
+  ord->bl = L.pbl;
+  ord->sbp = L.psb;
   ord->tlist = L.tlist;
   ord->tcount = L.tcount;
   ord->tl_stride = nt;
+  (void)hipMemsetAsync(L.queue, 0, 8 * 4, st);
+  ord->queue = L.queue;
+  ord->rborder = no_lpt ? nullptr : L.rborder;
   return 0;
 }
 

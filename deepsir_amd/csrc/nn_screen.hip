@@ -165,14 +165,17 @@ __global__ __launch_bounds__(256) void split_norm_kernel(const float* __restrict
 #else
 #define DSIR_MORE(x) (x)
 #endif
-template <int RT, int NWV>
+constexpr int kMaxBoundTiles = 4096;   // tiles of a pruned search's column order (LDS: tile flags of the bound pass, an item's tile list)
+// ORD = false: the dense search (every tile of the item's column range, natural row / column order) - the `ord` fields are not
+// touched and the code is the round-2 kernel's; ORD = true: the pruned search of nn_prune.hip (row / column orders, tile lists)
+template <int RT, int NWV, bool ORD>
 __device__ __forceinline__ void screen_item(const int wi, const _Float16* __restrict__ Ah, const _Float16* __restrict__ Al,
                                                      const _Float16* __restrict__ Bh, const _Float16* __restrict__ Bl,
                                                      const float* __restrict__ sa, const float* __restrict__ sb, int J, int K,
                                                      int cols_per_split, int rb_count, int splits,
                                                      unsigned int* __restrict__ umin, int32_t* __restrict__ cnt,
                                                      int2* __restrict__ cand, int32_t* __restrict__ ovf,
-                                                     int32_t* __restrict__ rowlist, int ovf_min) {
+                                                     int32_t* __restrict__ rowlist, int ovf_min, const ScreenOrder ord) {
   constexpr int NP = SBC * 8 / (NWV * 64);          // 16-byte pieces of each tile part per thread
   static_assert(NP >= 1 && NP * NWV * 64 == SBC * 8, "staging layout");
   constexpr int NSB = SBC * 4 / (NWV * 64) > 0 ? SBC * 4 / (NWV * 64) : 1;   // replicated accumulator seeds per thread
@@ -181,9 +184,10 @@ __device__ __forceinline__ void screen_item(const int wi, const _Float16* __rest
   __shared__ float4 sbs[2][SBC];                    // 2^11 c, c = -(|b|^2 - d_b) / 2, replicated x4: the first MFMA's C operand
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fq = lane >> 4;
-  const int rb = wi % rb_count;
+  int rb = wi % rb_count;
   const int split = (wi / rb_count) % splits;
   const int pair = wi / (rb_count * splits);
+  if (ORD && ord.rborder) rb = ord.rborder[pair * rb_count + rb];   // pruned search: row blocks in the order of their tile counts, longest first
   const int row0 = (rb * NWV + w) * (16 * RT);
   const int64_t arow = (int64_t)pair * J, brow = (int64_t)pair * K;
   // a pair with that many undecidable rows is searched exhaustively as a whole.  The counter grows while the kernel runs
@@ -200,7 +204,8 @@ __device__ __forceinline__ void screen_item(const int wi, const _Float16* __rest
   h8 ah[RT][2], al[RT][2];
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
-    const int row = min(row0 + rt * 16 + fr, J - 1);
+    int row = min(row0 + rt * 16 + fr, J - 1);
+    if (ORD && ord.rows) row = ord.rows[arow + row];   // pruned search: the block's rows are rows [row0, ..) of the given ORDER
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       ah[rt][c] = *reinterpret_cast<const h8*>(Ah + (arow + row) * 64 + 32 * c + 8 * fq);
@@ -217,25 +222,59 @@ __device__ __forceinline__ void screen_item(const int wi, const _Float16* __rest
 
   const int c_begin = split * cols_per_split;
   const int c_end = min(K, c_begin + cols_per_split);
+  // the item's tile sequence: dense (every tile of its column range) or, pruned search, its share of the block's tile LIST;
+  // columns are positions in the given column ORDER (ord.cols: position -> ref row; nullptr: identity)
+  const int32_t* tl = nullptr;
+  int n_i = (c_end - c_begin + SBC - 1) / SBC;
+  if (ORD && ord.tlist) {
+    const int n_all = ord.tcount[pair * rb_count + rb];
+    const int li0 = (int)((int64_t)split * n_all / splits), li1 = (int)((int64_t)(split + 1) * n_all / splits);
+    tl = ord.tlist + ((int64_t)pair * rb_count + rb) * ord.tl_stride + li0;
+    n_i = li1 - li0;
+  }
+  n_i = __builtin_amdgcn_readfirstlane(n_i);
+  if (n_i <= 0) return;                                // block-uniform; nothing of this row block falls to this split
+  // the item's tile list in LDS: a tile's fetch must not wait for a global load of its own address first (the prefetch
+  // distance of three tiles, ~4 us, does not cover two dependent trips to L2 / HBM under load)
+  __shared__ int tls[ORD ? kMaxBoundTiles : 1];
+  if (ORD && tl) {
+    for (int i = tid; i < n_i; i += NWV * 64) tls[i] = tl[i];
+    __syncthreads();                                   // (the item's first barrier pair above keeps the previous item's readers out)
+  }
+  auto tile_c0 = [&](int i) -> int {
+    if (!ORD) return c_begin + i * SBC;                // dense: plain arithmetic, addresses clamped by the loads
+    const int ic = min(i, n_i - 1);
+    return tl ? tls[ic] * SBC : c_begin + ic * SBC;
+  };
+  const int c_lim = (ORD && tl) ? K : c_end;
   // staging: thread -> 16-byte piece (8 channels) of the tile: column f >> 3, piece f & 7
   // two register sets: a tile is fetched two iterations before it is needed (the L2 / MALL latency under load exceeds
   // the time of one tile) and written to the free LDS buffer at the end of the iteration before
-  struct Pre { h8 h[NP], l[NP]; float sb[NSB]; };
+  // sb: the accumulator seeds.  Pruned search: |b|^2 as loaded + column-in-range bits (`ok`), the seed formed when the tile is
+  // stored to LDS: its gload branches, and with the use next to the load the compiler waited THERE - s_waitcnt vmcnt(0) behind
+  // the tile fetches just issued, once per tile (ISA; 15 % of the kernel).  The dense search keeps the round-2 form (the same
+  // restructuring measured 3 % slower there)
+  struct Pre { h8 h[NP], l[NP]; float sb[NSB]; unsigned ok; };
   Pre preA, preB;
-  auto gload = [&](Pre& pre, int c0) {
+  auto gload = [&](Pre& pre, int it) {                 // tile `it` of the sequence (past its end: clamped, never used)
+    const int c0 = tile_c0(it);
+    const bool live = !ORD || it < n_i;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
       const int f = tid + NWV * 64 * i;
-      const int r = min(c0 + (f >> 3), K - 1);
+      const int r = min(c0 + (f >> 3), K - 1);       // ORD: Bh / Bl are the copies in column order
       pre.h[i] = *reinterpret_cast<const h8*>(Bh + (brow + r) * 64 + 8 * (f & 7));
       pre.l[i] = *reinterpret_cast<const h8*>(Bl + (brow + r) * 64 + 8 * (f & 7));
     }
+    pre.ok = 0u;
 #pragma unroll
     for (int i = 0; i < NSB; ++i) {
       const int f = tid + NWV * 64 * i;
       const int col = c0 + (f >> 2);
-      const float s = sb[brow + min(col, K - 1)];
-      pre.sb[i] = (col < c_end && f < SBC * 4) ? -2097152.f * (s - kC1 * s) : -INFINITY;   // columns past the range never win
+      const int r = min(col, K - 1);
+      const bool ok = live && col < c_lim && f < SBC * 4;                 // columns past the range never win
+      if (ORD) { pre.sb[i] = ord.sbp[brow + r]; pre.ok |= ok ? 1u << i : 0u; }
+      else { const float s = sb[brow + r]; pre.sb[i] = ok ? -2097152.f * (s - kC1 * s) : -INFINITY; }
     }
   };
   auto lstore = [&](const Pre& pre, int buf) {
@@ -248,7 +287,9 @@ __device__ __forceinline__ void screen_item(const int wi, const _Float16* __rest
 #pragma unroll
     for (int i = 0; i < NSB; ++i) {
       const int f = tid + NWV * 64 * i;
-      if (f < SBC * 4) reinterpret_cast<float*>(sbs[buf])[f] = pre.sb[i];
+      // the accumulator seed 2^22 c, c = -(|b|^2 - d_b) / 2; columns past the range never win
+      if (f < SBC * 4)
+        reinterpret_cast<float*>(sbs[buf])[f] = !ORD ? pre.sb[i] : ((pre.ok >> i) & 1u) ? -2097152.f * (pre.sb[i] - kC1 * pre.sb[i]) : -INFINITY;
     }
   };
   // fragments of one 16-column step: lane holds column fr of the step, channels 8 fq .. (+32)
@@ -293,7 +334,8 @@ __device__ __forceinline__ void screen_item(const int wi, const _Float16* __rest
     colP = col;
   };
   // one tile: ranks into (z1, z2, k1); `pre` holds the tile after it and is refilled with the one two further on
-  auto tile = [&](int c0, int buf, Pre& pre) {
+  auto tile = [&](int it, int buf, Pre& pre) {
+    const int c0 = tile_c0(it);
     const _Float16* bhp = &Bs[buf][0][fr * SRS + 8 * fq];
     const _Float16* blp = &Bs[buf][1][fr * SRS + 8 * fq];
     const float4* cp = &sbs[buf][fr];
@@ -308,21 +350,32 @@ __device__ __forceinline__ void screen_item(const int wi, const _Float16* __rest
     }
 #ifndef DSIR_ABL_NOSTAGE
     lstore(pre, buf ^ 1);
-    gload(pre, c0 + 3 * SBC);                         // clamped addresses: harmless past the range
+    gload(pre, it + 3);                               // clamped addresses: harmless past the range
     __syncthreads();
 #endif
   };
 #undef DSIR_MFMA
   // all three fetches in flight before the first store waits for its own (vmcnt counts them in order)
   Pre pre0;
-  gload(pre0, c_begin);
-  gload(preA, c_begin + SBC);
-  gload(preB, c_begin + 2 * SBC);
+  gload(pre0, 0);
+  gload(preA, 1);
+  gload(preB, 2);
   lstore(pre0, 0);
   __syncthreads();
-  for (int c0 = c_begin; c0 < c_end; c0 += 2 * SBC) {
-    tile(c0, 0, preA);
-    if (c0 + SBC < c_end) tile(c0 + SBC, 1, preB);
+  if (ORD) {
+    // two tiles per trip, the odd last one peeled: a straight-line loop body, for which the compiler's vmcnt bookkeeping of the
+    // two fetch sets in flight is exact (vmcnt(5), (4), (3) in front of the three stores of a set)
+    int it = 0;
+    for (; it + 1 < n_i; it += 2) {
+      tile(it, 0, preA);
+      tile(it + 1, 1, preB);
+    }
+    if (it < n_i) tile(it, 0, preA);
+  } else {
+    for (int it = 0; it < n_i; it += 2) {
+      tile(it, 0, preA);
+      if (it + 1 < n_i) tile(it + 1, 1, preB);
+    }
   }
   // the last step's accumulators
 #pragma unroll
@@ -336,18 +389,32 @@ __device__ __forceinline__ void screen_item(const int wi, const _Float16* __rest
   // the epilogue's gathers (|a|^2 of the lane's rows, |b|^2 of their best columns) first, all independent: one memory
   // latency for the 4 RT elements instead of one each in front of the atomics
   float sanv[RT][4], sbkv[RT][4];
+  int rowv[RT][4];
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      sanv[rt][r] = sa[arow + min(row0 + rt * 16 + 4 * fq + r, J - 1)];
-      sbkv[rt][r] = sb[brow + max(k1[rt][r], 0)];
+      int ro = min(row0 + rt * 16 + 4 * fq + r, J - 1);
+      if (ORD && ord.rows) ro = ord.rows[arow + ro];
+      rowv[rt][r] = ro;
+      int ko = max(k1[rt][r], 0);
+      if (ORD && ord.cols) {                           // k1 is a position in the column order: back to the ref row
+        ko = ord.cols[brow + ko];
+        if (k1[rt][r] >= 0) k1[rt][r] = ko;
+      }
+      sanv[rt][r] = sa[arow + ro];
+      sbkv[rt][r] = sb[brow + ko];
     }
+  // three passes over the lane's 4 RT elements, so that the memory round trips of a pass overlap instead of queueing behind
+  // each other (16 dependent trips per item before; rows in a given order scatter them over as many cache lines):
+  // thresholds + atomicMin (no return) -> one counted atomicAdd per element (both of its entries) -> the entries' stores
+  float l1v[RT][4], l2v[RT][4];
+  int nent[RT][4], base[RT][4];
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int row = row0 + rt * 16 + 4 * fq + r;
+      const bool live_row = row0 + rt * 16 + 4 * fq + r < J;
       const float san = sanv[rt][r];
       const float slo = san - kC1 * san - kC0;       // |a|^2 - d_a
       // z' = 2^22 z: L = slo - 2 z = slo - 2^-21 z'
@@ -358,37 +425,73 @@ __device__ __forceinline__ void screen_item(const int wi, const _Float16* __rest
       float T = u;
 #pragma unroll
       for (int o = 1; o < 16; o <<= 1) T = fminf(T, __shfl_xor(T, o));
-      if (row < J) {
-        if (fr == 0) atomicMin(umin + arow + row, order_bits(T));
-        auto emit = [&](int code, float lower) {
-          const int slot = atomicAdd(cnt + arow + row, 1);
-          if (slot < CAP) cand[(arow + row) * CAP + slot] = make_int2(code, __float_as_int(lower));
-          else if (slot == CAP) rowlist[arow + atomicAdd(ovf + pair, 1)] = row;   // this row just overflowed (once per row)
-        };
-        if (k >= 0 && l1 <= T) emit(k, l1);
-        // a second column of this lane's class (columns c_begin + fr + 16 m of this split) may qualify as well: which
-        // one is not tracked, so the class itself becomes an entry and the row goes to the exhaustive kernel
-        if (l2 <= T) emit(-(1 + split * 16 + fr), l2);
-      }
+      if (live_row && fr == 0) atomicMin(umin + arow + rowv[rt][r], order_bits(T));
+      l1v[rt][r] = l1; l2v[rt][r] = l2;
+      // entries of this element: its best column (code k) and / or its class: a second column of this lane's class (columns
+      // c_begin + fr + 16 m of this split) may qualify as well - which one is not tracked, so the class itself becomes an
+      // entry and the row goes to the exhaustive kernel
+      nent[rt][r] = live_row ? ((k >= 0 && l1 <= T) ? 1 : 0) + (l2 <= T ? 2 : 0) : 0;      // bit 0: column entry, bit 1: class entry
+    }
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = (nent[rt][r] & 1) + (nent[rt][r] >> 1);
+      base[rt][r] = n ? atomicAdd(cnt + arow + rowv[rt][r], n) : 0;
+    }
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = rowv[rt][r];
+      int slot = base[rt][r];
+      auto emit = [&](int code, float lower) {
+        if (slot < CAP) cand[(arow + row) * CAP + slot] = make_int2(code, __float_as_int(lower));
+        else if (slot == CAP) rowlist[arow + atomicAdd(ovf + pair, 1)] = row;   // this row just overflowed (once per row)
+        ++slot;
+      };
+      if (nent[rt][r] & 1) emit(k1[rt][r], l1v[rt][r]);
+      if (nent[rt][r] & 2) emit(-(1 + split * 16 + fr), l2v[rt][r]);
     }
 }
 
 // The launch: one work item (pair, ref split, row block) per workgroup, or - DSIR_SCREEN_PERSIST workgroups per CU - a
 // persistent grid whose workgroups walk the items with stride gridDim (no workgroup launch / drain between items).  XCD-aware
 // in both forms: workgroups are dealt round-robin over the 8 XCDs, the remap hands every XCD a contiguous range of items.
-template <int RT, int NWV>
+template <int RT, int NWV, bool ORD>
 __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(DSIR_SCREEN_WPE, DSIR_SCREEN_WPE))) void screen_kernel(const _Float16* __restrict__ Ah, const _Float16* __restrict__ Al,
                                                      const _Float16* __restrict__ Bh, const _Float16* __restrict__ Bl,
                                                      const float* __restrict__ sa, const float* __restrict__ sb, int J, int K,
                                                      int cols_per_split, int rb_count, int splits,
                                                      unsigned int* __restrict__ umin, int32_t* __restrict__ cnt,
                                                      int2* __restrict__ cand, int32_t* __restrict__ ovf,
-                                                     int32_t* __restrict__ rowlist, int ovf_min, int total) {
+                                                     int32_t* __restrict__ rowlist, int ovf_min, int total, const ScreenOrder ord) {
   const int nwg = gridDim.x, id = blockIdx.x;
+  if (ORD) {
+    // pruned search: items differ in length (per pair and along the row order), so the static deal below would leave XCDs idle
+    // while others still work.  A persistent grid instead: every XCD owns a queue - the contiguous item range the static deal
+    // would give it, for the same L2 locality - and its workgroups pop items from it; a workgroup whose queue is empty helps
+    // the next XCD's.  Every workgroup leaves after finding all 8 queues empty.
+    __shared__ int s_wi;
+    const int q8 = total >> 3, r8 = total & 7;
+    for (int q = 0; q < 8; ++q) {
+      const int x = ((id & 7) + q) & 7;
+      const int start = x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8, len = q8 + (x < r8 ? 1 : 0);
+      for (;;) {
+        if (threadIdx.x == 0) s_wi = atomicAdd(ord.queue + x, 1);
+        __syncthreads();
+        const int i = s_wi;
+        __syncthreads();
+        if (i >= len) break;
+        screen_item<RT, NWV, ORD>(start + i, Ah, Al, Bh, Bl, sa, sb, J, K, cols_per_split, rb_count, splits, umin, cnt, cand, ovf, rowlist, ovf_min, ord);
+      }
+    }
+    return;
+  }
   const int q8 = nwg >> 3, r8 = nwg & 7, xcd = id & 7;
   const int first = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3);
   for (int wi = first; wi < total; wi += nwg)
-    screen_item<RT, NWV>(wi, Ah, Al, Bh, Bl, sa, sb, J, K, cols_per_split, rb_count, splits, umin, cnt, cand, ovf, rowlist, ovf_min);
+    screen_item<RT, NWV, ORD>(wi, Ah, Al, Bh, Bl, sa, sb, J, K, cols_per_split, rb_count, splits, umin, cnt, cand, ovf, rowlist, ovf_min, ord);
 }
 
 // exact D(row, k) exactly as nn_match.hip evaluates it: the k-ordered fmaf chain of v_mfma_f32_16x16x4_f32 from a zero
@@ -588,11 +691,140 @@ __global__ void screen_export_kernel(const unsigned int* __restrict__ umin, cons
   }
 }
 
+// ---- the bound pass of the pruned search (nn_prune.hip) on the matrix core: which column tiles must a row block visit?
+// A tile t (64 ref columns, centroid c_t, radius r_t) can be skipped by a row whose minimum is known to be <= T iff
+// (|a - c_t| - r_t)_+^2 > T.  |a - c_t|^2 is bounded from BELOW by this file's own screening bound: the centroids are split like
+// descriptors and L(a, c_t) <= D(a, c_t) comes out of the same six-MFMA chain (rows x nt centroids: 1/64 of a search).
+// Block = 8 waves x RT row tiles = one row block of the screening (rows in the given order); per 16-centroid step every lane
+// tests its column against its 4 RT rows, the wave folds the answers into a 16-bit column mask, and the tiles some row needs
+// are compacted into the block's list.
+template <int RT>
+__global__ __launch_bounds__(512) void tile_bound_kernel(const _Float16* __restrict__ Ah, const _Float16* __restrict__ Al,
+                                                         const float* __restrict__ sa, const int32_t* __restrict__ rows,
+                                                         const float* __restrict__ T, const _Float16* __restrict__ Ch,
+                                                         const _Float16* __restrict__ Cl, const float* __restrict__ cn2,
+                                                         const float* __restrict__ rad, int J, int nt, int32_t* __restrict__ tlist,
+                                                         int32_t* __restrict__ tcount, int tl_stride) {
+  __shared__ unsigned int flags[kMaxBoundTiles / 16];
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fq = lane >> 4;
+  const int rb = blockIdx.x, pair = blockIdx.y, nrb = gridDim.x;
+  const int64_t arow = (int64_t)pair * J;
+  const int row0 = (rb * 8 + w) * (16 * RT);
+  const int nsteps = (nt + 15) >> 4;
+  for (int i = tid; i < nsteps; i += 512) flags[i] = 0u;
+  h8 ah[RT][2], al[RT][2];
+  float slo[RT][4], Tv[RT][4], mrg[RT][4];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    const int ra = rows[arow + min(row0 + rt * 16 + fr, J - 1)];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      ah[rt][c] = *reinterpret_cast<const h8*>(Ah + (arow + ra) * 64 + 32 * c + 8 * fq);
+      al[rt][c] = *reinterpret_cast<const h8*>(Al + (arow + ra) * 64 + 32 * c + 8 * fq);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int pos = row0 + rt * 16 + 4 * fq + r;
+      const int re = rows[arow + min(pos, J - 1)];
+      const float san = sa[arow + re];
+      slo[rt][r] = san - kC1 * san - kC0;
+      mrg[rt][r] = 1e-5f * (1.f + san);
+      Tv[rt][r] = pos < J ? T[arow + re] : -INFINITY;       // rows past the end need nothing
+    }
+  }
+  __syncthreads();
+  const _Float16* ch = Ch + (int64_t)pair * nt * 64;
+  const _Float16* cl = Cl + (int64_t)pair * nt * 64;
+  for (int s = 0; s < nsteps; ++s) {
+    const int t = 16 * s + fr;
+    const int tc = min(t, nt - 1);
+    const h8 bh0 = *reinterpret_cast<const h8*>(ch + (int64_t)tc * 64 + 8 * fq), bh1 = *reinterpret_cast<const h8*>(ch + (int64_t)tc * 64 + 32 + 8 * fq);
+    const h8 bl0 = *reinterpret_cast<const h8*>(cl + (int64_t)tc * 64 + 8 * fq), bl1 = *reinterpret_cast<const h8*>(cl + (int64_t)tc * 64 + 32 + 8 * fq);
+    const float c2 = cn2[(int64_t)pair * nt + tc];
+    const float rt_ = rad[(int64_t)pair * nt + tc];
+    const float seed = t < nt ? -2097152.f * (c2 - kC1 * c2) : -INFINITY;      // tiles past the end: L = +inf, never needed
+    bool need = false;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      f32x4 z = f32x4{seed, seed, seed, seed};
+      z = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[rt][0], bh0, z, 0, 0, 0);      // screen_item's chain
+      z = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[rt][1], bh1, z, 0, 0, 0);
+      z = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[rt][0], bl0, z, 0, 0, 0);
+      z = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[rt][0], bh0, z, 0, 0, 0);
+      z = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[rt][1], bl1, z, 0, 0, 0);
+      z = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[rt][1], bh1, z, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        // L <= D(a, c) (the screening bound), D(a, c) within mrg + 1e-5 c2 of the true |a - c|^2: a lower bound of that
+        const float lo = fmaf(z[r], -4.76837158203125e-7f, slo[rt][r]) - mrg[rt][r] - 1e-5f * c2;
+        const float gap = fmaxf(sqrtf(fmaxf(lo, 0.f)) * 0.99999f - rt_, 0.f);
+        need = need || !(gap * gap > Tv[rt][r]);                                 // NaN anywhere: visit; Tv = -inf: never
+      }
+    }
+    const unsigned long long m = __ballot(need);
+    const unsigned int m16 = (unsigned int)((m | (m >> 16) | (m >> 32) | (m >> 48)) & 0xffffull);
+    if (lane == 0 && m16) atomicOr(&flags[s], m16);
+  }
+  __syncthreads();
+  if (tid < 64) {
+    int32_t* out = tlist + ((int64_t)pair * nrb + rb) * tl_stride;
+    int cnt = 0;
+    for (int base = 0; base < nt; base += 64) {
+      const int t = base + tid;
+      const bool f = t < nt && ((flags[t >> 4] >> (t & 15)) & 1u);
+      const unsigned long long m = __ballot(f);
+      if (f) out[cnt + __popcll(m & ((1ull << tid) - 1ull))] = t;
+      cnt += __popcll(m);
+    }
+    if (tid == 0) tcount[pair * nrb + rb] = cnt;
+  }
+}
+
+// the row blocks of every pair by descending tile count (ties: by index): the persistent search takes the long items first, so
+// that its last round is made of short ones (longest-processing-time-first; the tail of a launch was up to one full-length item,
+// 18 % of the kernel at 65536 points).  One workgroup per pair, rank by counting - a pair has at most a few hundred row blocks
+__global__ __launch_bounds__(256) void rank_blocks_kernel(const int32_t* __restrict__ tcount, int nrb, int32_t* __restrict__ rborder) {
+  const int32_t* c = tcount + (int64_t)blockIdx.x * nrb;
+  int32_t* out = rborder + (int64_t)blockIdx.x * nrb;
+  for (int i = threadIdx.x; i < nrb; i += 256) {
+    const int ci = c[i];
+    int rank = 0;
+    for (int j = 0; j < nrb; ++j) { const int cj = c[j]; rank += (cj > ci || (cj == ci && j < i)) ? 1 : 0; }
+    out[rank] = i;
+  }
+}
+
 inline int grid_for(int64_t n) { const int64_t g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > 65535 ? 65535 : g)); }
 
 }  // namespace
 
+int nn_screen_max_bound_tiles() { return kMaxBoundTiles; }
+
+// tile lists of every (pair, row block) for the row order `rows` and the per-row upper bounds T (nn_prune.hip)
+void launch_tile_bound(const void* ah, const void* al, const float* sa, const int32_t* rows, const float* T, const void* ch, const void* cl,
+                       const float* cn2, const float* rad, int pairs, int J, int nt, int32_t* tlist, int32_t* tcount, int tl_stride,
+                       int32_t* rborder, hipStream_t st) {
+  const int rpb = nn_screen_rows_per_block(J);
+  const dim3 grid((J + rpb - 1) / rpb, pairs);
+  const _Float16 *Ah = reinterpret_cast<const _Float16*>(ah), *Al = reinterpret_cast<const _Float16*>(al);
+  const _Float16 *Ch = reinterpret_cast<const _Float16*>(ch), *Cl = reinterpret_cast<const _Float16*>(cl);
+  if (rpb == 512) hipLaunchKernelGGL(tile_bound_kernel<4>, grid, dim3(512), 0, st, Ah, Al, sa, rows, T, Ch, Cl, cn2, rad, J, nt, tlist, tcount, tl_stride);
+  else            hipLaunchKernelGGL(tile_bound_kernel<2>, grid, dim3(512), 0, st, Ah, Al, sa, rows, T, Ch, Cl, cn2, rad, J, nt, tlist, tcount, tl_stride);
+  if (rborder) hipLaunchKernelGGL(rank_blocks_kernel, dim3(pairs), dim3(256), 0, st, tcount, (int)grid.x, rborder);
+}
+
 int nn_screen_cap() { return CAP; }
+
+// row tiles per wave: four (512-row blocks: every ref fragment read from LDS feeds four MFMA chains, -12 % kernel time at
+// J = 5000) unless the padding of J to whole blocks costs more than that
+int nn_screen_rows_per_block(int J) {
+  constexpr int NWV = DSIR_SCREEN_NWV;
+  static const int force_rt = getenv("DSIR_SCREEN_RT") ? atoi(getenv("DSIR_SCREEN_RT")) : DSIR_SCREEN_RT;   // A/B hook
+  auto padded = [&](int rt) { const int64_t r = NWV * 16 * rt; return ((J + r - 1) / r) * r; };
+  const int RT = force_rt == 2 || force_rt == 4 ? force_rt : (0.88 * (double)padded(4) <= (double)padded(2) ? 4 : 2);
+  return NWV * 16 * RT;
+}
 
 void launch_screen_bounds(const float* a, const float* b, const void* ah, const void* al, const void* bh, const void* bl,
                           const float* sa, const float* sb, int J, int K, float* lower, float* upper, float* exact,
@@ -637,7 +869,8 @@ void launch_split16_norm(const float* x, int64_t rows, void* hi, void* lo, float
 void launch_nn_screen(const float* a, const float* b, const void* ah, const void* al, const void* bh, const void* bl,
                       const float* sa, const float* sb, int pairs, int J, int K, int32_t* idx, void* scratch, hipStream_t st,
                       hipEvent_t ev0, hipEvent_t ev1, unsigned long long* stats, bool keep_gate, const int32_t* bad,
-                      unsigned long long* acc, hipEvent_t evk0, hipEvent_t evk1) {
+                      unsigned long long* acc, hipEvent_t evk0, hipEvent_t evk1, const ScreenOrder& ord_in) {
+  ScreenOrder ord = ord_in;
   const size_t rows = (size_t)pairs * J;
   char* p = reinterpret_cast<char*>(scratch);
   auto take = [&](size_t bytes) { char* r = p; p += (bytes + 255) & ~(size_t)255; return r; };
@@ -662,10 +895,8 @@ void launch_nn_screen(const float* a, const float* b, const void* ah, const void
   constexpr int NWV = DSIR_SCREEN_NWV;   // waves per block: they share one staged ref tile (the L2 -> LDS fill is the scarce resource)
   // row tiles per wave: four (512-row blocks: every ref fragment read from LDS feeds four MFMA chains, -12 % kernel time
   // at J = 5000) unless the padding of J to whole blocks costs more than that
-  static const int force_rt = getenv("DSIR_SCREEN_RT") ? atoi(getenv("DSIR_SCREEN_RT")) : DSIR_SCREEN_RT;   // A/B hook
-  auto padded = [&](int rt) { const int64_t r = NWV * 16 * rt; return ((J + r - 1) / r) * r; };
-  const int RT = force_rt == 2 || force_rt == 4 ? force_rt : (0.88 * (double)padded(4) <= (double)padded(2) ? 4 : 2);
-  const int rows_per_block = NWV * 16 * RT;
+  const int rows_per_block = nn_screen_rows_per_block(J);
+  const int RT = rows_per_block / (NWV * 16);
   const int rb_count = (J + rows_per_block - 1) / rows_per_block;
   const int64_t base = (int64_t)pairs * rb_count;
   const int tiles = (K + SBC - 1) / SBC;
@@ -694,16 +925,22 @@ void launch_nn_screen(const float* a, const float* b, const void* ah, const void
   splits = (K + cols - 1) / cols;
   const int total = (int)((int64_t)rb_count * splits * pairs);
   static const int persist = getenv("DSIR_SCREEN_PERSIST") ? atoi(getenv("DSIR_SCREEN_PERSIST")) : 0;   // workgroups per CU; 0 = one per item
-  const dim3 grid((unsigned)(persist > 0 && total > persist * resident ? persist * resident : total));
+  const bool ordered = ord.tlist && ord.queue;         // launch_prune_rows fills every field or none
+  const dim3 grid(ordered ? (unsigned)(total < resident ? total : resident)             // persistent, per-XCD item queues (screen_kernel)
+                          : (unsigned)(persist > 0 && total > persist * resident ? persist * resident : total));
   const _Float16 *Ah = reinterpret_cast<const _Float16*>(ah), *Al = reinterpret_cast<const _Float16*>(al);
   const _Float16 *Bh = reinterpret_cast<const _Float16*>(bh), *Bl = reinterpret_cast<const _Float16*>(bl);
   if (evk0) (void)hipEventRecord(evk0, st);
-  if (RT == 4)
-    hipLaunchKernelGGL((screen_kernel<4, NWV>), grid, dim3(NWV * 64), 0, st, Ah, Al, Bh, Bl, sa, sb, J, K, cols, rb_count, splits, umin,
-                       cnt, cand, ovf, rowlist, ovf_min, total);
-  else
-    hipLaunchKernelGGL((screen_kernel<2, NWV>), grid, dim3(NWV * 64), 0, st, Ah, Al, Bh, Bl, sa, sb, J, K, cols, rb_count, splits, umin,
-                       cnt, cand, ovf, rowlist, ovf_min, total);
+  if (ordered) {                                       // the pruned search streams the ref side's copies in column order
+    if (ord.cols) { Bh = reinterpret_cast<const _Float16*>(ord.bh); Bl = reinterpret_cast<const _Float16*>(ord.bl); }
+    else ord.sbp = sb;
+  }
+#define DSIR_LAUNCH_SCREEN(RTV, ORDV)                                                                                                  \
+  hipLaunchKernelGGL((screen_kernel<RTV, NWV, ORDV>), grid, dim3(NWV * 64), 0, st, Ah, Al, Bh, Bl, sa, sb, J, K, cols, rb_count, splits, \
+                     umin, cnt, cand, ovf, rowlist, ovf_min, total, ord)
+  if (RT == 4) { if (ordered) DSIR_LAUNCH_SCREEN(4, true); else DSIR_LAUNCH_SCREEN(4, false); }
+  else         { if (ordered) DSIR_LAUNCH_SCREEN(2, true); else DSIR_LAUNCH_SCREEN(2, false); }
+#undef DSIR_LAUNCH_SCREEN
   if (evk1) (void)hipEventRecord(evk1, st);
   hipLaunchKernelGGL(exact_pick_kernel, dim3((J + 255) / 256, pairs), dim3(256), 0, st, a, b, sa, sb, J, K, umin, cnt, cand, ovf,
                      ovf_min, rowlist, idx);

@@ -515,6 +515,17 @@ class Engine:
         self._call(self.lib.dsir_screen_stats(self.h, 1 if reset else 0, out))
         return {k: int(out[i]) for i, k in enumerate(self.SCREEN_STAT_NAMES)}
 
+    def prune_stats(self, reset=True) -> Tuple[int, int]:
+        """(tile products visited, tile products without pruning) of the pruned search since the last reset (dsir_prune_stats)."""
+        out = (C.c_int64 * 2)()
+        self._call(self.lib.dsir_prune_stats(self.h, 1 if reset else 0, out))
+        return int(out[0]), int(out[1])
+
+    def set_prune_min_points(self, min_points: int):
+        """A/B switch: the pruned search runs for ref clouds of that many points and more (0 = never; same bits either way;
+        include/dsir.h, dsir_set_prune_min_points)."""
+        self._call(self.lib.dsir_set_prune_min_points(self.h, int(min_points)))
+
     def match_timer_device(self, reset=True):
         """(total ms, launches) of the timed nn_match launches on the device clock (first wave start .. last wave end)."""
         ms, n = C.c_double(), C.c_int64()

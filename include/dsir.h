@@ -320,6 +320,14 @@ int dsir_enable_match_timer(dsir_ctx* ctx, int enable);
  * [4] searches that took the exhaustive kernel directly (small problems, forced runs excluded).  Synchronises.
  * Not counted while a hipGraph replays (dsir_enable_graph): [4] is a host-side counter. */
 int dsir_screen_stats(dsir_ctx* ctx, int reset, int64_t* out);
+/* The pruned search of long ref ranges (csrc/nn_prune.hip; clouds of 8192 points and more, from the second registration
+ * iteration on): out (HOST, 2 x i64) = (row block, column tile) products the screening visited, and the number it would have
+ * visited without pruning, since the last reset.  Synchronises. */
+int dsir_prune_stats(dsir_ctx* ctx, int reset, int64_t* out);
+/* A/B switch (measurement / test): the pruned search runs for ref clouds of min_points points and more (default 8192, initialised
+ * from DSIR_PRUNE_MIN_K; 0 = never).  Pruned and unpruned searches return the same bits: only products that cannot hold a row's
+ * arg-min - nor tie with it - are skipped. */
+int dsir_set_prune_min_points(dsir_ctx* ctx, int min_points);
 
 /* Diagnostics of the fp16 screening (csrc/nn_screen.hip) on ONE pair, all pointers DEVICE memory: for every (row, column)
  * the screening's lower bound L, its upper bound U = L + 2 d and the exact fp32 distance D of dsir_nn_match

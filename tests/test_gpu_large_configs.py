@@ -11,7 +11,8 @@
     differing rows are exactly those ties: their excess stays below 0.3 x the tolerance).  The reference does this
     search in fp32 in 11 row chunks at 65536 points (model.py:558-569, matchnet.py:96-113);
   * screened vs exhaustive: the same registration with DSIR_NO_SCREEN=1 in a second process returns the same bits
-    (16384 and 65536 points: ref ranges long enough for the 2 - 4-way column split of screen_kernel's launch).
+    (16384 and 65536 points: ref ranges long enough for the 2 - 4-way column split of screen_kernel's launch, and for the
+    pruned search of csrc/nn_prune.hip, which skips (row block, column tile) products from the second iteration on).
 """
 import os
 import subprocess
@@ -124,6 +125,56 @@ def test_large_register_screened_equals_exhaustive(tmp_path, pairs, n, feat_len,
         outs.append(np.load(out))
     a, b = outs
     assert int(a["screened_searches"]) == 5 and int(b["screened_searches"]) == 0
+    # the pruned search (csrc/nn_prune.hip) is what ran in iterations 1 - 4, and it did skip (row block, column tile) products
+    kept, total = int(a["tiles_visited"]), int(a["tiles_unpruned"])
+    print(f"[prune] {n} points: {kept} of {total} tile products visited in iterations 1 - 4 ({100.0 * kept / max(total, 1):.1f} %)")
+    assert total > 0 and kept < total
     print(f"[screen] {n} points: {int(a['rows_undecided'])} of {5 * pairs * n} rows undecided, {int(a['pairs_exhaustive'])} pair searches exhaustive")
     for k in ("idx", "logits", "transforms"):
         assert np.array_equal(a[k], b[k]), f"{k} differs between the screened and the exhaustive arg-min at {n} points"
+
+
+@pytest.mark.parametrize("pairs,J,K,partial", [(4, 7000, 7300, 0), (2, 10100, 9999, 1)])
+def test_pruned_search_on_ragged_sizes_gives_the_unpruned_bits(pairs, J, K, partial):
+    """The pruned search forced onto sizes that are multiples of nothing (J % 512, K % 64 != 0: a partial last row block, a
+    partial last column tile, odd tile lists), src and ref clouds of different sizes, ref points with exact duplicates
+    (tiles of radius 0 and tied distances): idx / logits / transforms of the pruned, the unpruned screened and the exhaustive
+    search agree bit for bit, and the pruned search did skip products."""
+    from deepsir_amd.arch import NetConfig
+    from deepsir_amd.engine import Engine
+    from deepsir_amd.synth import make_batch
+    from deepsir_amd.weights import generate_state_dict
+    cfg = NetConfig(feat_len=3)
+    n = max(J, K)
+    eng = Engine(cfg, 0, max_points=n, max_pairs=pairs)
+    eng.load_state_dict(generate_state_dict(cfg, 2))
+    raw = make_batch(n, [9100 + p for p in range(pairs)], 3, "3dmatch", bool(partial))
+    src = cu(np.ascontiguousarray(raw["points_src"][:, :J]))
+    ref_np = np.ascontiguousarray(raw["points_ref"][:, :K]).copy()
+    ref_np[:, 100:164] = ref_np[:, 99:100]          # 64 copies of one point: identical descriptors wherever their neighbourhoods agree
+    ref_np[:, K - 3:] = ref_np[:, 5:6]              # duplicates in the partial last tile
+    ref = cu(ref_np)
+    outs = {}
+    for name in ("pruned", "unpruned", "exhaustive"):
+        eng.set_prune_min_points(64 if name == "pruned" else 0)
+        eng.enable_screen(name != "exhaustive")
+        eng.screen_stats(reset=True)
+        eng.prune_stats(reset=True)
+        o = eng.register(src, ref, 4)
+        st = eng.screen_stats()
+        kept, total = eng.prune_stats()
+        if name == "exhaustive":
+            assert st["screened_searches"] == 0
+        else:
+            assert st["screened_searches"] == 4, st
+        if name == "pruned":
+            print(f"[prune] J {J} K {K} pairs {pairs}: {kept} of {total} tile products visited in iterations 1 - 3")
+            nrb, nt = -(-J // 512), -(-K // 64)
+            assert total == 3 * pairs * nrb * nt and 0 < kept < total
+        else:
+            assert total == 0
+        outs[name] = {k: o[k].cpu().numpy() for k in ("idx", "logits", "transforms")}
+    eng.close()
+    for k in ("idx", "logits", "transforms"):
+        assert np.array_equal(outs["pruned"][k], outs["unpruned"][k]), f"{k}: pruned != unpruned"
+        assert np.array_equal(outs["pruned"][k], outs["exhaustive"][k]), f"{k}: pruned != exhaustive"

@@ -48,7 +48,9 @@ b = make_batch(N, list(range(10_000, 10_000 + P)), feat_len, shape, partial)
 src, ref = torch.from_numpy(b["points_src"]).cuda(), torch.from_numpy(b["points_ref"]).cuda()
 o = eng.register(src, ref, 5, want_desc=True)
 print(f"points {N} pairs {P} shape {shape} partial {partial}: blocks of {RB} rows x tiles of {CT} columns")
-for order in ("as given", "morton"):
+# "need+morton": rows grouped by how many tiles they need themselves (8 classes), then by match position: rows that need
+# everything (poor previous match, no counterpart) no longer drag the blocks of well-matched rows up to the full list
+for order in ("as given", "morton", "need+morton", "T1+morton", "T2+morton"):
     for it in range(1, 5):
         kept = total = 0
         radii = []
@@ -56,12 +58,25 @@ for order in ("as given", "morton"):
             r = o["desc_ref"][p]
             a = o["desc_src"][it, p]
             prev = o["idx"][it - 1, p].long()
-            if order == "morton":
+            if order != "as given":
                 perm = torch.argsort(morton(ref[p, :, :3]))
                 inv = torch.empty_like(perm); inv[perm] = torch.arange(N, device=perm.device)
                 r = r[perm]
                 prev_pos = inv[prev]                      # position of the previous match in the sorted ref order
-                rows = torch.argsort(prev_pos)            # src rows ordered by where their previous match sits
+                key = prev_pos
+                if order == "need+morton":
+                    nt_ = (N + CT - 1) // CT
+                    rp_ = torch.cat([r, r[-1:].expand(nt_ * CT - N, -1)], 0).view(nt_, CT, 64)
+                    c_ = rp_.mean(1)
+                    rad_ = (rp_ - c_[:, None, :]).norm(dim=2).max(1)[0]
+                    T_ = ((a - r[prev_pos]) ** 2).sum(1) + 1e-5
+                    own = (((torch.cdist(a, c_) - rad_[None, :]).clamp(min=0) ** 2) <= T_[:, None]).float().mean(1)
+                    key = (own * 7.999).long() * (1 << 20) + prev_pos
+                if order in ("T1+morton", "T2+morton"):   # classes of the upper bound itself: 1 / 2 per octave (free: no extra bound pass)
+                    T_ = ((a - r[prev_pos]) ** 2).sum(1) + 1e-5
+                    cls = T_.view(torch.int32).long() >> (23 if order == "T1+morton" else 22)
+                    key = cls * (1 << 20) + prev_pos
+                rows = torch.argsort(key)                 # src rows ordered by where their previous match sits
                 a, prev_pos = a[rows], prev_pos[rows]
             else:
                 prev_pos = prev
@@ -81,6 +96,6 @@ for order in ("as given", "morton"):
             blk = needp.any(1)                            # [nb, nt]: some row of the block needs the tile
             kept += int(blk.sum()); total += nb * nt
         rr = np.concatenate(radii)
-        print(f"  order {order:9s} iter {it}: products kept {kept}/{total} = {kept / total:.3f}; rows' own need {float(need.float().mean()):.3f}; "
+        print(f"  order {order:11s} iter {it}: products kept {kept}/{total} = {kept / total:.3f}; rows' own need {float(need.float().mean()):.3f}; "
               f"tile radius median {np.median(rr):.3f} max {rr.max():.3f}")
 eng.close()

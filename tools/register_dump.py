@@ -22,6 +22,8 @@ eng.load_state_dict(to_torch_state_dict(generate_state_dict(cfg, 3)))
 b = make_batch(N, list(range(500, 500 + P)), feat_len, shape, partial)
 o = eng.register(torch.from_numpy(b["points_src"]).cuda(), torch.from_numpy(b["points_ref"]).cuda(), iters)
 st = eng.screen_stats()
-np.savez(out, screened_searches=np.int64(st["screened_searches"]), rows_undecided=np.int64(st["rows_undecided"]),
+kept, total = eng.prune_stats()
+np.savez(out, tiles_visited=np.int64(kept), tiles_unpruned=np.int64(total),
+         screened_searches=np.int64(st["screened_searches"]), rows_undecided=np.int64(st["rows_undecided"]),
          pairs_exhaustive=np.int64(st["pairs_exhaustive"]), **{k: o[k].cpu().numpy() for k in ("transforms", "idx", "logits")})
 eng.close()
