@@ -382,12 +382,14 @@ def main():
         def one_engine_pass():
             e0.enable_match_timer(True)
             e0.match_timer2(reset=True)
+            e0.prune_stats(reset=True)
             for _ in range(3):
                 e0.register(s0, r0, n_iter, want_aux=False, sync=False, out={"transforms": o0["transforms"]})
             e0.sync()
             op, k, n = e0.match_timer2(reset=True)
+            kept, unpruned = e0.prune_stats(reset=True)      # (row block, column tile) products of the pruned launches (csrc/nn_prune.hip)
             e0.enable_match_timer(False)
-            return (op / n, k / n, int(n)) if n else None
+            return (op / n, k / n, int(n), kept, unpruned) if n else None
 
         single = one_engine_pass()
         if screened and not a.no_companion:
@@ -558,16 +560,28 @@ def main():
         # ---- roofline of the dominant kernel
         roof = {"bound": "mfma", "unit": "TFLOP/s"}
         if single is not None:
-            op_ms, k_ms, nl = single
+            op_ms, k_ms, nl, kept, unpruned = single
             if screened:
                 ex = screen_flops(P_launch, N, N)
+                pruned = None
+                if unpruned > 0:
+                    # long ref ranges: the launches of iterations >= 1 visit only the listed (row block, column tile) products -
+                    # EXECUTED flops per launch = the dense figure x the share of the products the timed launches visited
+                    n_pruned = nl * (n_iter - 1) // n_iter
+                    share = ((nl - n_pruned) + n_pruned * kept / unpruned) / nl
+                    pruned = {"launches_pruned": n_pruned, "of_launches": nl, "tile_products_visited": kept, "tile_products_unpruned": unpruned,
+                              "executed_share_of_dense_flops": round(share, 4), "dense_flops_per_launch": ex,
+                              "note": "pruned search (csrc/nn_prune.hip): products that cannot hold a row's arg-min are skipped from the second "
+                                      "iteration on; same bits as the unpruned search (tests/test_gpu_large_configs.py)"}
+                    ex = ex * share
                 roof.update({
                     "kernel": "screen_kernel<4,8> (csrc/nn_screen.hip): fp16-split MFMA screening of the 64-channel descriptor arg-min "
                               "under a rigorous bound; the exact fp32 decision among the survivors follows in exact_pick_kernel / nn_match_kernel",
                     "dtype": "f16 in, f32 accumulate (v_mfma_f32_16x16x32_f16)",
                     "achieved": round(ex / (k_ms / 1e3) / 1e12, 3), "peak": PEAK_F16_MFMA_TFLOPS,
                     "frac": round(ex / (k_ms / 1e3) / 1e12 / PEAK_F16_MFMA_TFLOPS, 4),
-                    "flops_per_launch": ex, "flops_note": "EXECUTED MFMA flops: (ah.bh + ah.bl + al.bh) x 2 x 64 per (row, column) = 384 J K per pair",
+                    "flops_per_launch": ex, "flops_note": "EXECUTED MFMA flops: (ah.bh + ah.bl + al.bh) x 2 x 64 per (row, column) = 384 J K per pair"
+                                                          + (" x the share of the products the launches visit (`pruned`)" if pruned else ""),
                     "frac_algorithmic": round(match_flops(P_launch, N, N) / (k_ms / 1e3) / 1e12 / PEAK_F16_MFMA_TFLOPS, 4),
                     "frac_algorithmic_note": "SURVEY 8d's rule: ALGORITHMIC flops of the operation this kernel serves (the reference formulation's "
                                              "131 J K per pair) / the kernel's duration / the same fp16 peak: two thirds of the MFMA work the kernel "
@@ -584,6 +598,8 @@ def main():
                     "achieved": round(ex / (k_ms / 1e3) / 1e12, 3), "peak": PEAK_F32_MFMA_TFLOPS,
                     "frac": round(ex / (k_ms / 1e3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                     "flops_per_launch": ex, "flops_note": "algorithmic = executed: 131 J K per pair (SURVEY 8d)"})
+            if screened and pruned:
+                roof["pruned"] = pruned
             traffic = None
             pmc = os.path.join(ROOT, "profiles", "nn_match_pmc.json")
             if os.path.exists(pmc):
@@ -610,7 +626,7 @@ def main():
                         "stream around that kernel alone, ONE engine registering its share of the batch; rocprofv3 --kernel-trace of "
                         "this command agrees, profiles/), against the dense MFMA peak of the dtype it issues"})
             if single_ex is not None:
-                op2, k2, n2 = single_ex
+                op2, k2, n2 = single_ex[:3]
                 roof["exhaustive_kernel"] = {
                     "kernel": "nn_match_kernel<2> (csrc/nn_match.hip), dsir_enable_screen(0)", "dtype": "f32", "avg_launch_ms": round(k2, 5),
                     "achieved": round(alg / (k2 / 1e3) / 1e12, 3), "peak": PEAK_F32_MFMA_TFLOPS,

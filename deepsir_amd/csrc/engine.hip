@@ -110,6 +110,7 @@ struct dsir_ctx {
   // arg-min path of dsir_register: 1 = screened (nn_screen.hip) for large problems, 0 = always the exhaustive kernel
   int screen_mode = 1;
   int prune_min_points = 8192;          // pruned search (nn_prune.hip) for ref clouds of that many points and more; 0 = off
+  long long prune_min_rows = 65536;     // ... in launches of that many src rows (pairs x points) and more
   // aggregation chain: 1 = fp16-split products on the fp16 matrix pipe (agg_chain_h.hip), 0 = exact-fp32 chain (agg_chain.hip)
   int agg_split = 1;
   // device-clock brackets {first wave start, last wave end} of the timed nn_match launches
@@ -1176,7 +1177,10 @@ static int register_enqueue(dsir_ctx* c, const dsir_pair_batch* in, int n_iter, 
     sc_scratch = ws.raw(nn_screen_scratch_bytes(P, J));
   }
   // pruned search (nn_prune.hip) for long ref ranges: column order + tile bounds once, row order + tile lists per iteration
-  const bool prune = screen && c->prune_min_points > 0 && K >= c->prune_min_points && n_iter > 1 && nn_prune_supported(P, J, K);
+  // ... and only with enough rows in the launch to fill the chip with items (128 row blocks): below that the search lasts as long as
+  // its longest item either way and the preparation is pure cost (one 16384-point pair: 5.18 -> 5.59 ms per registration with it)
+  const bool prune = screen && c->prune_min_points > 0 && K >= c->prune_min_points && n_iter > 1 && (int64_t)P * J >= c->prune_min_rows &&
+                     nn_prune_supported(P, J, K);
   void* pr_scratch = prune ? ws.raw(nn_prune_scratch_bytes(P, J, K)) : nullptr;
   // persistent storage of the inlier model's position-encoding branch (EncCache), alive across the iterations
   EncCache enc_cache;
@@ -1604,9 +1608,10 @@ int dsir_enable_agg_split(dsir_ctx* c, int enable) {
   return 0;
 }
 
-int dsir_set_prune_min_points(dsir_ctx* c, int min_points) {
+int dsir_set_prune_thresholds(dsir_ctx* c, int min_points, int64_t min_rows) {
   if (!c) return 1;
   c->prune_min_points = min_points > 0 ? min_points : 0;
+  c->prune_min_rows = min_rows > 0 ? min_rows : 0;
   // a captured registration has the choice baked in
   if (c->graph_exec) { hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
   c->graph_key.clear();

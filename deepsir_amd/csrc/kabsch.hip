@@ -22,6 +22,9 @@ namespace dsir {
 
 namespace {
 
+// the passes' loops are unrolled x4: a thread's iterations are independent up to the fp64 adds (kept in order: same bits), and
+// on large clouds - 64 points per thread and pass at 65536 - the index -> ref gather chains of consecutive iterations overlap
+#define DSIR_KABSCH_UNROLL _Pragma("unroll 4")
 constexpr int NTHR = 1024;
 constexpr int NWAVE = NTHR / 64;
 
@@ -80,12 +83,14 @@ __global__ __launch_bounds__(NTHR) void kabsch_kernel(const KabschArgs a) {
 
   // pass 1: S = sum |w|
   double v1[1] = {0.0};
+  DSIR_KABSCH_UNROLL
   for (int i = threadIdx.x; i < m; i += NTHR) v1[0] += (double)fabsf(weight(i));
   block_sum<1>(v1, sh);
   const float den = (float)v1[0] + 1e-16f;   // model.py:35 (fp32 sum + _EPS)
 
   // pass 2: weighted centroids
   double v6[6] = {0, 0, 0, 0, 0, 0};
+  DSIR_KABSCH_UNROLL
   for (int i = threadIdx.x; i < m; i += NTHR) {
     const float wn = weight(i) / den;
     float tx, ty, tz;
@@ -103,6 +108,7 @@ __global__ __launch_bounds__(NTHR) void kabsch_kernel(const KabschArgs a) {
 
   // pass 3: covariance H[a][b] = sum (s_a - cs_a) * ((t_b - ct_b) * wn)
   double v9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  DSIR_KABSCH_UNROLL
   for (int i = threadIdx.x; i < m; i += NTHR) {
     const float wn = weight(i) / den;
     float t[3];

@@ -527,7 +527,7 @@ __global__ __launch_bounds__(256) void exact_pick_kernel(const float* __restrict
   const float T = unorder_bits(umin[row]);
   const int2* ce = cand + row * CAP;
   int kept = 0, first = 0;
-  bool cls = n <= 0;
+  bool cls = false;
   for (int e = 0; e < n; ++e) {
     const int2 c = ce[e];
     if (__int_as_float(c.y) <= T) {
@@ -535,11 +535,11 @@ __global__ __launch_bounds__(256) void exact_pick_kernel(const float* __restrict
       else if (kept++ == 0) first = c.x;
     }
   }
-  if (cls) {
+  if (kept == 0) {                                   // no column entry at all (non-finite input): the exhaustive kernel
     rowlist[(int64_t)pair * J + atomicAdd(ovf + pair, 1)] = j;
     return;
   }
-  if (kept == 1) {
+  if (kept == 1 && !cls) {
     idx[row] = first;
     return;
   }
@@ -552,10 +552,25 @@ __global__ __launch_bounds__(256) void exact_pick_kernel(const float* __restrict
   unsigned long long best = ~0ull;
   for (int e = 0; e < n; ++e) {
     const int2 c = ce[e];
-    if (__int_as_float(c.y) <= T) {
+    if (c.x >= 0 && __int_as_float(c.y) <= T) {
       const unsigned long long key =
           ((unsigned long long)order_bits(exact_dist(a, Bp + (int64_t)c.x * 64, san, sbp[c.x])) << 32) | (unsigned int)c.x;
       best = key < best ? key : best;
+    }
+  }
+  if (cls) {
+    // a class entry stands for columns whose lower bounds are >= its own: it matters only if that bound does not exceed the
+    // best EXACT distance found among the column entries (an actual distance of the row, so D >= L > it rules the class out,
+    // ties included) - a tighter test than the screening threshold T, which sits a bound width above the minimum
+    const float dbest = unorder_bits((unsigned int)(best >> 32));
+    bool open = !(dbest == dbest);
+    for (int e = 0; e < n && !open; ++e) {
+      const int2 c = ce[e];
+      open = c.x < 0 && __int_as_float(c.y) <= T && !(__int_as_float(c.y) > dbest);
+    }
+    if (open) {
+      rowlist[(int64_t)pair * J + atomicAdd(ovf + pair, 1)] = j;
+      return;
     }
   }
   idx[row] = (int32_t)(best & 0xffffffffull);

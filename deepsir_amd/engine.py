@@ -521,10 +521,10 @@ class Engine:
         self._call(self.lib.dsir_prune_stats(self.h, 1 if reset else 0, out))
         return int(out[0]), int(out[1])
 
-    def set_prune_min_points(self, min_points: int):
-        """A/B switch: the pruned search runs for ref clouds of that many points and more (0 = never; same bits either way;
-        include/dsir.h, dsir_set_prune_min_points)."""
-        self._call(self.lib.dsir_set_prune_min_points(self.h, int(min_points)))
+    def set_prune_thresholds(self, min_points: int = 8192, min_rows: int = 65536):
+        """A/B switch: the pruned search runs for ref clouds of min_points points and more (0 = never) in launches of min_rows src
+        rows and more; same bits either way (include/dsir.h, dsir_set_prune_thresholds)."""
+        self._call(self.lib.dsir_set_prune_thresholds(self.h, int(min_points), int(min_rows)))
 
     def match_timer_device(self, reset=True):
         """(total ms, launches) of the timed nn_match launches on the device clock (first wave start .. last wave end)."""

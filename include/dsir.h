@@ -325,9 +325,10 @@ int dsir_screen_stats(dsir_ctx* ctx, int reset, int64_t* out);
  * visited without pruning, since the last reset.  Synchronises. */
 int dsir_prune_stats(dsir_ctx* ctx, int reset, int64_t* out);
 /* A/B switch (measurement / test): the pruned search runs for ref clouds of min_points points and more (default 8192, initialised
- * from DSIR_PRUNE_MIN_K; 0 = never).  Pruned and unpruned searches return the same bits: only products that cannot hold a row's
- * arg-min - nor tie with it - are skipped. */
-int dsir_set_prune_min_points(dsir_ctx* ctx, int min_points);
+ * from DSIR_PRUNE_MIN_K; 0 = never) in launches of min_rows src rows (pairs x points) and more (default 65536: below that the
+ * launch does not fill the chip with work items and the preparation is pure cost).  Pruned and unpruned searches return the
+ * same bits: only products that cannot hold a row's arg-min - nor tie with it - are skipped. */
+int dsir_set_prune_thresholds(dsir_ctx* ctx, int min_points, int64_t min_rows);
 
 /* Diagnostics of the fp16 screening (csrc/nn_screen.hip) on ONE pair, all pointers DEVICE memory: for every (row, column)
  * the screening's lower bound L, its upper bound U = L + 2 d and the exact fp32 distance D of dsir_nn_match

@@ -156,7 +156,7 @@ def test_pruned_search_on_ragged_sizes_gives_the_unpruned_bits(pairs, J, K, part
     ref = cu(ref_np)
     outs = {}
     for name in ("pruned", "unpruned", "exhaustive"):
-        eng.set_prune_min_points(64 if name == "pruned" else 0)
+        eng.set_prune_thresholds(64 if name == "pruned" else 0, 1)
         eng.enable_screen(name != "exhaustive")
         eng.screen_stats(reset=True)
         eng.prune_stats(reset=True)

@@ -19,6 +19,7 @@ partial = bool(int(sys.argv[7])) if len(sys.argv) > 7 else False
 cfg = NetConfig(feat_len=feat_len)
 eng = Engine(cfg, 0, max_points=max(N, 1024), max_pairs=P)
 eng.load_state_dict(to_torch_state_dict(generate_state_dict(cfg, 3)))
+eng.set_prune_thresholds(8192, 1)     # the pruned search for every launch on clouds of 8192 points and more, however few rows it has
 b = make_batch(N, list(range(500, 500 + P)), feat_len, shape, partial)
 o = eng.register(torch.from_numpy(b["points_src"]).cuda(), torch.from_numpy(b["points_ref"]).cuda(), iters)
 st = eng.screen_stats()
