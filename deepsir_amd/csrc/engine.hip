@@ -1182,6 +1182,8 @@ static int register_enqueue(dsir_ctx* c, const dsir_pair_batch* in, int n_iter, 
   const bool prune = screen && c->prune_min_points > 0 && K >= c->prune_min_points && n_iter > 1 && (int64_t)P * J >= c->prune_min_rows &&
                      nn_prune_supported(P, J, K);
   void* pr_scratch = prune ? ws.raw(nn_prune_scratch_bytes(P, J, K)) : nullptr;
+  // chunk partials of the pose solve on large clouds (kabsch.hip)
+  double* kab_part = kabsch_part_bytes(P, J) ? ws.get<double>(kabsch_part_bytes(P, J) / sizeof(double)) : nullptr;
   // persistent storage of the inlier model's position-encoding branch (EncCache), alive across the iterations
   EncCache enc_cache;
   static const bool no_hoist = getenv("DSIR_NO_HOIST") != nullptr;   // A/B switch
@@ -1279,6 +1281,7 @@ static int register_enqueue(dsir_ctx* c, const dsir_pair_batch* in, int n_iter, 
     a.T_cum = out->transforms + (size_t)it * 12; a.T_prev = it ? out->transforms + (size_t)(it - 1) * 12 : nullptr;
     a.T_stride = (int64_t)n_iter * 12;
     a.matched_out = (it == n_iter - 1) ? out->pt_ref_new : nullptr;
+    a.part = kab_part;
     launch_kabsch(a, st);
   }
   if (c->ws.overflow) return fail(c, "workspace exhausted (raise max_points / max_pairs in dsir_cfg)");

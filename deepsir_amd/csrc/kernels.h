@@ -279,7 +279,11 @@ struct KabschArgs {
   float* matched_out;    // [pairs][m][3] gathered ref points (or nullptr)
   int ref_ld;            // floats between ref points (0 => 3)
   const int32_t* skip;   // [pairs] or nullptr: non-zero => this pair's update is the identity, src_out untouched (ICP)
+  double* part;          // kabsch_part_bytes(pairs, m) of scratch, or nullptr: clouds of kKabschChunkedMin points and more are then
+                         // reduced in chunks by several workgroups per pair (same formulas; the fp64 sums in another order)
 };
+constexpr int kKabschChunkedMin = 16384;
+size_t kabsch_part_bytes(int pairs, int m);   // 0 below kKabschChunkedMin
 void launch_kabsch(const KabschArgs& a, hipStream_t st);
 
 // icp.hip — point-to-point ICP refinement (test.py:241-258 / open3d registration_icp), all pairs at once
