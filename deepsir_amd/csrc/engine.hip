@@ -635,9 +635,16 @@ int build_pyramid(dsir_ctx* c, const float* points, int stride, int clouds, int 
   for (int l = 0; l <= g.num_layers; ++l) { lv.nl[l] = p.nl[l]; lv.off[l] = p.off[l]; lv.soff[l] = p.soff[l]; }
   // every level's points are a prefix of the level above, hence of the input cloud (data_base.py:166-172): one launch for all
   launch_copy_xyz_levels(points, (int64_t)n * stride, stride, lv, clouds, xyz, xyz_cs, st);
+  static const bool no_grid = getenv("DSIR_NO_GRID") != nullptr;   // A/B switch
+  static const int grid_min = getenv("DSIR_GRID_MIN") ? atoi(getenv("DSIR_GRID_MIN")) : 1024;   // tuning hook
+  static const bool no_nn1_grid = getenv("DSIR_NO_NN1_GRID") != nullptr;   // A/B switch: brute-force interpolation search throughout
+  static const long long nn1_grid_min = getenv("DSIR_NN1_GRID_MIN") ? atoll(getenv("DSIR_NN1_GRID_MIN")) : 65536;   // tuning hook
+  // interpolation search of level l (support = level l + 1) through level l + 1's grid: when that level has one and the launch has
+  // queries enough to fill the chip with one lane per query (same bits either way)
+  auto nn1_by_grid = [&](int l) {
+    return !no_grid && !no_nn1_grid && l + 1 < g.num_layers && p.nl[l + 1] >= grid_min && (int64_t)clouds * p.nl[l] >= nn1_grid_min;
+  };
   for (int l = 0; l < g.num_layers; ++l) {
-    static const bool no_grid = getenv("DSIR_NO_GRID") != nullptr;   // A/B switch
-    static const int grid_min = getenv("DSIR_GRID_MIN") ? atoi(getenv("DSIR_GRID_MIN")) : 1024;   // tuning hook
     if (p.nl[l] >= grid_min && !no_grid) {
       // large levels: exact grid-pruned search (knn_grid.hip); same bits as the brute force
       const size_t mark = c->ws.mark();
@@ -645,11 +652,14 @@ int build_pyramid(dsir_ctx* c, const float* points, int stride, int clouds, int 
       if (c->ws.overflow) return fail(c, "workspace exhausted in the KNN pyramid");
       launch_knn16_grid(points, (int64_t)n * stride, stride, p.nl[l], clouds, neigh + (int64_t)p.off[l] * kKnn, neigh_cs,
                         scratch, st);
-      c->ws.release(mark);   // stream-ordered: later users of this memory run after the query kernel
+      // this level's points are the support of the level above's interpolation search: it walks the grid just built
+      if (l > 0 && nn1_by_grid(l - 1))
+        launch_nn1_grid(points, (int64_t)n * stride, stride, p.nl[l - 1], p.nl[l], clouds, interp + p.off[l - 1], p.S, scratch, st);
+      c->ws.release(mark);   // stream-ordered: later users of this memory run after the query kernels
     } else {
       launch_knn16(points, (int64_t)n * stride, stride, p.nl[l], clouds, neigh + (int64_t)p.off[l] * kKnn, neigh_cs, st);
     }
-    launch_nn1(points, (int64_t)n * stride, stride, p.nl[l], p.nl[l + 1], clouds, interp + p.off[l], p.S, st);
+    if (!nn1_by_grid(l)) launch_nn1(points, (int64_t)n * stride, stride, p.nl[l], p.nl[l + 1], clouds, interp + p.off[l], p.S, st);
   }
   // sub_idx of level l = the neighbour lists of its first n_{l+1} points: all levels in one launch
   launch_copy_sub_levels(neigh, neigh_cs, lv, clouds, sub, sub_cs, st);

@@ -172,6 +172,9 @@ void launch_knn16_grid(const float* pts, int64_t cloud_stride, int stride, int n
                        int64_t out_cloud_stride, void* scratch, hipStream_t st);
 void launch_nn1(const float* pts, int64_t cloud_stride, int stride, int n_query, int n_support, int clouds,
                 int32_t* out, int64_t out_cloud_stride, hipStream_t st);
+// the same search through the grid launch_knn16_grid has just built over the first n_support points (its scratch); same bits
+void launch_nn1_grid(const float* pts, int64_t cloud_stride, int stride, int n_query, int n_support, int clouds, int32_t* out,
+                     int64_t out_cloud_stride, const void* grid_scratch, hipStream_t st);
 void launch_copy_xyz(const float* pts, int64_t cloud_stride, int stride, int n, int clouds, float* out,
                      int64_t out_cloud_stride, hipStream_t st);
 // all levels of a pyramid in one launch each (every level is a prefix of the level above, data_base.py:166-172):

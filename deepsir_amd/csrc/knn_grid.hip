@@ -397,6 +397,72 @@ __global__ __launch_bounds__(KB4) void grid_knn4_kernel(const float4* __restrict
 
 }  // namespace
 
+// Nearest SUPPORT point (support = the first n_support points of the cloud = the next pyramid level) of every query point,
+// through the grid that level's own 16-NN search has just built: the same shell walk and termination as grid_knn_kernel with a
+// top-1 instead of a top-16 - bit for bit the brute force of knn.hip::nn1_kernel (smallest (distance, index); a query
+// without any finite distance gets 0).  One lane per query, queries in their natural order.  Brute force costs
+// n_query x n_support distances per cloud (65536 x 16384 at the top level of a 64 k-point cloud: 296 us per launch of two
+// clouds), the walk ~27 cells x 8 points per query.
+__global__ __launch_bounds__(256) void grid_nn1_kernel(const float* __restrict__ pts, int64_t cs, int stride, int n_query,
+                                                       const float4* __restrict__ sorted, const int* __restrict__ starts,
+                                                       const GridParams* __restrict__ gp, int max_cells, int n_support,
+                                                       int32_t* __restrict__ out, int64_t ocs) {
+  const int cloud = blockIdx.y;
+  const int qi = blockIdx.x * 256 + threadIdx.x;
+  if (qi >= n_query) return;
+  const float* P = pts + cloud * cs;
+  const float qx = P[(int64_t)qi * stride], qy = P[(int64_t)qi * stride + 1], qz = P[(int64_t)qi * stride + 2];
+  const GridParams g = gp[cloud];
+  const float4* S = sorted + (int64_t)cloud * n_support;
+  const int* ST = starts + (int64_t)cloud * (max_cells + 1);
+  const int cx = cell_coord(qx, g.ox, g.inv_h, g.gx);
+  const int cy = cell_coord(qy, g.oy, g.inv_h, g.gy);
+  const int cz = cell_coord(qz, g.oz, g.inv_h, g.gz);
+  unsigned long long best = ~0ull;
+  auto scan = [&](int b, int e) {
+    for (int k = b; k < e; k += 4) {
+      float4 sv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) sv[u] = S[min(k + u, e - 1)];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float d = sqdist3(qx, qy, qz, sv[u].x, sv[u].y, sv[u].z);
+        const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(sv[u].w);
+        if (k + u < e && d < INFINITY && key < best) best = key;      // NaN and inf distances never win (nn1_kernel: d < bd)
+      }
+    }
+  };
+  const int rmax = max(max(max(cx, g.gx - 1 - cx), max(cy, g.gy - 1 - cy)), max(cz, g.gz - 1 - cz));
+  for (int r = 0; r <= rmax; ++r) {
+    const int z0 = max(cz - r, 0), z1 = min(cz + r, g.gz - 1);
+    const int y0 = max(cy - r, 0), y1 = min(cy + r, g.gy - 1);
+    const int x0 = max(cx - r, 0), x1 = min(cx + r, g.gx - 1);
+    for (int z = z0; z <= z1; ++z)
+      for (int y = y0; y <= y1; ++y) {
+        // a row of the shell: the whole x-run when it lies on a face, else its two end cells
+        const bool face = (z == cz - r) || (z == cz + r) || (y == cy - r) || (y == cy + r);
+        const int rowbase = (z * g.gy + y) * g.gx;
+        if (face) scan(ST[rowbase + x0], ST[rowbase + x1 + 1]);
+        else {
+          if (cx - r >= 0) scan(ST[rowbase + cx - r], ST[rowbase + cx - r + 1]);
+          if (cx + r <= g.gx - 1) scan(ST[rowbase + cx + r], ST[rowbase + cx + r + 1]);
+        }
+      }
+    // distance from the query to the nearest face of the visited cube that still has cells behind it (grid_knn_kernel)
+    float bound = INFINITY;
+    if (cx - r > 0) bound = fminf(bound, qx - (g.ox + (float)(cx - r) * g.h));
+    if (cx + r < g.gx - 1) bound = fminf(bound, (g.ox + (float)(cx + r + 1) * g.h) - qx);
+    if (cy - r > 0) bound = fminf(bound, qy - (g.oy + (float)(cy - r) * g.h));
+    if (cy + r < g.gy - 1) bound = fminf(bound, (g.oy + (float)(cy + r + 1) * g.h) - qy);
+    if (cz - r > 0) bound = fminf(bound, qz - (g.oz + (float)(cz - r) * g.h));
+    if (cz + r < g.gz - 1) bound = fminf(bound, (g.oz + (float)(cz + r + 1) * g.h) - qz);
+    if (bound == INFINITY) break;                   // the cube covers the whole grid
+    bound -= 1e-4f * g.h;                           // points binned by rounded coordinates can sit a few ulps outside their cell
+    if (bound > 0.f && best != ~0ull && __uint_as_float((unsigned)(best >> 32)) < bound * bound * 0.9999f) break;
+  }
+  out[cloud * ocs + qi] = best == ~0ull ? 0 : (int32_t)(unsigned)(best & 0xffffffffull);
+}
+
 size_t knn_grid_scratch_bytes(int clouds, int n) {
   const size_t max_cells = (size_t)n / 2 + 64;
   size_t b = 0;
@@ -431,6 +497,23 @@ void launch_knn16_grid(const float* pts, int64_t cs, int stride, int n, int clou
     hipLaunchKernelGGL(grid_knn_kernel, dim3((n + KB - 1) / KB, clouds), dim3(KB), 0, st, sorted, starts, gp, max_cells, n, out, ocs);
   else
     hipLaunchKernelGGL(grid_knn4_kernel, dim3((n + KB4 / 4 - 1) / (KB4 / 4), clouds), dim3(KB4), 0, st, sorted, starts, gp, max_cells, n, out, ocs);
+}
+
+// nn1 through the grid launch_knn16_grid(.., n = n_support, .., scratch) has left in `scratch` (same carving)
+void launch_nn1_grid(const float* pts, int64_t cs, int stride, int n_query, int n_support, int clouds, int32_t* out, int64_t ocs,
+                     const void* scratch, hipStream_t st) {
+  const int n = n_support;
+  const int max_cells = n / 2 + 64;
+  const char* p = reinterpret_cast<const char*>(scratch);
+  auto take = [&](size_t bytes) { const char* r = p; p += (bytes + 255) & ~(size_t)255; return r; };
+  const GridParams* gp = reinterpret_cast<const GridParams*>(take((size_t)clouds * sizeof(GridParams)));
+  take((size_t)clouds * n * sizeof(int));                    // cell_of
+  take((size_t)clouds * max_cells * sizeof(int));            // counts
+  const int* starts = reinterpret_cast<const int*>(take((size_t)clouds * (max_cells + 1) * sizeof(int)));
+  take((size_t)clouds * max_cells * sizeof(int));            // cursor
+  const float4* sorted = reinterpret_cast<const float4*>(take((size_t)clouds * n * sizeof(float4)));
+  hipLaunchKernelGGL(grid_nn1_kernel, dim3((n_query + 255) / 256, clouds), dim3(256), 0, st, pts, cs, stride, n_query, sorted, starts, gp,
+                     max_cells, n_support, out, ocs);
 }
 
 }  // namespace dsir

@@ -86,6 +86,39 @@ def test_knn_pyramid_bit_exact(n, seed):
         assert np.array_equal(interp[c].cpu().numpy(), ref["interp_idx"])
 
 
+def test_interp_search_through_the_grid_bit_exact():
+    """The interpolation search (nearest point of the next level) walks that level's grid when the launch holds >= 65536
+    queries (csrc/knn_grid.hip::grid_nn1_kernel): 16 clouds of 4224 points (levels 4224 / 1056 / 264 / 66: level 0 searches
+    level 1's grid) of shapes that stress the walk - uniform, planar, collinear, clusters with far outliers among the QUERY-only
+    points (queries far outside the support's bounding box), all points identical, exact duplicates of support points,
+    a lattice (exact ties: the lower index wins) - against the brute-force oracle, every level, bit for bit."""
+    from deepsir_amd.arch import NetConfig
+    from deepsir_amd.weights import generate_state_dict
+    from oracle.knn import knn_pyramid
+    cfg = NetConfig(feat_len=3)
+    eng = engine_for(cfg, generate_state_dict(cfg, 0), "w0nn1", max_points=4224, max_pairs=16)
+    rng = np.random.default_rng(11)
+    n = 4224
+    clouds = []
+    for c in range(10):
+        clouds.append(rng.uniform(0, 3, (n, 3)).astype(np.float32))
+    planar = rng.uniform(0, 3, (n, 3)).astype(np.float32); planar[:, 2] = 0.5
+    line = np.zeros((n, 3), np.float32); line[:, 0] = rng.uniform(-5, 5, n)
+    blobs = (rng.standard_normal((n, 3)) * 0.05 + rng.integers(0, 4, (n, 1)) * 2.0).astype(np.float32)
+    blobs[2000:2016] = rng.uniform(-500, 500, (16, 3))                    # outliers that are queries only (index >= 1056)
+    same = np.tile(np.array([[1.25, -2.5, 0.75]], np.float32), (n, 1))
+    dup = rng.uniform(0, 3, (n, 3)).astype(np.float32); dup[1056:2112] = dup[:1056]; dup[5] = dup[900]   # queries ON support points; a support duplicate
+    lattice = np.stack(np.meshgrid(*[np.arange(17, dtype=np.float32)] * 3, indexing="ij"), -1).reshape(-1, 3)[rng.permutation(17 ** 3)[:n]]
+    clouds += [planar, line, blobs, same, dup, lattice.astype(np.float32)]
+    pts = np.stack(clouds)
+    assert pts.shape == (16, n, 3)
+    xyz, neigh, sub, interp = eng.knn_pyramid(cu(pts))
+    for c in range(16):
+        ref = knn_pyramid(pts[c], 16, cfg.sub_sampling_ratio)
+        assert np.array_equal(interp[c].cpu().numpy(), ref["interp_idx"]), f"interp_idx of cloud {c}"
+        assert np.array_equal(neigh[c].cpu().numpy(), ref["neigh_idx"]), f"neigh_idx of cloud {c}"
+
+
 def test_knn_grid_adversarial_clouds_bit_exact():
     """The grid-pruned search (levels with >= 2048 points) must equal the brute-force oracle bit for bit
     on clouds that stress the grid: planar, collinear, clustered with far outliers, all points identical,
