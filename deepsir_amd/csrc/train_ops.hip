@@ -153,7 +153,10 @@ __global__ __launch_bounds__(256) void t_gemm_dw_reduce_kernel(const float* __re
 }
 
 // ---- GroupNorm / BatchNorm(train) -------------------------------------------------------------------------------------
-constexpr int GN_CHUNK_ROWS = 1024, GN_MAX_CHUNKS = 64;
+// row chunks of the GroupNorm reductions: 128 rows and up to 256 chunks per cloud (round 3; 1024 / 64 before: a per-point layer of
+// 8 x 5000 rows ran as 40 workgroups whose threads walked 128 rows each, 60 us - the trace showed 24 - 80 workgroups per launch
+// on most of the 148 layers of a step)
+constexpr int GN_CHUNK_ROWS = 128, GN_MAX_CHUNKS = 256;
 inline int gn_chunks(int M) { const int c = (M + GN_CHUNK_ROWS - 1) / GN_CHUNK_ROWS; return c < 1 ? 1 : (c > GN_MAX_CHUNKS ? GN_MAX_CHUNKS : c); }
 
 // stage 1: one block per (row chunk, group, cloud): sum and sum of squares over its rows x gw channels, fp64
@@ -775,7 +778,7 @@ inline DwPlan dw_plan(int64_t rows, int N, int K, bool bias) {
   DwPlan p;
   p.Kp = K + (bias ? 1 : 0);
   const int64_t tiles = (int64_t)((N + TB - 1) / TB) * ((p.Kp + TB - 1) / TB);
-  int64_t sp = (rows + 511) / 512;                       // >= 512 rows per split
+  int64_t sp = (rows + 127) / 128;                       // >= 128 rows per split (512 before: 32 barrier-separated K steps, 40 us, for 79 workgroups)
   const int64_t cap = tiles >= 2048 ? 1 : 2048 / tiles;   // ~ 2048 workgroups in all
   sp = sp > cap ? cap : sp;
   sp = sp > 1024 ? 1024 : sp;
@@ -855,7 +858,12 @@ int dsir_t_gn_bwd(void* stream, const float* dOut, const float* Y, const float* 
                      rpc, partial);
   const int64_t cnt = (int64_t)clouds * C * 2;
   hipLaunchKernelGGL(t_gn_bwd_sums_final_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, partial, nch, C, cnt, sums);
-  int rpb = (int)(((int64_t)16384 + C - 1) / C);         // ~ 16 k elements per block
+  // elements per block: 16 k on the large layers, down to 4 k where that is needed for ~1000 workgroups (a block first forms the
+  // group means from `sums`: C loads - not less than that many elements per thread-block pass)
+  const int64_t total = (int64_t)clouds * M * C;
+  int64_t per = total / 1024;
+  per = per < 4096 ? 4096 : (per > 16384 ? 16384 : per);
+  int rpb = (int)((per + C - 1) / C);
   rpb = rpb < 1 ? 1 : rpb;
   hipLaunchKernelGGL(t_gn_bwd_apply_kernel, dim3((M + rpb - 1) / rpb, clouds), dim3(256), (size_t)groups * 2 * sizeof(float), st, dOut, Y,
                      stats, sums, M, C, groups, gamma, beta, act, dY, rpb);
