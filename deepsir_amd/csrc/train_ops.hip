@@ -22,8 +22,8 @@ constexpr int TLD = TK + 2;   // LDS row (floats): fragment reads (row r, k = 4 
 __global__ __launch_bounds__(256) void t_gemm_kernel(const float* __restrict__ X, int ldx, const float* __restrict__ W, int wn, int wk,
                                                      const float* __restrict__ bias, float* __restrict__ Y, int ldy, int64_t rows,
                                                      int K, int N, float beta) {
-  __shared__ float Xs[TB * TLD];
-  __shared__ float Ws[TB * TLD];
+  __shared__ float Xs[2][TB * TLD];
+  __shared__ float Ws[2][TB * TLD];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int fr = lane & 15, fq = lane >> 4;
   const int64_t m0 = (int64_t)blockIdx.x * TB;
@@ -37,30 +37,47 @@ __global__ __launch_bounds__(256) void t_gemm_kernel(const float* __restrict__ X
   // rows of X (and of W when it is k-contiguous) are read as one 16-byte load per thread where alignment allows
   const bool xv = (ldx & 3) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0;
   const bool wv = wk == 1 && (wn & 3) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0;
-  for (int k0 = 0; k0 < K; k0 += TK) {
+  // the next K chunk is fetched into registers while the MFMAs of the current one run, then written to the other LDS buffer:
+  // one barrier per chunk and no exposed load latency (round 3; the deep layers - 40 workgroups, K = 512 - were a chain of 32
+  // fetch -> barrier -> 4 MFMAs -> barrier steps, 43 us)
+  float xq[4], wq[4];
+  auto gload = [&](int k0) {
     const int kb = k0 + sk;
     if (xv && xr < rows && kb + 3 < K) {
       const float4 v = *reinterpret_cast<const float4*>(X + xr * ldx + kb);
-      Xs[sr * TLD + sk] = v.x; Xs[sr * TLD + sk + 1] = v.y; Xs[sr * TLD + sk + 2] = v.z; Xs[sr * TLD + sk + 3] = v.w;
+      xq[0] = v.x; xq[1] = v.y; xq[2] = v.z; xq[3] = v.w;
     } else {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) Xs[sr * TLD + sk + u] = (xr < rows && kb + u < K) ? X[xr * ldx + kb + u] : 0.f;
+      for (int u = 0; u < 4; ++u) xq[u] = (xr < rows && kb + u < K) ? X[xr * ldx + kb + u] : 0.f;
     }
     if (wv && wc < N && kb + 3 < K) {
       const float4 v = *reinterpret_cast<const float4*>(W + (int64_t)wc * wn + kb);
-      Ws[sr * TLD + sk] = v.x; Ws[sr * TLD + sk + 1] = v.y; Ws[sr * TLD + sk + 2] = v.z; Ws[sr * TLD + sk + 3] = v.w;
+      wq[0] = v.x; wq[1] = v.y; wq[2] = v.z; wq[3] = v.w;
     } else {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) Ws[sr * TLD + sk + u] = (wc < N && kb + u < K) ? W[(int64_t)wc * wn + (int64_t)(kb + u) * wk] : 0.f;
+      for (int u = 0; u < 4; ++u) wq[u] = (wc < N && kb + u < K) ? W[(int64_t)wc * wn + (int64_t)(kb + u) * wk] : 0.f;
     }
-    __syncthreads();
+  };
+  auto sstore = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { Xs[buf][sr * TLD + sk + u] = xq[u]; Ws[buf][sr * TLD + sk + u] = wq[u]; }
+  };
+  gload(0);
+  sstore(0);
+  __syncthreads();
+  int buf = 0;
+  for (int k0 = 0; k0 < K; k0 += TK) {
+    const bool more = k0 + TK < K;
+    if (more) gload(k0 + TK);
 #pragma unroll
     for (int s = 0; s < TK / 4; ++s) {
-      const float a = Xs[(16 * w + fr) * TLD + 4 * s + fq];
+      const float a = Xs[buf][(16 * w + fr) * TLD + 4 * s + fq];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Ws[(16 * t + fr) * TLD + 4 * s + fq], acc[t], 0, 0, 0);
+      for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Ws[buf][(16 * t + fr) * TLD + 4 * s + fq], acc[t], 0, 0, 0);
     }
+    if (more) sstore(buf ^ 1);
     __syncthreads();
+    buf ^= 1;
   }
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
@@ -84,8 +101,8 @@ constexpr int DLD = TB + 16;   // LDS row of the transposed-use tiles: (k-row q,
 __global__ __launch_bounds__(256) void t_gemm_dw_kernel(const float* __restrict__ dY, int ldy, const float* __restrict__ X, int ldx,
                                                         int64_t rows, int64_t rows_per_split, int N, int K, int Kp,
                                                         float* __restrict__ partial) {
-  __shared__ __attribute__((aligned(16))) float As[TK * DLD];
-  __shared__ __attribute__((aligned(16))) float Bs[TK * DLD];
+  __shared__ __attribute__((aligned(16))) float As[2][TK * DLD];
+  __shared__ __attribute__((aligned(16))) float Bs[2][TK * DLD];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int fr = lane & 15, fq = lane >> 4;
   const int n0 = blockIdx.x * TB, k0 = blockIdx.y * TB;
@@ -97,32 +114,53 @@ __global__ __launch_bounds__(256) void t_gemm_dw_kernel(const float* __restrict_
   f32x4 acc[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int64_t r0 = r_begin; r0 < r_end; r0 += TK) {
+  // as in t_gemm_kernel: the next 16-row chunk travels to registers during the MFMAs of the current one; one barrier per chunk
+  float4 aq, bq;
+  auto gload = [&](int64_t r0) {
     const int64_t r = r0 + sr;
     const bool rin = r < r_end;
     if (av && rin && n0 + sc + 3 < N) {
-      *reinterpret_cast<float4*>(&As[sr * DLD + sc]) = *reinterpret_cast<const float4*>(dY + r * ldy + n0 + sc);
+      aq = *reinterpret_cast<const float4*>(dY + r * ldy + n0 + sc);
     } else {
+      float t[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) As[sr * DLD + sc + u] = (rin && n0 + sc + u < N) ? dY[r * ldy + n0 + sc + u] : 0.f;
+      for (int u = 0; u < 4; ++u) t[u] = (rin && n0 + sc + u < N) ? dY[r * ldy + n0 + sc + u] : 0.f;
+      aq = make_float4(t[0], t[1], t[2], t[3]);
     }
     if (bv && rin && k0 + sc + 3 < K) {
-      *reinterpret_cast<float4*>(&Bs[sr * DLD + sc]) = *reinterpret_cast<const float4*>(X + r * ldx + k0 + sc);
+      bq = *reinterpret_cast<const float4*>(X + r * ldx + k0 + sc);
     } else {
+      float t[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int k = k0 + sc + u;
-        Bs[sr * DLD + sc + u] = !rin ? 0.f : (k < K ? X[r * ldx + k] : (k == K && Kp > K ? 1.f : 0.f));
+        t[u] = !rin ? 0.f : (k < K ? X[r * ldx + k] : (k == K && Kp > K ? 1.f : 0.f));
       }
+      bq = make_float4(t[0], t[1], t[2], t[3]);
     }
-    __syncthreads();
+  };
+  auto sstore = [&](int buf) {
+    *reinterpret_cast<float4*>(&As[buf][sr * DLD + sc]) = aq;
+    *reinterpret_cast<float4*>(&Bs[buf][sr * DLD + sc]) = bq;
+  };
+  int buf = 0;
+  if (r_begin < r_end) {
+    gload(r_begin);
+    sstore(0);
+  }
+  __syncthreads();
+  for (int64_t r0 = r_begin; r0 < r_end; r0 += TK) {
+    const bool more = r0 + TK < r_end;
+    if (more) gload(r0 + TK);
 #pragma unroll
     for (int s = 0; s < TK / 4; ++s) {
-      const float a = As[(4 * s + fq) * DLD + 16 * w + fr];
+      const float a = As[buf][(4 * s + fq) * DLD + 16 * w + fr];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Bs[(4 * s + fq) * DLD + 16 * t + fr], acc[t], 0, 0, 0);
+      for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Bs[buf][(4 * s + fq) * DLD + 16 * t + fr], acc[t], 0, 0, 0);
     }
+    if (more) sstore(buf ^ 1);
     __syncthreads();
+    buf ^= 1;
   }
   float* P = partial + (int64_t)blockIdx.z * N * Kp;
 #pragma unroll
@@ -136,16 +174,16 @@ __global__ __launch_bounds__(256) void t_gemm_dw_kernel(const float* __restrict_
   }
 }
 
-// eight lanes per element: lane j sums the splits j, j + 8, ... in order, then a fixed xor tree (deterministic)
+// 32 lanes per element: lane j sums the splits j, j + 32, ... in order, then a fixed xor tree (deterministic)
 __global__ __launch_bounds__(256) void t_gemm_dw_reduce_kernel(const float* __restrict__ partial, int splits, int N, int K, int Kp,
                                                                float* __restrict__ dW, float* __restrict__ db) {
-  const int64_t e = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
-  const int j = threadIdx.x & 7;
+  const int64_t e = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
+  const int j = threadIdx.x & 31;
   const int64_t total = (int64_t)N * Kp;
   float s = 0.f;
   if (e < total)
-    for (int i = j; i < splits; i += 8) s += partial[(int64_t)i * total + e];
-  s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+    for (int i = j; i < splits; i += 32) s += partial[(int64_t)i * total + e];
+  s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8); s += __shfl_xor(s, 16);
   if (e >= total || j != 0) return;
   const int n = (int)(e / Kp), k = (int)(e % Kp);
   if (k < K) dW[(int64_t)n * K + k] += s;
@@ -182,13 +220,19 @@ __global__ __launch_bounds__(256) void t_gn_stats_kernel(const float* __restrict
   }
 }
 
-// stage 2: chunks in order -> mean, 1 / sqrt(var + eps)
-__global__ void t_gn_stats_final_kernel(const double* __restrict__ partial, int nchunks, int count, double inv_total,
-                                        float* __restrict__ stats) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;      // cloud * groups + g
-  if (i >= count) return;
+// stage 2: mean, 1 / sqrt(var + eps).  Eight lanes per (cloud, group): lane j adds the chunks j, j + 8, ... in order, then a fixed
+// xor tree - deterministic, and 32 dependent loads instead of 256 on the large layers
+__global__ __launch_bounds__(256) void t_gn_stats_final_kernel(const double* __restrict__ partial, int nchunks, int count, double inv_total,
+                                                               float* __restrict__ stats) {
+  const int i = blockIdx.x * 32 + (threadIdx.x >> 3);      // cloud * groups + g
+  const int j = threadIdx.x & 7;
   double a = 0.0, b = 0.0;
-  for (int c = 0; c < nchunks; ++c) { a += partial[((int64_t)i * nchunks + c) * 2]; b += partial[((int64_t)i * nchunks + c) * 2 + 1]; }
+  if (i < count)
+    for (int c = j; c < nchunks; c += 8) { a += partial[((int64_t)i * nchunks + c) * 2]; b += partial[((int64_t)i * nchunks + c) * 2 + 1]; }
+  a += __shfl_xor(a, 1); b += __shfl_xor(b, 1);
+  a += __shfl_xor(a, 2); b += __shfl_xor(b, 2);
+  a += __shfl_xor(a, 4); b += __shfl_xor(b, 4);
+  if (i >= count || j != 0) return;
   const double mean = a * inv_total;
   double var = b * inv_total - mean * mean;
   var = var > 0.0 ? var : 0.0;
@@ -242,14 +286,18 @@ __global__ __launch_bounds__(256) void t_gn_bwd_sums_kernel(const float* __restr
   }
 }
 
-// stage 2: chunks in order -> sums[cloud][C][2]
-__global__ void t_gn_bwd_sums_final_kernel(const float* __restrict__ partial, int nchunks, int C, int64_t count, float* __restrict__ sums) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // (cloud * C + c) * 2 + which
-  if (i >= count) return;
-  const int64_t cloud = i / (2 * C), rest = i % (2 * C);
+// stage 2: sums[cloud][C][2]; eight lanes per output as in t_gn_stats_final_kernel
+__global__ __launch_bounds__(256) void t_gn_bwd_sums_final_kernel(const float* __restrict__ partial, int nchunks, int C, int64_t count,
+                                                                  float* __restrict__ sums) {
+  const int64_t i = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);     // (cloud * C + c) * 2 + which
+  const int j = threadIdx.x & 7;
   double a = 0.0;
-  for (int k = 0; k < nchunks; ++k) a += partial[(cloud * nchunks + k) * 2 * C + rest];
-  sums[i] = (float)a;
+  if (i < count) {
+    const int64_t cloud = i / (2 * C), rest = i % (2 * C);
+    for (int k = j; k < nchunks; k += 8) a += partial[(cloud * nchunks + k) * 2 * C + rest];
+  }
+  a += __shfl_xor(a, 1); a += __shfl_xor(a, 2); a += __shfl_xor(a, 4);
+  if (i < count && j == 0) sums[i] = (float)a;
 }
 
 // dY = rstd (gamma g - mean_group(gamma g) - xhat mean_group(gamma g xhat)); one block per (row range, cloud)
@@ -820,7 +868,7 @@ int dsir_t_gemm_dw(void* stream, const float* dY, int ldy, const float* X, int l
   const dim3 grid((unsigned)((N + TB - 1) / TB), (unsigned)((p.Kp + TB - 1) / TB), (unsigned)p.splits);
   hipLaunchKernelGGL(t_gemm_dw_kernel, grid, dim3(256), 0, (hipStream_t)stream, dY, ldy, X, ldx, rows, p.rows_per_split, N, K, p.Kp,
                      partial);
-  hipLaunchKernelGGL(t_gemm_dw_reduce_kernel, dim3((unsigned)(((int64_t)N * p.Kp + 31) / 32)), dim3(256), 0, (hipStream_t)stream, partial, p.splits, N, K,
+  hipLaunchKernelGGL(t_gemm_dw_reduce_kernel, dim3((unsigned)(((int64_t)N * p.Kp + 7) / 8)), dim3(256), 0, (hipStream_t)stream, partial, p.splits, N, K,
                      p.Kp, dW, db);
   return done();
 }
@@ -838,7 +886,7 @@ int dsir_t_gn_fwd(void* stream, const float* Y, int clouds, int M, int C, int gr
   const int nch = gn_chunks(M), rpc = (M + nch - 1) / nch;
   double* partial = reinterpret_cast<double*>(scratch);
   hipLaunchKernelGGL(t_gn_stats_kernel, dim3(nch, groups, clouds), dim3(256), 0, st, Y, M, C, groups, rpc, partial);
-  hipLaunchKernelGGL(t_gn_stats_final_kernel, dim3((clouds * groups + 255) / 256), dim3(256), 0, st, partial, nch, clouds * groups,
+  hipLaunchKernelGGL(t_gn_stats_final_kernel, dim3((clouds * groups + 31) / 32), dim3(256), 0, st, partial, nch, clouds * groups,
                      1.0 / ((double)M * (C / groups)), stats);
   const int64_t total = (int64_t)clouds * M * C;
   hipLaunchKernelGGL(t_gn_apply_kernel, dim3(grid1(total)), dim3(256), 0, st, Y, stats, M, C, groups, gamma, beta, act, out, total);
@@ -857,7 +905,7 @@ int dsir_t_gn_bwd(void* stream, const float* dOut, const float* Y, const float* 
   hipLaunchKernelGGL(t_gn_bwd_sums_kernel, dim3((C + 31) / 32, nch, clouds), dim3(256), 0, st, dOut, Y, stats, M, C, groups, gamma, beta, act,
                      rpc, partial);
   const int64_t cnt = (int64_t)clouds * C * 2;
-  hipLaunchKernelGGL(t_gn_bwd_sums_final_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, partial, nch, C, cnt, sums);
+  hipLaunchKernelGGL(t_gn_bwd_sums_final_kernel, dim3((unsigned)((cnt + 31) / 32)), dim3(256), 0, st, partial, nch, C, cnt, sums);
   // elements per block: 16 k on the large layers, down to 4 k where that is needed for ~1000 workgroups (a block first forms the
   // group means from `sums`: C loads - not less than that many elements per thread-block pass)
   const int64_t total = (int64_t)clouds * M * C;
