@@ -305,9 +305,17 @@ __global__ __launch_bounds__(256) void t_gn_bwd_apply_kernel(const float* __rest
                                                              const float* __restrict__ stats, const float* __restrict__ sums, int M,
                                                              int C, int groups, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, int act, float* __restrict__ dY,
-                                                             int rows_per_block) {
+                                                             int rows_per_block, float* __restrict__ dgamma, float* __restrict__ dbeta) {
   extern __shared__ float gm[];   // [groups][2]: mean(gamma g), mean(gamma g xhat)
   const int cloud = blockIdx.y, gw = C / groups;
+  // the parameter gradients (sums over the clouds, in cloud order) ride along in the first workgroup: one launch less per layer
+  if (blockIdx.x == 0 && blockIdx.y == 0)
+    for (int c = threadIdx.x; c < C; c += 256) {
+      float a = 0.f, b = 0.f;
+      for (int i = 0; i < (int)gridDim.y; ++i) { a += sums[((int64_t)i * C + c) * 2]; b += sums[((int64_t)i * C + c) * 2 + 1]; }
+      dbeta[c] += a;
+      dgamma[c] += b;
+    }
   for (int g = threadIdx.x; g < groups; g += 256) {
     double a = 0.0, b = 0.0;
     for (int c = g * gw; c < (g + 1) * gw; ++c) {
@@ -330,16 +338,6 @@ __global__ __launch_bounds__(256) void t_gn_bwd_apply_kernel(const float* __rest
     if (act && !(xh * gamma[c] + beta[c] > 0.f)) d *= 0.2f;
     dY[e] = st[1] * (gamma[c] * d - gm[2 * g] - xh * gm[2 * g + 1]);
   }
-}
-
-__global__ void t_gn_bwd_params_kernel(const float* __restrict__ sums, int clouds, int C, float* __restrict__ dgamma,
-                                       float* __restrict__ dbeta) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  float a = 0.f, b = 0.f;
-  for (int i = 0; i < clouds; ++i) { a += sums[((int64_t)i * C + c) * 2]; b += sums[((int64_t)i * C + c) * 2 + 1]; }
-  dbeta[c] += a;
-  dgamma[c] += b;
 }
 
 // ---- gathers ----------------------------------------------------------------------------------------------------------
@@ -914,8 +912,7 @@ int dsir_t_gn_bwd(void* stream, const float* dOut, const float* Y, const float* 
   int rpb = (int)((per + C - 1) / C);
   rpb = rpb < 1 ? 1 : rpb;
   hipLaunchKernelGGL(t_gn_bwd_apply_kernel, dim3((M + rpb - 1) / rpb, clouds), dim3(256), (size_t)groups * 2 * sizeof(float), st, dOut, Y,
-                     stats, sums, M, C, groups, gamma, beta, act, dY, rpb);
-  hipLaunchKernelGGL(t_gn_bwd_params_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums, clouds, C, dgamma, dbeta);
+                     stats, sums, M, C, groups, gamma, beta, act, dY, rpb, dgamma, dbeta);
   return done();
 }
 
