@@ -1025,6 +1025,11 @@ int dsir_kabsch(dsir_ctx* c, const float* src, const float* tgt, const float* w,
   KabschArgs a{};
   a.src = src; a.ref = tgt; a.idx = nullptr; a.w = w; a.src_stride = (int64_t)m * 3; a.ref_stride = (int64_t)m * 3;
   a.sigmoid = 0; a.pairs = pairs; a.m = m; a.T = T; a.invalid = invalid;
+  if (const size_t pb = kabsch_part_bytes(pairs, m)) {      // large clouds: the chunked reduction of dsir_register (kabsch.hip)
+    c->ws.top = 0; c->ws.overflow = false;
+    a.part = c->ws.get<double>(pb / sizeof(double));
+    if (c->ws.overflow) return fail(c, "dsir_kabsch: workspace exhausted");
+  }
   launch_kabsch(a, c->stream);
   return post(c);
 }

@@ -14,6 +14,8 @@
 // (model.py:53,57).  Non-finite H => identity + invalid flag (model.py:61-64).
 // The same launch applies the transform to the src points, gathers the matched
 // ref points and composes the cumulative transform.
+#include <cstdlib>
+
 #include "kernels.h"
 #include "device_utils.h"
 #include "svd3.h"
@@ -347,13 +349,19 @@ __global__ __launch_bounds__(256) void kabsch_apply_kernel(const KabschArgs a) {
 
 }  // namespace
 
+// clouds of that many points and more take the chunked path; DSIR_KABSCH_CHUNKED_MIN (read per call: a test switches it) moves it
+static int chunked_min() {
+  const char* e = getenv("DSIR_KABSCH_CHUNKED_MIN");
+  return e ? atoi(e) : kKabschChunkedMin;
+}
+
 size_t kabsch_part_bytes(int pairs, int m) {
-  return m >= kKabschChunkedMin ? (size_t)pairs * ((m + CHUNK - 1) / CHUNK) * 16 * sizeof(double) : 0;
+  return m >= chunked_min() ? (size_t)pairs * ((m + CHUNK - 1) / CHUNK) * 16 * sizeof(double) : 0;
 }
 
 void launch_kabsch(const KabschArgs& a, hipStream_t st) {
   if (a.pairs <= 0) return;
-  if (a.part && a.m >= kKabschChunkedMin) {
+  if (a.part && a.m >= chunked_min()) {
     // the choice depends on the cloud size alone: a pair's pose does not depend on what else is in the batch
     const int nch = (a.m + CHUNK - 1) / CHUNK;
     const dim3 grid(nch, a.pairs);

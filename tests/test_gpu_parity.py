@@ -233,6 +233,44 @@ def test_kabsch_golden_cases():
         assert np.all(np.linalg.det(R) > 0.999), n
 
 
+@pytest.mark.parametrize("m", [16384, 20001, 65536])
+def test_kabsch_chunked_reduction_on_large_clouds(m):
+    """Clouds of >= 16384 points are reduced in chunks of 4096 points by several workgroups per pair (csrc/kabsch.hip): against
+    the oracle's solve (fp64 SVD, model.py:22-66) within 5e-6 rad / 5e-6 m, and against the one-workgroup kernel on the same
+    input (DSIR_KABSCH_CHUNKED_MIN moves the threshold) within 1e-6 - same formulas, the fp64 partial sums in another order."""
+    import os
+    from deepsir_amd.arch import NetConfig
+    from deepsir_amd.weights import generate_state_dict
+    from oracle.network import OracleNet
+    cfg = NetConfig(feat_len=3)
+    eng = engine_for(cfg, generate_state_dict(cfg, 0), "w0kab", max_points=65536, max_pairs=2)
+    rng = np.random.default_rng(m)
+    P = 2
+    src = rng.uniform(-2, 2, (P, m, 3)).astype(np.float32)
+    ang = rng.uniform(-0.5, 0.5, (P, 3))
+    tgt = np.empty_like(src)
+    for p in range(P):
+        cx, cy, cz = np.cos(ang[p]); sx, sy, sz = np.sin(ang[p])
+        R = np.array([[cz * cy, cz * sy * sx - sz * cx, cz * sy * cx + sz * sx], [sz * cy, sz * sy * sx + cz * cx, sz * sy * cx - cz * sx],
+                      [-sy, cy * sx, cy * cx]])
+        tgt[p] = (src[p].astype(np.float64) @ R.T + rng.uniform(-1, 1, 3)).astype(np.float32)
+    tgt += rng.normal(0, 0.01, tgt.shape).astype(np.float32)
+    w = rng.uniform(0, 1, (P, m)).astype(np.float32)
+    w[0, : m // 3] = 0.0                                   # a third of the points of pair 0 without weight
+    T_chunked, bad = eng.kabsch(cu(src), cu(tgt), cu(w))
+    assert not bool(bad.any())
+    os.environ["DSIR_KABSCH_CHUNKED_MIN"] = str(1 << 30)
+    try:
+        T_single, bad1 = eng.kabsch(cu(src), cu(tgt), cu(w))
+    finally:
+        del os.environ["DSIR_KABSCH_CHUNKED_MIN"]
+    assert not bool(bad1.any())
+    assert_pose_close(T_chunked.cpu().numpy(), T_single.cpu().numpy(), 1e-6, 1e-6, f"chunked vs one workgroup, m = {m}")
+    ref = np.stack([OracleNet.kabsch(torch.from_numpy(src[p:p + 1]), torch.from_numpy(tgt[p:p + 1]), torch.from_numpy(w[p:p + 1, :, None]))[0].numpy()[0]
+                    for p in range(P)])
+    assert_pose_close(T_chunked.cpu().numpy(), ref, 5e-6, 5e-6, f"chunked vs oracle, m = {m}")
+
+
 # --------------------------------------------------------------------------- whole path
 @pytest.mark.parametrize("name", ["stage_n1024_s1", "stage_n1024_s2_sep", "e2e_n2048_s3", "e2e_n2048_s4_sep",
                                   "e2e_n2048_s6_f4", "e2e_n5000_s5"])
