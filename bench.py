@@ -565,14 +565,14 @@ def main():
                 ex = screen_flops(P_launch, N, N)
                 pruned = None
                 if unpruned > 0:
-                    # long ref ranges: the launches of iterations >= 1 visit only the listed (row block, column tile) products -
+                    # long ref ranges: the launches visit only the listed (row block, column tile) products -
                     # EXECUTED flops per launch = the dense figure x the share of the products the timed launches visited
-                    n_pruned = nl * (n_iter - 1) // n_iter
-                    share = ((nl - n_pruned) + n_pruned * kept / unpruned) / nl
+                    n_pruned = nl                                  # every iteration's launch walks tile lists
+                    share = kept / unpruned
                     pruned = {"launches_pruned": n_pruned, "of_launches": nl, "tile_products_visited": kept, "tile_products_unpruned": unpruned,
                               "executed_share_of_dense_flops": round(share, 4), "dense_flops_per_launch": ex,
-                              "note": "pruned search (csrc/nn_prune.hip): products that cannot hold a row's arg-min are skipped from the second "
-                                      "iteration on; same bits as the unpruned search (tests/test_gpu_large_configs.py)"}
+                              "note": "pruned search (csrc/nn_prune.hip): products that cannot hold a row's arg-min are skipped; same bits as the "
+                                      "unpruned search (tests/test_gpu_large_configs.py)"}
                     ex = ex * share
                 roof.update({
                     "kernel": "screen_kernel<4,8> (csrc/nn_screen.hip): fp16-split MFMA screening of the 64-channel descriptor arg-min "

@@ -1194,7 +1194,7 @@ static int register_enqueue(dsir_ctx* c, const dsir_pair_batch* in, int n_iter, 
   // pruned search (nn_prune.hip) for long ref ranges: column order + tile bounds once, row order + tile lists per iteration
   // ... and only with enough rows in the launch to fill the chip with items (128 row blocks): below that the search lasts as long as
   // its longest item either way and the preparation is pure cost (one 16384-point pair: 5.18 -> 5.59 ms per registration with it)
-  const bool prune = screen && c->prune_min_points > 0 && K >= c->prune_min_points && n_iter > 1 && (int64_t)P * J >= c->prune_min_rows &&
+  const bool prune = screen && c->prune_min_points > 0 && K >= c->prune_min_points && (int64_t)P * J >= c->prune_min_rows &&
                      nn_prune_supported(P, J, K);
   void* pr_scratch = prune ? ws.raw(nn_prune_scratch_bytes(P, J, K)) : nullptr;
   // chunk partials of the pose solve on large clouds (kabsch.hip)
@@ -1268,9 +1268,10 @@ static int register_enqueue(dsir_ctx* c, const dsir_pair_batch* in, int n_iter, 
       if (screen) {
         launch_split16_norm(desc_s, (int64_t)P * J, sc_ah, sc_al, sc_sa, st);
         ScreenOrder ord;
-        if (prune && it > 0) {
-          // the previous iteration's matches bound every row's minimum from above: skip the tiles that cannot beat them
-          const int32_t* idx_prev = out->idx ? out->idx + (size_t)(it - 1) * P * J : idx_it;
+        if (prune) {
+          // an actual distance of every row - to its previous match, to the columns of its nearest tile - bounds its minimum from
+          // above: skip the tiles that cannot beat it (iteration 0 has only the second kind)
+          const int32_t* idx_prev = it == 0 ? nullptr : (out->idx ? out->idx + (size_t)(it - 1) * P * J : idx_it);
           if (launch_prune_rows(desc_s, desc_r, sc_ah, sc_al, sc_sa, sc_sb, idx_prev, P, J, K, pr_scratch, st, &ord, c->screen_acc + 4))
             return fail(c, "pruned search: sorting the rows failed");
         }

@@ -230,6 +230,10 @@ struct ScreenOrder {
 };
 int nn_screen_rows_per_block(int J);   // rows a workgroup of the screening owns for this J (what tile lists are built for)
 int nn_screen_max_bound_tiles();
+void launch_centroid_argmin(const void* ah, const void* al, const void* ch, const void* cl, const float* cn2, int pairs, int J, int nt,
+                            int32_t* tstar, hipStream_t st);
+void launch_tile_T(const void* ah, const void* al, const float* sa, const int32_t* rows, const int32_t* tstar, const void* bh, const void* bl,
+                   const float* sbp, int pairs, int J, int K, int nt, float* T, hipStream_t st);
 void launch_tile_bound(const void* ah, const void* al, const float* sa, const int32_t* rows, const float* T, const void* ch, const void* cl,
                        const float* cn2, const float* rad, int pairs, int J, int nt, int32_t* tlist, int32_t* tcount, int tl_stride,
                        int32_t* rborder, hipStream_t st);

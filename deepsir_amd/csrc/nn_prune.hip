@@ -1,21 +1,23 @@
 // Pruned nearest-descriptor search: which (row block, column tile) products of the screening (nn_screen.hip) can be skipped.
 //
 // On large clouds the arg-min is most of the path (71 % of the flops at 16 k points, 89 % at 64 k), and
-// screen_kernel multiplies every block of src descriptors with every tile of ref descriptors.  From the second registration
-// iteration on, the previous iteration's match p_j of a row gives an UPPER bound of its minimum for free,
-//       T_j = D(a_j, b_{p_j})                       (an actual distance of an actual column: min_k D(j, k) <= T_j),
-// and a tile t of 64 ref descriptors with centroid c_t and radius r_t = max_{b in t} |b - c_t| a LOWER bound of all its columns,
+// screen_kernel multiplies every block of src descriptors with every tile of ref descriptors.  A tile t of 64 ref descriptors with
+// centroid c_t and radius r_t = max_{b in t} |b - c_t| bounds all its columns from BELOW,
 //       D(a, b) = |a - b|^2 >= (|a - c_t| - r_t)_+^2        (triangle inequality),
-// so a tile whose lower bound exceeds T_j for EVERY row of a block cannot hold the arg-min of any of them - nor tie with it:
-// the skipped columns are strictly farther - and the block may skip it.  Nothing approximate enters a decision: the bounds
+// and any actual distance of a row bounds its minimum from ABOVE.  Two such distances are at hand:
+//   * T_j = D(a_j, b_{p_j}), p_j the previous iteration's match (exact fp32, row_prep_kernel), and
+//   * the smallest screening upper bound U = L + 2 d >= D over the columns of the tile whose centroid is nearest to a_j
+//     (tile_T_kernel; available in iteration 0 as well, and tight when the previous match is stale after a large pose update).
+// A tile whose lower bound exceeds min of the two for EVERY row of a block cannot hold the arg-min of any of them - nor tie with
+// it: the skipped columns are strictly farther - and the block may skip it.  Nothing approximate enters a decision: the bounds
 // only remove work, the surviving products go through the screening and the exact fp32 pick unchanged.
 // The bounds bite when tiles are compact and a block's rows agree on which tiles matter.  Descriptors are continuous
 // functions of position (model.py:209-235: per-point MLPs of xyz, score and local features), so
 //   * ref columns are taken in MORTON ORDER of their points (once per registration: the ref side is loop invariant) - tile
 //     radius 0.82 -> 0.39 / 0.13 on 16 k / 64 k-point clouds - and
-//   * src rows in the order of their previous match's position in that order (per iteration).
-// Measured on the engine's descriptors (tools/prune_stats.py): 54 % of the products of iterations 1 - 4 go at 16 384 points,
-// 35 - 62 % at 65 536, none at 5 000 (79 tiles: the search is not worth pruning there and is not).
+//   * src rows in the order of their nearest-centroid tile (per iteration; centroid_argmin_kernel).
+// Measured on the engine's descriptors (tools/prune_stats.py, "tileT"): 48 - 61 % of the products of the five iterations are
+// visited at 16 384 points, 35 - 61 % at 65 536, ~all at 5 000 (79 tiles: the search is not worth pruning there and is not).
 // All arithmetic of the bounds is fp32 with explicit safety margins (the exact distances they are compared with are fp32
 // evaluations, too): margins of 2e-5 (1 + |a|^2 + |b|^2) against evaluation errors below 4e-6 (1 + ...) - see the kernels.
 #include <hipcub/hipcub.hpp>
@@ -123,30 +125,35 @@ __global__ __launch_bounds__(256) void tile_stats_kernel(const float* __restrict
   }
 }
 
-// per src row: the position of its previous match in the column order (the key its row order is sorted by) and the upper bound
-// T = D(a, b_prev) + margin, D evaluated as nn_match.hip evaluates it (fmaf chain over the channels, the reference's roundings)
+// per src row: the sort key of the row order (its nearest-centroid tile) and the upper bound from the previous iteration's match,
+// T = D(a, b_prev) + margin, D evaluated as nn_match.hip evaluates it (fmaf chain over the channels, the reference's roundings);
+// iteration 0 (idx_prev == nullptr): +inf (tile_T_kernel supplies the bound)
 __global__ __launch_bounds__(256) void row_prep_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                        const float* __restrict__ sa, const float* __restrict__ sb,
-                                                       const int32_t* __restrict__ idx_prev, const int32_t* __restrict__ inv, int J, int K,
-                                                       int kbits, int64_t total, bool keep_all, uint32_t* __restrict__ key, uint32_t* __restrict__ val,
-                                                       float* __restrict__ T) {
+                                                       const int32_t* __restrict__ idx_prev, const int32_t* __restrict__ tstar, int J, int K,
+                                                       int tbits, int64_t total, bool keep_all, uint32_t* __restrict__ key,
+                                                       uint32_t* __restrict__ val, float* __restrict__ T) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int pair = (int)(i / J);
-    int k = idx_prev[i];
-    k = k < 0 ? 0 : (k >= K ? K - 1 : k);
-    const float4* ap = reinterpret_cast<const float4*>(a + i * 64);
-    const float4* bp = reinterpret_cast<const float4*>(b + ((int64_t)pair * K + k) * 64);
-    float acc = 0.f;
+    float bound = INFINITY;
+    if (idx_prev && !keep_all) {
+      int k = idx_prev[i];
+      k = k < 0 ? 0 : (k >= K ? K - 1 : k);
+      const float4* ap = reinterpret_cast<const float4*>(a + i * 64);
+      const float4* bp = reinterpret_cast<const float4*>(b + ((int64_t)pair * K + k) * 64);
+      float acc = 0.f;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const float4 u = ap[q], v = bp[q];
-      acc = fmaf(u.x, v.x, acc); acc = fmaf(u.y, v.y, acc); acc = fmaf(u.z, v.z, acc); acc = fmaf(u.w, v.w, acc);
+      for (int q = 0; q < 16; ++q) {
+        const float4 u = ap[q], v = bp[q];
+        acc = fmaf(u.x, v.x, acc); acc = fmaf(u.y, v.y, acc); acc = fmaf(u.z, v.z, acc); acc = fmaf(u.w, v.w, acc);
+      }
+      const float san = sa[i], sbn = sb[(int64_t)pair * K + k];
+      const float d = __fadd_rn(__fmaf_rn(acc, -2.f, san), sbn);
+      // non-finite rows get an infinite bound (they visit every tile)
+      if (d == d) bound = d + 2e-5f * (1.f + san + sbn);
     }
-    const float san = sa[i], sbn = sb[(int64_t)pair * K + k];
-    const float d = __fadd_rn(__fmaf_rn(acc, -2.f, san), sbn);
-    // non-finite rows get an infinite bound (they visit every tile)
-    T[i] = (d == d && !keep_all) ? d + 2e-5f * (1.f + san + sbn) : INFINITY;
-    key[i] = ((uint32_t)pair << kbits) | (uint32_t)inv[(int64_t)pair * K + k];
+    T[i] = bound;
+    key[i] = ((uint32_t)pair << tbits) | (uint32_t)tstar[i];
     val[i] = (uint32_t)(i % J);
   }
 }
@@ -174,7 +181,7 @@ __global__ void prune_account_kernel(const int32_t* __restrict__ tcount, int n, 
 }
 
 struct Layout {
-  int32_t *cols, *inv, *rows, *tlist, *tcount, *queue, *rborder;
+  int32_t *cols, *inv, *rows, *tlist, *tcount, *queue, *rborder, *tstar;
   float *cen, *cn2, *rad, *T, *box;
   void *ch, *cl;                       // the centroids as the screening's fp16 pairs
   void *pbh, *pbl;                     // the ref side's fp16 pairs in column order
@@ -195,6 +202,7 @@ Layout carve(void* scratch, int pairs, int J, int K) {
   L.cols = reinterpret_cast<int32_t*>(take((size_t)pairs * K * 4));
   L.inv = reinterpret_cast<int32_t*>(take((size_t)pairs * K * 4));
   L.rows = reinterpret_cast<int32_t*>(take((size_t)pairs * J * 4));
+  L.tstar = reinterpret_cast<int32_t*>(take((size_t)pairs * J * 4));
   L.tlist = reinterpret_cast<int32_t*>(take((size_t)pairs * nrb * nt * 4));
   L.tcount = reinterpret_cast<int32_t*>(take((size_t)pairs * nrb * 4));
   L.queue = reinterpret_cast<int32_t*>(take(8 * 4));
@@ -264,15 +272,18 @@ int launch_prune_rows(const float* desc_s, const float* desc_r, const void* ah, 
   const int rpb = nn_screen_rows_per_block(J);
   const int nrb = (J + rpb - 1) / rpb;
   const int64_t total = (int64_t)pairs * J;
-  const int kbits = bits_for(K);
+  const int tbits = bits_for(nt);
   static const bool id_rows = getenv("DSIR_PRUNE_ID_ROWS") != nullptr;     // measurement hook: rows in their natural order
   static const bool no_lpt = getenv("DSIR_PRUNE_NO_LPT") != nullptr;       // A/B hook: items in row-block order
   static const bool keep_all = getenv("DSIR_PRUNE_KEEP_ALL") != nullptr;   // measurement hook: every tile on every list (the mechanism's own cost)
-  hipLaunchKernelGGL(row_prep_kernel, dim3(grid_for(total)), dim3(256), 0, st, desc_s, desc_r, sa, sb, idx_prev, L.inv, J, K, kbits, total, keep_all, L.k0,
-                     L.v0, L.T);
+  static const bool no_tile_T = getenv("DSIR_PRUNE_NO_TILE_T") != nullptr; // A/B hook: upper bounds from the previous match only
+  launch_centroid_argmin(ah, al, L.ch, L.cl, L.cn2, pairs, J, nt, L.tstar, st);
+  hipLaunchKernelGGL(row_prep_kernel, dim3(grid_for(total)), dim3(256), 0, st, desc_s, desc_r, sa, sb, idx_prev, L.tstar, J, K, tbits, total,
+                     keep_all, L.k0, L.v0, L.T);
   size_t tmp = L.cub_bytes;
-  if (hipcub::DeviceRadixSort::SortPairs(L.cub, tmp, L.k0, L.k1, L.v0, L.v1, (int)total, 0, kbits + bits_for(pairs), st) != hipSuccess) return 1;
+  if (hipcub::DeviceRadixSort::SortPairs(L.cub, tmp, L.k0, L.k1, L.v0, L.v1, (int)total, 0, tbits + bits_for(pairs), st) != hipSuccess) return 1;
   hipLaunchKernelGGL(order_kernel, dim3(grid_for(total)), dim3(256), 0, st, L.v1, J, total, id_rows, L.rows, (int32_t*)nullptr);
+  if (!keep_all && !no_tile_T) launch_tile_T(ah, al, sa, L.rows, L.tstar, L.pbh, L.pbl, L.psb, pairs, J, K, nt, L.T, st);
   launch_tile_bound(ah, al, sa, L.rows, L.T, L.ch, L.cl, L.cn2, L.rad, pairs, J, nt, L.tlist, L.tcount, nt, no_lpt ? nullptr : L.rborder, st);
   if (acc) hipLaunchKernelGGL(prune_account_kernel, dim3(1), dim3(256), 0, st, L.tcount, pairs * nrb, nt, acc);
   ord->rows = L.rows;

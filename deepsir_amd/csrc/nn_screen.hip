@@ -796,6 +796,159 @@ __global__ __launch_bounds__(512) void tile_bound_kernel(const _Float16* __restr
   }
 }
 
+// ---- where does a row look first?  The tile whose CENTROID is nearest (smallest screening lower bound L(a, c_t)), per src row, rows
+// in their natural order.  That tile orders the rows (rows that start in the same tile sit in the same row block and agree on
+// which tiles matter) and supplies an upper bound of the row's minimum that does not need a previous iteration (tile_T_kernel).
+// Same MFMA chain and operands as tile_bound_kernel; L = slo_row - 2^-21 z', so the arg-min of L over t is the arg-max of z'.
+template <int RT>
+__global__ __launch_bounds__(512) void centroid_argmin_kernel(const _Float16* __restrict__ Ah, const _Float16* __restrict__ Al,
+                                                              const _Float16* __restrict__ Ch, const _Float16* __restrict__ Cl,
+                                                              const float* __restrict__ cn2, int J, int nt, int32_t* __restrict__ tstar) {
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fq = lane >> 4;
+  const int rb = blockIdx.x, pair = blockIdx.y;
+  const int64_t arow = (int64_t)pair * J;
+  const int row0 = (rb * 8 + w) * (16 * RT);
+  if (row0 >= J) return;                                 // wave-uniform; no barrier in this kernel
+  h8 ah[RT][2], al[RT][2];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    const int ra = min(row0 + rt * 16 + fr, J - 1);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      ah[rt][c] = *reinterpret_cast<const h8*>(Ah + (arow + ra) * 64 + 32 * c + 8 * fq);
+      al[rt][c] = *reinterpret_cast<const h8*>(Al + (arow + ra) * 64 + 32 * c + 8 * fq);
+    }
+  }
+  float bz[RT][4];
+  int bt[RT][4];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { bz[rt][r] = -INFINITY; bt[rt][r] = 0; }
+  const _Float16* ch = Ch + (int64_t)pair * nt * 64;
+  const _Float16* cl = Cl + (int64_t)pair * nt * 64;
+  const int nsteps = (nt + 15) >> 4;
+  for (int s = 0; s < nsteps; ++s) {
+    const int t = 16 * s + fr;
+    const int tc = min(t, nt - 1);
+    const h8 bh0 = *reinterpret_cast<const h8*>(ch + (int64_t)tc * 64 + 8 * fq), bh1 = *reinterpret_cast<const h8*>(ch + (int64_t)tc * 64 + 32 + 8 * fq);
+    const h8 bl0 = *reinterpret_cast<const h8*>(cl + (int64_t)tc * 64 + 8 * fq), bl1 = *reinterpret_cast<const h8*>(cl + (int64_t)tc * 64 + 32 + 8 * fq);
+    const float c2 = cn2[(int64_t)pair * nt + tc];
+    const float seed = t < nt ? -2097152.f * (c2 - kC1 * c2) : -INFINITY;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      f32x4 z = f32x4{seed, seed, seed, seed};
+      z = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[rt][0], bh0, z, 0, 0, 0);
+      z = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[rt][1], bh1, z, 0, 0, 0);
+      z = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[rt][0], bl0, z, 0, 0, 0);
+      z = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[rt][0], bh0, z, 0, 0, 0);
+      z = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[rt][1], bl1, z, 0, 0, 0);
+      z = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[rt][1], bh1, z, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (z[r] > bz[rt][r]) { bz[rt][r] = z[r]; bt[rt][r] = t; }        // NaN never wins; first (lowest) tile on ties within a lane
+    }
+  }
+  // the 16 lanes of a row group hold its column classes: larger z' wins, the lower tile on ties (any tile is a valid choice)
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float z = bz[rt][r];
+      int t = bt[rt][r];
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {
+        const float zo = __shfl_xor(z, o);
+        const int to = __shfl_xor(t, o);
+        if (zo > z || (zo == z && to < t)) { z = zo; t = to; }
+      }
+      const int row = row0 + rt * 16 + 4 * fq + r;
+      if (fr == 0 && row < J) tstar[arow + row] = t;
+    }
+}
+
+// ---- an upper bound of every row's minimum from the tiles its 16-row group points at.  One wave per 16 consecutive rows of the row
+// ORDER (rows sorted by their nearest-centroid tile: a group points at one or two tiles): for every distinct tile among the
+// group's rows the screening chain on (16 rows x 64 columns of the ref operands in column order), U = L + 2 d >= D(row, column)
+// for every (row, column) - the screening's proven upper bound of the exact fp32 distance -, so min U over ANY columns bounds the
+// row minimum from above.  T[row] = min(T[row], min U + margin): T arrives holding the bound from the previous iteration's match
+// (or +inf in iteration 0) and leaves as what tile_bound_kernel prunes against.
+__global__ __launch_bounds__(256) void tile_T_kernel(const _Float16* __restrict__ Ah, const _Float16* __restrict__ Al,
+                                                     const float* __restrict__ sa, const int32_t* __restrict__ rows,
+                                                     const int32_t* __restrict__ tstar, const _Float16* __restrict__ Bh,
+                                                     const _Float16* __restrict__ Bl, const float* __restrict__ sbp, int J, int K, int nt,
+                                                     float* __restrict__ T) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int pair = blockIdx.y;
+  const int g0 = (blockIdx.x * 4 + w) * 16;              // first position of the wave's group in the row order
+  if (g0 >= J) return;                                   // wave-uniform; no barrier in this kernel
+  const int64_t arow = (int64_t)pair * J, brow = (int64_t)pair * K;
+  const int ra = rows[arow + min(g0 + fr, J - 1)];        // the row whose A fragment this lane holds
+  h8 ah[2], al[2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    ah[c] = *reinterpret_cast<const h8*>(Ah + (arow + ra) * 64 + 32 * c + 8 * fq);
+    al[c] = *reinterpret_cast<const h8*>(Al + (arow + ra) * 64 + 32 * c + 8 * fq);
+  }
+  int rowe[4];
+  float san[4], slo[4], best[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    rowe[r] = rows[arow + min(g0 + 4 * fq + r, J - 1)];
+    san[r] = sa[arow + rowe[r]];
+    slo[r] = san[r] - kC1 * san[r] - kC0;
+    best[r] = INFINITY;
+  }
+  int mine = tstar[arow + ra];                            // the tile this lane's row points at (lanes fr, all four fq copies)
+  mine = mine < 0 ? 0 : (mine >= nt ? nt - 1 : mine);
+  bool pending = g0 + fr < J;
+  for (int guard = 0; guard < 16; ++guard) {              // at most 16 distinct tiles per group
+    // the lowest tile some lane still waits for
+    int t = pending ? mine : 0x7fffffff;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) t = min(t, __shfl_xor(t, o));
+    if (t == 0x7fffffff) break;                           // wave-uniform
+    if (mine == t) pending = false;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int pos = min(64 * t + 16 * s + fr, K - 1);
+      const bool live = 64 * t + 16 * s + fr < K;
+      const _Float16* bh = Bh + (brow + pos) * 64;
+      const _Float16* bl = Bl + (brow + pos) * 64;
+      const h8 bh0 = *reinterpret_cast<const h8*>(bh + 8 * fq), bh1 = *reinterpret_cast<const h8*>(bh + 32 + 8 * fq);
+      const h8 bl0 = *reinterpret_cast<const h8*>(bl + 8 * fq), bl1 = *reinterpret_cast<const h8*>(bl + 32 + 8 * fq);
+      const float sbk = sbp[brow + pos];
+      const float seed = -2097152.f * (sbk - kC1 * sbk);
+      f32x4 z = f32x4{seed, seed, seed, seed};
+      z = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[0], bh0, z, 0, 0, 0);         // screen_item's chain
+      z = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[1], bh1, z, 0, 0, 0);
+      z = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[0], bl0, z, 0, 0, 0);
+      z = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[0], bh0, z, 0, 0, 0);
+      z = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[1], bl1, z, 0, 0, 0);
+      z = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[1], bh1, z, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float l = fmaf(z[r], -4.76837158203125e-7f, slo[r]);
+        // U = L + 2 d (the epilogue of screen_item) + the margin row_prep_kernel puts on an exact distance
+        const float u = l + kW * (kC1 * (san[r] + sbk) + kC0) + 2e-5f * (1.f + san[r] + sbk);
+        if (live) best[r] = fminf(best[r], u);           // NaN: ignored (a row without finite bound keeps +inf: it visits every tile)
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float b = best[r];
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) b = fminf(b, __shfl_xor(b, o));
+    if (fr == 0 && g0 + 4 * fq + r < J) {
+      const float old = T[arow + rowe[r]];
+      T[arow + rowe[r]] = fminf(old, b);                   // one writer per row
+    }
+  }
+}
+
 // the row blocks of every pair by descending tile count (ties: by index): the persistent search takes the long items first, so
 // that its last round is made of short ones (longest-processing-time-first; the tail of a launch was up to one full-length item,
 // 18 % of the kernel at 65536 points).  One workgroup per pair, rank by counting - a pair has at most a few hundred row blocks
@@ -815,6 +968,26 @@ inline int grid_for(int64_t n) { const int64_t g = (n + 255) / 256; return (int)
 }  // namespace
 
 int nn_screen_max_bound_tiles() { return kMaxBoundTiles; }
+
+// nearest-centroid tile of every src row (natural row order)
+void launch_centroid_argmin(const void* ah, const void* al, const void* ch, const void* cl, const float* cn2, int pairs, int J, int nt,
+                            int32_t* tstar, hipStream_t st) {
+  const int rpb = nn_screen_rows_per_block(J);
+  const dim3 grid((J + rpb - 1) / rpb, pairs);
+  const _Float16 *Ah = reinterpret_cast<const _Float16*>(ah), *Al = reinterpret_cast<const _Float16*>(al);
+  const _Float16 *Ch = reinterpret_cast<const _Float16*>(ch), *Cl = reinterpret_cast<const _Float16*>(cl);
+  if (rpb == 512) hipLaunchKernelGGL(centroid_argmin_kernel<4>, grid, dim3(512), 0, st, Ah, Al, Ch, Cl, cn2, J, nt, tstar);
+  else            hipLaunchKernelGGL(centroid_argmin_kernel<2>, grid, dim3(512), 0, st, Ah, Al, Ch, Cl, cn2, J, nt, tstar);
+}
+
+// T[row] = min(T[row], upper bound from the tiles the row's 16-row group (in the row order) points at); bh / bl / sbp: the ref
+// operands in column order
+void launch_tile_T(const void* ah, const void* al, const float* sa, const int32_t* rows, const int32_t* tstar, const void* bh, const void* bl,
+                   const float* sbp, int pairs, int J, int K, int nt, float* T, hipStream_t st) {
+  hipLaunchKernelGGL(tile_T_kernel, dim3((J + 63) / 64, pairs), dim3(256), 0, st, reinterpret_cast<const _Float16*>(ah),
+                     reinterpret_cast<const _Float16*>(al), sa, rows, tstar, reinterpret_cast<const _Float16*>(bh),
+                     reinterpret_cast<const _Float16*>(bl), sbp, J, K, nt, T);
+}
 
 // tile lists of every (pair, row block) for the row order `rows` and the per-row upper bounds T (nn_prune.hip)
 void launch_tile_bound(const void* ah, const void* al, const float* sa, const int32_t* rows, const float* T, const void* ch, const void* cl,

@@ -50,14 +50,16 @@ o = eng.register(src, ref, 5, want_desc=True)
 print(f"points {N} pairs {P} shape {shape} partial {partial}: blocks of {RB} rows x tiles of {CT} columns")
 # "need+morton": rows grouped by how many tiles they need themselves (8 classes), then by match position: rows that need
 # everything (poor previous match, no counterpart) no longer drag the blocks of well-matched rows up to the full list
-for order in ("as given", "morton", "need+morton", "T1+morton", "T2+morton"):
-    for it in range(1, 5):
+# "tileT": the upper bound T also takes the exact minimum over the columns of the tile with the NEAREST CENTROID (an actual
+# distance of the row, hence valid) - available in iteration 0 too, where rows are ordered by that tile instead of a previous match
+for order in ("as given", "morton", "need+morton", "T1+morton", "T2+morton", "tileT"):
+    for it in range(0 if order == "tileT" else 1, 5):
         kept = total = 0
         radii = []
         for p in range(P):
             r = o["desc_ref"][p]
             a = o["desc_src"][it, p]
-            prev = o["idx"][it - 1, p].long()
+            prev = o["idx"][max(it - 1, 0), p].long()
             if order != "as given":
                 perm = torch.argsort(morton(ref[p, :, :3]))
                 inv = torch.empty_like(perm); inv[perm] = torch.arange(N, device=perm.device)
@@ -76,11 +78,24 @@ for order in ("as given", "morton", "need+morton", "T1+morton", "T2+morton"):
                     T_ = ((a - r[prev_pos]) ** 2).sum(1) + 1e-5
                     cls = T_.view(torch.int32).long() >> (23 if order == "T1+morton" else 22)
                     key = cls * (1 << 20) + prev_pos
+                if order == "tileT" and it == 0:          # no previous match: rows by the tile with the nearest centroid
+                    nt_ = (N + CT - 1) // CT
+                    rp_ = torch.cat([r, r[-1:].expand(nt_ * CT - N, -1)], 0).view(nt_, CT, 64)
+                    key = torch.cdist(a, rp_.mean(1)).argmin(1) * CT
                 rows = torch.argsort(key)                 # src rows ordered by where their previous match sits
                 a, prev_pos = a[rows], prev_pos[rows]
             else:
                 prev_pos = prev
             T = ((a - r[prev_pos]) ** 2).sum(1) + 1e-5   # upper bound of the row minimum (+ safety margin)
+            if order == "tileT":
+                nt_ = (N + CT - 1) // CT
+                rp_ = torch.cat([r, r[-1:].expand(nt_ * CT - N, -1)], 0).view(nt_, CT, 64)
+                tstar = torch.cdist(a, rp_.mean(1)).argmin(1)                     # nearest centroid (rows already in their order)
+                Tt = torch.empty_like(T)
+                for s0 in range(0, a.shape[0], 4096):
+                    blk = rp_[tstar[s0:s0 + 4096]]                                  # [rows, 64, 64]
+                    Tt[s0:s0 + 4096] = ((a[s0:s0 + 4096, None, :] - blk) ** 2).sum(2).min(1)[0] + 1e-5
+                T = Tt if it == 0 else torch.minimum(T, Tt)
             nt = (N + CT - 1) // CT
             pad = nt * CT - N
             rp = torch.cat([r, r[-1:].expand(pad, -1)], 0).view(nt, CT, 64)
