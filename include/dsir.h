@@ -320,9 +320,9 @@ int dsir_enable_match_timer(dsir_ctx* ctx, int enable);
  * [4] searches that took the exhaustive kernel directly (small problems, forced runs excluded).  Synchronises.
  * Not counted while a hipGraph replays (dsir_enable_graph): [4] is a host-side counter. */
 int dsir_screen_stats(dsir_ctx* ctx, int reset, int64_t* out);
-/* The pruned search of long ref ranges (csrc/nn_prune.hip; clouds of 8192 points and more, from the second registration
- * iteration on): out (HOST, 2 x i64) = (row block, column tile) products the screening visited, and the number it would have
- * visited without pruning, since the last reset.  Synchronises. */
+/* The pruned search of long ref ranges (csrc/nn_prune.hip; clouds of 8192 points and more in launches of 65536 src rows and more,
+ * every registration iteration): out (HOST, 2 x i64) = (row block, column tile) products the screening visited, and the number it
+ * would have visited without pruning, since the last reset.  Synchronises. */
 int dsir_prune_stats(dsir_ctx* ctx, int reset, int64_t* out);
 /* A/B switch (measurement / test): the pruned search runs for ref clouds of min_points points and more (default 8192, initialised
  * from DSIR_PRUNE_MIN_K; 0 = never) in launches of min_rows src rows (pairs x points) and more (default 65536: below that the
