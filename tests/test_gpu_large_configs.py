@@ -134,8 +134,8 @@ def test_large_register_screened_equals_exhaustive(tmp_path, pairs, n, feat_len,
         assert np.array_equal(a[k], b[k]), f"{k} differs between the screened and the exhaustive arg-min at {n} points"
 
 
-@pytest.mark.parametrize("pairs,J,K,partial", [(4, 7000, 7300, 0), (2, 10100, 9999, 1)])
-def test_pruned_search_on_ragged_sizes_gives_the_unpruned_bits(pairs, J, K, partial):
+@pytest.mark.parametrize("pairs,J,K,partial,poison", [(4, 7000, 7300, 0, 0), (2, 10100, 9999, 1, 0), (3, 8300, 8200, 0, 1)])
+def test_pruned_search_on_ragged_sizes_gives_the_unpruned_bits(pairs, J, K, partial, poison):
     """The pruned search forced onto sizes that are multiples of nothing (J % 512, K % 64 != 0: a partial last row block, a
     partial last column tile, odd tile lists), src and ref clouds of different sizes, ref points with exact duplicates
     (tiles of radius 0 and tied distances): idx / logits / transforms of the pruned, the unpruned screened and the exhaustive
@@ -153,6 +153,11 @@ def test_pruned_search_on_ragged_sizes_gives_the_unpruned_bits(pairs, J, K, part
     ref_np = np.ascontiguousarray(raw["points_ref"][:, :K]).copy()
     ref_np[:, 100:164] = ref_np[:, 99:100]          # 64 copies of one point: identical descriptors wherever their neighbourhoods agree
     ref_np[:, K - 3:] = ref_np[:, 5:6]              # duplicates in the partial last tile
+    if poison:                                      # non-finite points in ONE pair: that pair leaves the screening's domain (exhaustive,
+        src_np = src.cpu().numpy().copy()           # invalid flag), the others are still pruned
+        src_np[1, 17, 0] = np.nan
+        ref_np[1, 4000, 1] = np.inf
+        src = cu(src_np)
     ref = cu(ref_np)
     outs = {}
     for name in ("pruned", "unpruned", "exhaustive"):
@@ -173,8 +178,10 @@ def test_pruned_search_on_ragged_sizes_gives_the_unpruned_bits(pairs, J, K, part
             assert total == 4 * pairs * nrb * nt and 0 < kept < total
         else:
             assert total == 0
-        outs[name] = {k: o[k].cpu().numpy() for k in ("idx", "logits", "transforms")}
+        outs[name] = {k: o[k].cpu().numpy() for k in ("idx", "logits", "transforms", "invalid")}
     eng.close()
-    for k in ("idx", "logits", "transforms"):
-        assert np.array_equal(outs["pruned"][k], outs["unpruned"][k]), f"{k}: pruned != unpruned"
-        assert np.array_equal(outs["pruned"][k], outs["exhaustive"][k]), f"{k}: pruned != exhaustive"
+    if poison:
+        assert outs["pruned"]["invalid"][1] != 0 and outs["pruned"]["invalid"][0] == 0 and outs["pruned"]["invalid"][2] == 0
+    for k in ("idx", "logits", "transforms", "invalid"):
+        assert np.array_equal(outs["pruned"][k], outs["unpruned"][k], equal_nan=True), f"{k}: pruned != unpruned"
+        assert np.array_equal(outs["pruned"][k], outs["exhaustive"][k], equal_nan=True), f"{k}: pruned != exhaustive"
