@@ -715,6 +715,7 @@ int dsir_create(int device, const dsir_cfg* cfg, dsir_ctx** out) {
   c->device = device; c->cfg = *cfg;
   c->screen_mode = getenv("DSIR_NO_SCREEN") ? 0 : 1;
   if (const char* e = getenv("DSIR_PRUNE_MIN_K")) c->prune_min_points = atoi(e) > 0 ? atoi(e) : 0;   // A/B hook; 0 = off
+  if (const char* e = getenv("DSIR_PRUNE_MIN_ROWS")) c->prune_min_rows = atoll(e) > 0 ? atoll(e) : 0;   // tuning hook
   c->agg_split = getenv("DSIR_AGG_F32") ? 0 : 1;
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
     delete c;

@@ -729,7 +729,10 @@ __global__ __launch_bounds__(512) void tile_bound_kernel(const _Float16* __restr
   const int nsteps = (nt + 15) >> 4;
   for (int i = tid; i < nsteps; i += 512) flags[i] = 0u;
   h8 ah[RT][2], al[RT][2];
-  float slo[RT][4], Tv[RT][4], mrg[RT][4];
+  // skip iff (sqrt(lo) 0.99999 - r)_+^2 > T, tested without a square root per element as lo > ((sqrt(T) + r) k)^2, k = 1.00002 (the
+  // factor 1 / 0.99999 and the rounding of sqrtf): slo2 = |a|^2 - d_a - margin per row (+inf for rows past the end: they need
+  // nothing), sT = sqrt(T) k per row, r k per column
+  float slo2[RT][4], sT[RT][4];
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
     const int ra = rows[arow + min(row0 + rt * 16 + fr, J - 1)];
@@ -743,9 +746,8 @@ __global__ __launch_bounds__(512) void tile_bound_kernel(const _Float16* __restr
       const int pos = row0 + rt * 16 + 4 * fq + r;
       const int re = rows[arow + min(pos, J - 1)];
       const float san = sa[arow + re];
-      slo[rt][r] = san - kC1 * san - kC0;
-      mrg[rt][r] = 1e-5f * (1.f + san);
-      Tv[rt][r] = pos < J ? T[arow + re] : -INFINITY;       // rows past the end need nothing
+      slo2[rt][r] = pos < J ? (san - kC1 * san - kC0) - 1e-5f * (1.f + san) : INFINITY;
+      sT[rt][r] = pos < J ? sqrtf(T[arow + re]) * 1.00002f : 0.f;      // T < 0 or NaN: NaN - the row visits every tile
     }
   }
   __syncthreads();
@@ -757,8 +759,9 @@ __global__ __launch_bounds__(512) void tile_bound_kernel(const _Float16* __restr
     const h8 bh0 = *reinterpret_cast<const h8*>(ch + (int64_t)tc * 64 + 8 * fq), bh1 = *reinterpret_cast<const h8*>(ch + (int64_t)tc * 64 + 32 + 8 * fq);
     const h8 bl0 = *reinterpret_cast<const h8*>(cl + (int64_t)tc * 64 + 8 * fq), bl1 = *reinterpret_cast<const h8*>(cl + (int64_t)tc * 64 + 32 + 8 * fq);
     const float c2 = cn2[(int64_t)pair * nt + tc];
-    const float rt_ = rad[(int64_t)pair * nt + tc];
-    const float seed = t < nt ? -2097152.f * (c2 - kC1 * c2) : -INFINITY;      // tiles past the end: L = +inf, never needed
+    const float rk = rad[(int64_t)pair * nt + tc] * 1.00002f;
+    const float cterm = 1e-5f * c2;
+    const float seed = t < nt ? -2097152.f * (c2 - kC1 * c2) : -INFINITY;      // tiles past the end: L = +inf (their flags are not read)
     bool need = false;
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
@@ -771,10 +774,10 @@ __global__ __launch_bounds__(512) void tile_bound_kernel(const _Float16* __restr
       z = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[rt][1], bh1, z, 0, 0, 0);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        // L <= D(a, c) (the screening bound), D(a, c) within mrg + 1e-5 c2 of the true |a - c|^2: a lower bound of that
-        const float lo = fmaf(z[r], -4.76837158203125e-7f, slo[rt][r]) - mrg[rt][r] - 1e-5f * c2;
-        const float gap = fmaxf(sqrtf(fmaxf(lo, 0.f)) * 0.99999f - rt_, 0.f);
-        need = need || !(gap * gap > Tv[rt][r]);                                 // NaN anywhere: visit; Tv = -inf: never
+        // L <= D(a, c) (the screening bound), D(a, c) within 1e-5 (1 + |a|^2 + |c|^2) of the true |a - c|^2: a lower bound of that
+        const float lo = fmaf(z[r], -4.76837158203125e-7f, slo2[rt][r]) - cterm;
+        const float thr = sT[rt][r] + rk;
+        need = need || !(lo > thr * thr);                                        // NaN anywhere: visit
       }
     }
     const unsigned long long m = __ballot(need);
