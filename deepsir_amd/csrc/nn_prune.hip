@@ -181,7 +181,7 @@ __global__ void prune_account_kernel(const int32_t* __restrict__ tcount, int n, 
 }
 
 struct Layout {
-  int32_t *cols, *inv, *rows, *tlist, *tcount, *queue, *rborder, *tstar;
+  int32_t *cols, *rows, *tlist, *tcount, *queue, *rborder, *tstar;
   float *cen, *cn2, *rad, *T, *box;
   void *ch, *cl;                       // the centroids as the screening's fp16 pairs
   void *pbh, *pbl;                     // the ref side's fp16 pairs in column order
@@ -200,7 +200,6 @@ Layout carve(void* scratch, int pairs, int J, int K) {
   auto take = [&](size_t bytes) { char* r = p; p += align256(bytes); return r; };
   Layout L{};
   L.cols = reinterpret_cast<int32_t*>(take((size_t)pairs * K * 4));
-  L.inv = reinterpret_cast<int32_t*>(take((size_t)pairs * K * 4));
   L.rows = reinterpret_cast<int32_t*>(take((size_t)pairs * J * 4));
   L.tstar = reinterpret_cast<int32_t*>(take((size_t)pairs * J * 4));
   L.tlist = reinterpret_cast<int32_t*>(take((size_t)pairs * nrb * nt * 4));
@@ -253,7 +252,7 @@ int launch_prune_ref(const float* ref_xyz, int64_t xyz_cs, const float* desc_r, 
   hipLaunchKernelGGL(morton_kernel, dim3(grid_for(total)), dim3(256), 0, st, ref_xyz, xyz_cs, K, L.box, total, mbits, L.k0, L.v0);
   size_t tmp = L.cub_bytes;
   if (hipcub::DeviceRadixSort::SortPairs(L.cub, tmp, L.k0, L.k1, L.v0, L.v1, (int)total, 0, mbits + pbits, st) != hipSuccess) return 1;
-  hipLaunchKernelGGL(order_kernel, dim3(grid_for(total)), dim3(256), 0, st, L.v1, K, total, false, L.cols, L.inv);
+  hipLaunchKernelGGL(order_kernel, dim3(grid_for(total)), dim3(256), 0, st, L.v1, K, total, false, L.cols, (int32_t*)nullptr);
   const int64_t tiles_total = (int64_t)pairs * nt;
   hipLaunchKernelGGL(tile_stats_kernel, dim3((unsigned)((tiles_total + 3) / 4)), dim3(256), 0, st, desc_r, L.cols, K, nt, tiles_total, L.cen, L.cn2,
                      L.rad);
