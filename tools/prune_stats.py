@@ -52,8 +52,20 @@ print(f"points {N} pairs {P} shape {shape} partial {partial}: blocks of {RB} row
 # everything (poor previous match, no counterpart) no longer drag the blocks of well-matched rows up to the full list
 # "tileT": the upper bound T also takes the exact minimum over the columns of the tile with the NEAREST CENTROID (an actual
 # distance of the row, hence valid) - available in iteration 0 too, where rows are ordered by that tile instead of a previous match
-for order in ("as given", "morton", "need+morton", "T1+morton", "T2+morton", "tileT"):
-    for it in range(0 if order == "tileT" else 1, 5):
+# "kmeansT": like "tileT", but the ref columns are ordered by k-means clusters of the DESCRIPTORS (one cluster per tile's worth of
+# columns, 10 Lloyd iterations, columns sorted by cluster) instead of the Morton order of their points
+def kmeans_order(r, nt, iters=10):
+    g = torch.Generator(device="cpu").manual_seed(0)
+    cen = r[torch.randperm(r.shape[0], generator=g)[:nt].to(r.device)].clone()
+    for _ in range(iters):
+        a_ = torch.cdist(r, cen).argmin(1)
+        cen = torch.zeros_like(cen).index_add_(0, a_, r) / torch.bincount(a_, minlength=nt).clamp(min=1)[:, None]
+    a_ = torch.cdist(r, cen).argmin(1)
+    return torch.argsort(a_ * (1 << 20) + torch.arange(r.shape[0], device=r.device))
+
+
+for order in ("as given", "morton", "need+morton", "T1+morton", "T2+morton", "tileT", "kmeansT"):
+    for it in range(0 if order in ("tileT", "kmeansT") else 1, 5):
         kept = total = 0
         radii = []
         for p in range(P):
@@ -61,7 +73,7 @@ for order in ("as given", "morton", "need+morton", "T1+morton", "T2+morton", "ti
             a = o["desc_src"][it, p]
             prev = o["idx"][max(it - 1, 0), p].long()
             if order != "as given":
-                perm = torch.argsort(morton(ref[p, :, :3]))
+                perm = kmeans_order(r, (N + CT - 1) // CT) if order == "kmeansT" else torch.argsort(morton(ref[p, :, :3]))
                 inv = torch.empty_like(perm); inv[perm] = torch.arange(N, device=perm.device)
                 r = r[perm]
                 prev_pos = inv[prev]                      # position of the previous match in the sorted ref order
@@ -78,7 +90,7 @@ for order in ("as given", "morton", "need+morton", "T1+morton", "T2+morton", "ti
                     T_ = ((a - r[prev_pos]) ** 2).sum(1) + 1e-5
                     cls = T_.view(torch.int32).long() >> (23 if order == "T1+morton" else 22)
                     key = cls * (1 << 20) + prev_pos
-                if order == "tileT" and it == 0:          # no previous match: rows by the tile with the nearest centroid
+                if order in ("tileT", "kmeansT") and it == 0:          # no previous match: rows by the tile with the nearest centroid
                     nt_ = (N + CT - 1) // CT
                     rp_ = torch.cat([r, r[-1:].expand(nt_ * CT - N, -1)], 0).view(nt_, CT, 64)
                     key = torch.cdist(a, rp_.mean(1)).argmin(1) * CT
@@ -87,7 +99,7 @@ for order in ("as given", "morton", "need+morton", "T1+morton", "T2+morton", "ti
             else:
                 prev_pos = prev
             T = ((a - r[prev_pos]) ** 2).sum(1) + 1e-5   # upper bound of the row minimum (+ safety margin)
-            if order == "tileT":
+            if order in ("tileT", "kmeansT"):
                 nt_ = (N + CT - 1) // CT
                 rp_ = torch.cat([r, r[-1:].expand(nt_ * CT - N, -1)], 0).view(nt_, CT, 64)
                 tstar = torch.cdist(a, rp_.mean(1)).argmin(1)                     # nearest centroid (rows already in their order)
