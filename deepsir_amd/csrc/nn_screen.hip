@@ -753,13 +753,26 @@ __global__ __launch_bounds__(512) void tile_bound_kernel(const _Float16* __restr
   __syncthreads();
   const _Float16* ch = Ch + (int64_t)pair * nt * 64;
   const _Float16* cl = Cl + (int64_t)pair * nt * 64;
+  // the next step's centroid fragments travel while the current step's MFMAs run (a step's own loads were exposed: 24 MFMAs
+  // cannot start before four 16-byte loads and two scalars have come back)
+  struct CFrag { h8 bh0, bh1, bl0, bl1; float c2, rad; };
+  auto cload = [&](int s) {
+    const int tc = min(16 * s + fr, nt - 1);
+    CFrag f;
+    f.bh0 = *reinterpret_cast<const h8*>(ch + (int64_t)tc * 64 + 8 * fq); f.bh1 = *reinterpret_cast<const h8*>(ch + (int64_t)tc * 64 + 32 + 8 * fq);
+    f.bl0 = *reinterpret_cast<const h8*>(cl + (int64_t)tc * 64 + 8 * fq); f.bl1 = *reinterpret_cast<const h8*>(cl + (int64_t)tc * 64 + 32 + 8 * fq);
+    f.c2 = cn2[(int64_t)pair * nt + tc];
+    f.rad = rad[(int64_t)pair * nt + tc];
+    return f;
+  };
+  CFrag nxt = cload(0);
   for (int s = 0; s < nsteps; ++s) {
+    const CFrag cur = nxt;
+    if (s + 1 < nsteps) nxt = cload(s + 1);
     const int t = 16 * s + fr;
-    const int tc = min(t, nt - 1);
-    const h8 bh0 = *reinterpret_cast<const h8*>(ch + (int64_t)tc * 64 + 8 * fq), bh1 = *reinterpret_cast<const h8*>(ch + (int64_t)tc * 64 + 32 + 8 * fq);
-    const h8 bl0 = *reinterpret_cast<const h8*>(cl + (int64_t)tc * 64 + 8 * fq), bl1 = *reinterpret_cast<const h8*>(cl + (int64_t)tc * 64 + 32 + 8 * fq);
-    const float c2 = cn2[(int64_t)pair * nt + tc];
-    const float rk = rad[(int64_t)pair * nt + tc] * 1.00002f;
+    const h8 bh0 = cur.bh0, bh1 = cur.bh1, bl0 = cur.bl0, bl1 = cur.bl1;
+    const float c2 = cur.c2;
+    const float rk = cur.rad * 1.00002f;
     const float cterm = 1e-5f * c2;
     const float seed = t < nt ? -2097152.f * (c2 - kC1 * c2) : -INFINITY;      // tiles past the end: L = +inf (their flags are not read)
     bool need = false;
@@ -876,7 +889,8 @@ __global__ __launch_bounds__(512) void centroid_argmin_kernel(const _Float16* __
 // group's rows the screening chain on (16 rows x 64 columns of the ref operands in column order), U = L + 2 d >= D(row, column)
 // for every (row, column) - the screening's proven upper bound of the exact fp32 distance -, so min U over ANY columns bounds the
 // row minimum from above.  T[row] = min(T[row], min U + margin): T arrives holding the bound from the previous iteration's match
-// (or +inf in iteration 0) and leaves as what tile_bound_kernel prunes against.
+// (or +inf in iteration 0) and leaves as what tile_bound_kernel prunes against.  (64-row groups - a tile's operands read once per
+// 64 rows - measured twice as slow: 4 x fewer waves with 3 x longer dependent chains; the kernel is latency-, not bandwidth-bound.)
 __global__ __launch_bounds__(256) void tile_T_kernel(const _Float16* __restrict__ Ah, const _Float16* __restrict__ Al,
                                                      const float* __restrict__ sa, const int32_t* __restrict__ rows,
                                                      const int32_t* __restrict__ tstar, const _Float16* __restrict__ Bh,
