@@ -452,12 +452,35 @@ __global__ void t_inlier_input_kernel(const float* __restrict__ xs, const float*
 }
 
 // ---- attentive pooling ------------------------------------------------------------------------------------------------
+// k = 16 neighbours (the network's only value): a point's column of scores and features lives in registers - one read of S and
+// cat and one exp per element instead of three reads and two exps; same operations in the same order (same bits)
 __global__ void t_attpool_fwd_kernel(const float* __restrict__ cat, float* __restrict__ S, int k, int C, float* __restrict__ out,
                                      int64_t total) {
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
     const int c = (int)(e % C);
     const int64_t p = e / C;
     const int64_t b = p * k * C + c;
+    if (k == 16) {
+      float sv[16], cv[16];
+#pragma unroll
+      for (int t = 0; t < 16; ++t) { sv[t] = S[b + (int64_t)t * C]; cv[t] = cat[b + (int64_t)t * C]; }
+      float mx = -INFINITY;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) mx = fmaxf(mx, sv[t]);
+      float se = 0.f;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) { sv[t] = expf(sv[t] - mx); se += sv[t]; }
+      const float inv = 1.f / se;
+      float o = 0.f;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const float a = sv[t] * inv;
+        S[b + (int64_t)t * C] = a;
+        o += a * cv[t];
+      }
+      out[e] = o;
+      continue;
+    }
     float mx = -INFINITY;
     for (int t = 0; t < k; ++t) mx = fmaxf(mx, S[b + (int64_t)t * C]);
     float se = 0.f;
@@ -480,6 +503,21 @@ __global__ void t_attpool_bwd_kernel(const float* __restrict__ dOut, const float
     const int64_t p = e / C;
     const int64_t b = p * k * C + c;
     const float g = dOut[e];
+    if (k == 16) {
+      float av[16], cv[16];
+#pragma unroll
+      for (int t = 0; t < 16; ++t) { av[t] = A[b + (int64_t)t * C]; cv[t] = cat[b + (int64_t)t * C]; }
+      float dot = 0.f;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) dot += av[t] * cv[t];
+      dot *= g;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        dCat[b + (int64_t)t * C] = av[t] * g;
+        dS[b + (int64_t)t * C] = av[t] * (cv[t] * g - dot);
+      }
+      continue;
+    }
     float dot = 0.f;
     for (int t = 0; t < k; ++t) dot += A[b + (int64_t)t * C] * cat[b + (int64_t)t * C];
     dot *= g;                                // sum_t a_t (cat_t g)
