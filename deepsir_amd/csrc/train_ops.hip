@@ -174,20 +174,29 @@ __global__ __launch_bounds__(256) void t_gemm_dw_kernel(const float* __restrict_
   }
 }
 
-// 32 lanes per element: lane j sums the splits j, j + 32, ... in order, then a fixed xor tree (deterministic)
+// block = 32 consecutive elements x 8 split lanes: lane (el, sl) adds the splits sl, sl + 8, ... of its element in order - a wave reads
+// two 128-byte runs per trip instead of 64 scattered floats -, then the 8 lanes of an element meet in LDS in a fixed order
+// (deterministic)
 __global__ __launch_bounds__(256) void t_gemm_dw_reduce_kernel(const float* __restrict__ partial, int splits, int N, int K, int Kp,
                                                                float* __restrict__ dW, float* __restrict__ db) {
-  const int64_t e = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
-  const int j = threadIdx.x & 31;
+  __shared__ float sh[8][32];
+  const int el = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int64_t e = (int64_t)blockIdx.x * 32 + el;
   const int64_t total = (int64_t)N * Kp;
   float s = 0.f;
-  if (e < total)
-    for (int i = j; i < splits; i += 32) s += partial[(int64_t)i * total + e];
-  s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8); s += __shfl_xor(s, 16);
-  if (e >= total || j != 0) return;
+  if (e < total) {
+#pragma unroll 4
+    for (int i = sl; i < splits; i += 8) s += partial[(int64_t)i * total + e];
+  }
+  sh[sl][el] = s;
+  __syncthreads();
+  if (sl != 0 || e >= total) return;
+  float a = sh[0][el];
+#pragma unroll
+  for (int q = 1; q < 8; ++q) a += sh[q][el];
   const int n = (int)(e / Kp), k = (int)(e % Kp);
-  if (k < K) dW[(int64_t)n * K + k] += s;
-  else if (db) db[n] += s;
+  if (k < K) dW[(int64_t)n * K + k] += a;
+  else if (db) db[n] += a;
 }
 
 // ---- GroupNorm / BatchNorm(train) -------------------------------------------------------------------------------------
@@ -950,7 +959,7 @@ int dsir_t_gemm_dw(void* stream, const float* dY, int ldy, const float* X, int l
   const dim3 grid((unsigned)((N + TB - 1) / TB), (unsigned)((p.Kp + TB - 1) / TB), (unsigned)p.splits);
   hipLaunchKernelGGL(t_gemm_dw_kernel, grid, dim3(256), 0, (hipStream_t)stream, dY, ldy, X, ldx, rows, p.rows_per_split, N, K, p.Kp,
                      partial);
-  hipLaunchKernelGGL(t_gemm_dw_reduce_kernel, dim3((unsigned)(((int64_t)N * p.Kp + 7) / 8)), dim3(256), 0, (hipStream_t)stream, partial, p.splits, N, K,
+  hipLaunchKernelGGL(t_gemm_dw_reduce_kernel, dim3((unsigned)(((int64_t)N * p.Kp + 31) / 32)), dim3(256), 0, (hipStream_t)stream, partial, p.splits, N, K,
                      p.Kp, dW, db);
   return done();
 }
