@@ -507,7 +507,7 @@ class RandlaTrainer(_ParamStore):
         o = self.ops
         o.begin()
         for p, sh in shared.items():
-            if sh["denc2"] is None and sh["denc"] is None:
+            if p == "_pyr" or (sh["denc2"] is None and sh["denc"] is None):    # "_pyr": the cached pyramid slices of ``forward``
                 continue
             denc = self._mlp2d_bwd(sh["tape"], p + ".lfa.mlp2", sh["denc2"])
             o.axpy(1.0, sh["denc"], denc)
@@ -537,14 +537,23 @@ class RandlaTrainer(_ParamStore):
         off = np.concatenate([[0], np.cumsum(n[:L])]).astype(int)
         soff = np.concatenate([[0], np.cumsum(n[1:L + 1])]).astype(int)
         tape = RandlaTape()
+        # the per-level slices of the pyramid (strided views -> contiguous copies) are the same in every pass that shares ``shared``
+        # (the registration iterations of one step run on ONE pyramid): cut once, 16 copy kernels per pass less
+        pyr = None if shared is None else shared.get("_pyr")
+        if pyr is None:
+            pyr = {"xyz": [xyz_multi[:, off[l]:off[l + 1]].contiguous() for l in range(L)],
+                   "neigh": [neigh_idx[:, off[l]:off[l + 1]].contiguous() for l in range(L)],
+                   "sub": [sub_idx[:, soff[l]:soff[l + 1]].contiguous() for l in range(L)],
+                   "interp": [interp_idx[:, off[l]:off[l + 1], 0].contiguous() for l in range(L)]}
+            if shared is not None:
+                shared["_pyr"] = pyr
         x = self._mlp2d(tape, pf + ".mlp_pre", features.reshape(clouds * N, cin).contiguous(), clouds).reshape(clouds, N, -1)
         skips: List[torch.Tensor] = []
         args: List[torch.Tensor] = []
         for l in range(L):
             a, b = off[l], off[l + 1]
-            enc = self._res_block(tape, f"{pf}.dilated_res_blocks.{l}", x, xyz_multi[:, a:b].contiguous(), neigh_idx[:, a:b].contiguous(),
-                                  shared)
-            x, arg = o.maxpool_fwd(enc, sub_idx[:, soff[l]:soff[l + 1]].contiguous())                  # random_sample (:374-391)
+            enc = self._res_block(tape, f"{pf}.dilated_res_blocks.{l}", x, pyr["xyz"][l], pyr["neigh"][l], shared)
+            x, arg = o.maxpool_fwd(enc, pyr["sub"][l])                                                 # random_sample (:374-391)
             args.append(arg)
             if l == 0:
                 skips.append(enc)
@@ -554,7 +563,7 @@ class RandlaTrainer(_ParamStore):
         dec = []
         for j in range(L):
             a, b = off[L - j - 1], off[L - j]
-            ii = interp_idx[:, a:b, 0].contiguous()
+            ii = pyr["interp"][L - j - 1]
             sk = skips[-j - 2]
             cs, cu = sk.shape[2], x.shape[2]
             cat = o.empty(clouds * (b - a), cs + cu)
