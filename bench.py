@@ -19,8 +19,10 @@ Prints ONE JSON line on rank 0.
 from __future__ import annotations
 
 import argparse
-import json
 import os
+
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")   # before the GPU is touched: deepsir_amd/__init__.py
+import json
 import socket
 import subprocess
 import sys
@@ -56,6 +58,20 @@ def path_flops(n, n_iter):
         knn += 20.0 * lv * lv
         lv //= 4
     return 2 * R + n_iter * (2 * A + 131.0 * n * n + R + 40.0 * n) + knn
+
+
+class _StdoutToStderr:
+    """RCCL prints a version banner on STDOUT when its first communicator comes up; the driver wants ONE JSON line there."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
 
 
 def parse_args(argv=None):
@@ -246,15 +262,38 @@ def main():
     dev_index = local_rank % max(ndev, 1)      # rehearsing N ranks on fewer GPUs maps ranks round-robin
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist  # noqa: F811
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+    # The result gather is an RCCL all_gather at EVERY world size, N = 1 included (one rank gathering from itself runs the same
+    # library call path), so the communicator is created before any other GPU work - also when no launcher set the rendezvous up.
+    import torch.distributed as dist  # noqa: F811
+    dist_error = None
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if "MASTER_PORT" not in os.environ:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+    n_gpus = 1
+    with _StdoutToStderr():
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world)
+        except Exception as e:
+            if world > 1:
+                raise
+            dist_error = f"{type(e).__name__}: {e}"[:300]     # N = 1 can run without a communicator; the line says so
+            dist = None
+        # number of distinct GPUs in the job, from a collective (not from the environment) - also the communicator's first use
+        if dist is not None:
+            on = dev if dist.get_backend() == "nccl" else "cpu"
+            ids = [torch.zeros(1, dtype=torch.int64, device=on) for _ in range(world)]
+            dist.all_gather(ids, torch.tensor([dev_index], dtype=torch.int64, device=on))
+            ones = torch.ones(1, dtype=torch.int64, device=on)
+            dist.all_reduce(ones)
+            assert int(ones.item()) == world
+            n_gpus = len({int(t.item()) for t in ids})
+            torch.cuda.synchronize()
 
     from deepsir_amd.arch import NetConfig
     from deepsir_amd.dist import gather_results, shard_range, shard_sizes
@@ -303,17 +342,6 @@ def main():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-
-    # number of distinct GPUs in the job, from a collective (not from the environment)
-    n_gpus = 1
-    if dist is not None:
-        on = dev if dist.get_backend() == "nccl" else "cpu"
-        ids = [torch.zeros(1, dtype=torch.int64, device=on) for _ in range(world)]
-        dist.all_gather(ids, torch.tensor([dev_index], dtype=torch.int64, device=on))
-        ones = torch.ones(1, dtype=torch.int64, device=on)
-        dist.all_reduce(ones)
-        assert int(ones.item()) == world
-        n_gpus = len({int(t.item()) for t in ids})
 
     for _ in range(a.warmup):
         step()
@@ -365,7 +393,7 @@ def main():
     screened = sstats["screened_searches"] > 0
 
     # ------------------------------------------------------------------ rank-0 extras (outside the timed region)
-    model_only = single = single_ex = companion = latency = training = line_stress = None
+    model_only = single = single_ex = companion = latency = training = line_stress = concurrent_single = throughput_curve = config4 = None
     checks = []
     if a.timed_only:
         a.no_cpu_baseline = a.no_latency = a.no_companion = True
@@ -490,6 +518,76 @@ def main():
             latency = {"pairs_in_flight": 1, "ms_per_pair": round(ms, 4), "pairs_per_s": round(1e3 / ms, 2), "hipgraph": True,
                        "note": "the reference's own evaluation mode (test.py:56 BATCH_SIZE = 1, BASELINE configs[1] 'batch=1')"}
 
+        # K single-pair registrations in flight (deepsir_amd/serve.py): what a test.py-style caller that feeds one pair per call
+        # AHEAD of the results gets - requests coalesced into hipGraph-replayed batches of K / 2 on two engines in turn
+        if not a.no_latency and N <= 16384:
+            from deepsir_amd.serve import PairServer
+            serving = {}
+            for K_ in (2, 4, 8):
+                srv = PairServer(cfg, sd, dev_index, max_points=N, max_in_flight=K_, engines=2, n_iter=n_iter, want_aux=False)
+                nreq = min(L, 64)
+                reqs = [(src[i % L], ref[i % L]) for i in range(nreq)]
+                srv.run_closed_loop(reqs[: 2 * K_], K_)               # captures the graphs
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                res_ = srv.run_closed_loop(reqs, K_)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter() - t1
+                same = all(torch.equal(res_[i]["transforms"], out_buf["transforms"][i % L]) for i in range(nreq))
+                serving[f"K{K_}"] = {"pairs_in_flight": K_, "pairs_per_s": round(nreq / t1, 1), "requests": nreq,
+                                     "batches": srv.batches_dispatched, "equal_to_batched_results": bool(same)}
+                srv.close()
+            serving["note"] = ("closed loop: K single-pair requests outstanding, the next one submitted when the oldest result is collected; "
+                               "same bits as the batched path (equal_to_batched_results compares every pose with the timed run's)")
+            concurrent_single = serving
+            # pairs/s against pairs in flight: the same pool, P pairs per step (hipGraph replay up to 16 pairs per engine)
+            curve = {}
+            for p_ in (1, 2, 4, 8, 16, 32, 64, 128, 256):
+                if p_ > P:
+                    break
+                eng.enable_graph(p_ <= 32)
+                o_ = {"transforms": out_all[:p_]}
+                for _ in range(2):
+                    eng.register(src[:p_], ref[:p_], n_iter, want_aux=False, sync=False, out=o_)
+                eng.sync()
+                reps = 20 if p_ <= 8 else (8 if p_ <= 64 else 4)
+                t1 = time.perf_counter()
+                for _ in range(reps):
+                    eng.register(src[:p_], ref[:p_], n_iter, want_aux=False, sync=False, out=o_)
+                eng.sync()
+                curve[str(p_)] = round(p_ * reps / (time.perf_counter() - t1), 1)
+            eng.enable_graph(False)
+            throughput_curve = {"pairs_per_s_by_pairs_in_flight": curve,
+                                "note": f"one engine call of P pairs per step on the benchmarked pool ({S} streams: ceil(P / {S}) pairs per engine), "
+                                        "hipGraph replay up to 32 pairs per step; where a caller with B pairs per call lands between batch1_latency and `value`"}
+
+        # BASELINE configs[3] at N = 1: the 3DMatch test set's 1623 pairs as ONE rank's shard, walked in ragged engine calls
+        # (6 x 256 + 87), one padded all_gather per pass - the strong-scaling pass of --total-pairs on a single GPU
+        if not a.no_companion and not strong and N == 5000 and a.shape == "3dmatch" and not a.partial_overlap and P >= 64:
+            T4 = 1623
+            b4 = make_batch(N, [50_000 + i for i in range(T4)], cfg.feat_len, a.shape, False)
+            s4, r4 = torch.from_numpy(b4["points_src"]).to(dev), torch.from_numpy(b4["points_ref"]).to(dev)
+            o4 = torch.empty((T4, n_iter, 3, 4), dtype=torch.float32, device=dev)
+            calls4 = [(c0, min(c0 + P, T4)) for c0 in range(0, T4, P)]
+
+            def pass4():
+                for c0, c1 in calls4:
+                    eng.register(s4[c0:c1], r4[c0:c1], n_iter, want_aux=False, sync=False, out={"transforms": o4[c0:c1]})
+                eng.sync()
+                g4 = gather_results(o4, dist, sizes=[T4])
+                torch.cuda.synchronize()
+                return g4
+            pass4()
+            t1 = time.perf_counter()
+            for _ in range(2):
+                g4 = pass4()
+            t1 = (time.perf_counter() - t1) / 2
+            assert g4.shape[0] == T4 and torch.isfinite(g4).all()
+            config4 = {"total_pairs": T4, "engine_calls_per_pass": len(calls4), "pairs_per_s": round(T4 / t1, 1), "ms_per_pass": round(t1 * 1e3, 2),
+                       "note": "BASELINE configs[3] on one GPU: the 1623-pair set walked in engine calls of at most "
+                               f"{P} pairs (the last one ragged), results gathered once per pass; the 8-GPU form is bench.py --gpus 8 --total-pairs 1623"}
+            del s4, r4, o4, b4
+
         # the training step of the same pipeline, reported beside the headline, never as `value`
         if world == 1 and not a.no_latency and not a.no_companion and N <= 16384:
             try:
@@ -540,7 +638,7 @@ def main():
             "metric": "registered pairs/sec (5k-pt 3DMatch-shaped synthetic pairs, 5 registration iterations, KNN pyramid included)",
             "value": round(total_pairs / dt, 3), "unit": "pairs/s", "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32 (GEMMs as fp16-pair MFMA, fp32 accumulate; index decisions exact fp32)", "data": "synthetic",
             "config": {"workload": (f"{cname}: {wl}{', 50 % overlap crops + jitter' if a.partial_overlap else ''}, random SO(3)+t, raw clouds "
                                     f"resident in HBM -> (R,t) in HBM; THROUGHPUT mode: {P} pairs in flight per GPU per step on {S} HIP "
                                     f"streams ({P_launch} pairs per engine call) - the reference evaluates one pair at a time "
@@ -548,7 +646,9 @@ def main():
                        "points_per_cloud": N, "pairs_per_step_per_gpu": int(per_rank[0][0]), "pairs_in_flight_per_gpu": P, "streams_per_gpu": S,
                        "num_reg_iter": n_iter, "knn": 16, "world_size": world,
                        "weights": f"seeded random state-dict, variant '{variant}' (checkpoint not available)",
-                       "parallelism": f"pair-sharded x{world}, {'RCCL' if (dist is None or dist.get_backend() == 'nccl') else dist.get_backend() + ' (rehearsal)'} all_gather of results"},
+                       "parallelism": (f"pair-sharded x{world}, NO collective executed (process group not initialised: {dist_error})" if dist is None else
+                                       f"pair-sharded x{world}, {'RCCL' if dist.get_backend() == 'nccl' else dist.get_backend() + ' (rehearsal)'} "
+                                       f"all_gather of results (executed through a {world}-rank communicator; ranks[].gather_ms is its latency)")},
         }
         if strong:
             line["config"].update({"total_pairs": a.total_pairs, "pairs_per_engine_call": a.pairs,
@@ -663,6 +763,12 @@ def main():
             line["model_only"] = model_only
         if latency is not None:
             line["batch1_latency"] = latency
+        if concurrent_single is not None:
+            line["concurrent_single_pairs"] = concurrent_single
+        if throughput_curve is not None:
+            line["throughput_curve"] = throughput_curve
+        if config4 is not None:
+            line["config4_1623_pairs_n1"] = config4
         if training is not None:
             line["training_step"] = training
         if world == 1 and not a.no_cpu_baseline:

@@ -1,0 +1,32 @@
+"""MI355X-native registration engine behind the reference's ``network.model.Network`` interface."""
+import os as _os
+
+# hipGraph replay (include/dsir.h, dsir_enable_graph) on this ROCm: the runtime's "graph packet capture" fast path replays a
+# captured registration WRONGLY from its third launch on when the host has waited between launches (wrong poses, then GPU
+# memory faults: profiles/README.md, round 4; tools/graph_replay_check.py reproduces it).  The ROCclr flag below switches that
+# path off at no measurable cost (3.69 ms per single-pair replay either way).  The HIP runtime reads it when it INITIALISES,
+# so it has to be in the environment before the first GPU call of the process: importing this package before touching the GPU
+# is enough; ``graph_replay_safe()`` tells whether that held, and ``Engine.enable_graph`` refuses to capture when it did not.
+_FLAG = "DEBUG_CLR_GRAPH_PACKET_CAPTURE"
+_preset = _os.environ.get(_FLAG)
+_os.environ.setdefault(_FLAG, "0")
+
+
+def graph_replay_safe() -> bool:
+    """True when the flag above reached the HIP runtime: it was in the environment before this import, or the process had not
+    initialised the GPU yet when this package was imported."""
+    return _SAFE and _os.environ.get(_FLAG) == "0"
+
+
+def _gpu_untouched() -> bool:
+    import sys
+    t = sys.modules.get("torch")
+    if t is None:
+        return True
+    try:
+        return not t.cuda.is_initialized()
+    except Exception:
+        return True
+
+
+_SAFE = (_preset == "0") or _gpu_untouched()

@@ -103,6 +103,9 @@ SYMBOLS = {
     "dsir_screen_stats": (C.c_int, [C.c_void_p, C.c_int, c_i64_p]),
     "dsir_prune_stats": (C.c_int, [C.c_void_p, C.c_int, c_i64_p]),
     "dsir_set_prune_thresholds": (C.c_int, [C.c_void_p, C.c_int, C.c_int64]),
+    "dsir_set_kabsch_chunked_min": (C.c_int, [C.c_void_p, C.c_int]),
+    "dsir_set_tuning": (None, [C.c_int]),
+    "dsir_tuning": (C.c_int, []),
     "dsir_screen_bounds": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dsir_screen_cap": (C.c_int, []),

@@ -16,6 +16,20 @@
 
 using namespace dsir;
 
+// ------------------------------------------------------------------ the tuning gate
+// The ONLY place of the library that reads the environment.  Every DSIR_* measurement / A-B switch goes through
+// tuning_env(); unless the gate is open - DSIR_TUNING=1 in the environment, or dsir_set_tuning(1) before the first call
+// that reads a switch (most are read once into function-static state) - the library ignores every DSIR_* variable, so a
+// stray one in a user's environment cannot change kernel selection.
+static int g_tuning = -1;     // -1: not decided yet, 0: closed, 1: open
+const char* dsir::tuning_env(const char* name) {
+  if (g_tuning < 0) {
+    const char* e = getenv("DSIR_TUNING");
+    g_tuning = (e && e[0] == '1' && e[1] == 0) ? 1 : 0;
+  }
+  return g_tuning == 1 ? getenv(name) : nullptr;
+}
+
 namespace {
 
 thread_local std::string g_create_error;
@@ -31,7 +45,7 @@ struct HostParam {
 };
 
 struct Mlp2dW { const float *W = nullptr, *b = nullptr, *gamma = nullptr, *beta = nullptr; int cin = 0, cout = 0, groups = 0; };
-struct AttW { const float* fc = nullptr; const float* fc_g = nullptr; int d = 0; Mlp2dW mlp; };   // fc_g: see up_fc_g
+struct AttW { const float* fc = nullptr; const float* fc_g = nullptr; const float* fc_p = nullptr; int d = 0; Mlp2dW mlp; };   // fc_g: up_fc_g, fc_p: up_fc_p
 struct BlockW { Mlp2dW mlp1, lfa1, lfa2, mlp2, skip; AttW att1, att2; int d_in = 0, d = 0; };
 struct LinW { const float *W = nullptr, *b = nullptr; int cin = 0, cout = 0; };
 struct RandlaW { Mlp2dW pre; BlockW blk[4]; Mlp2dW mid; Mlp2dW dec[4]; const float* out_w = nullptr; int dec_out = 0; LinW fc[3]; int cin = 0, ncls = 0;
@@ -100,8 +114,15 @@ struct dsir_ctx {
   bool time_match = false;
   // hipGraph replay of dsir_register (launch-bound small batches)
   bool use_graph = false;
-  hipGraphExec_t graph_exec = nullptr;
-  std::vector<unsigned char> graph_key;
+  // captured registrations, one per distinct call signature (sizes AND buffer addresses): a server that batches 1 .. K
+  // single-pair requests into one call replays K graphs in turn (deepsir_amd/serve.py); the oldest is evicted beyond kMaxGraphs
+  struct Graph { std::vector<unsigned char> key; hipGraphExec_t exec; };
+  std::vector<Graph> graphs;
+  static constexpr size_t kMaxGraphs = 16;
+  void drop_graphs() {
+    for (auto& g : graphs) hipGraphExecDestroy(g.exec);
+    graphs.clear();
+  }
   struct MatchEvents { hipEvent_t op0, op1, k0, k1; };   // whole operation / its dominant kernel alone
   std::vector<MatchEvents> match_events;
   size_t match_events_used = 0;
@@ -113,6 +134,7 @@ struct dsir_ctx {
   long long prune_min_rows = 65536;     // ... in launches of that many src rows (pairs x points) and more
   // aggregation chain: 1 = fp16-split products on the fp16 matrix pipe (agg_chain_h.hip), 0 = exact-fp32 chain (agg_chain.hip)
   int agg_split = 1;
+  int kabsch_chunked_min = 0;           // clouds of that many points and more solve their pose in chunks; 0 = kKabschChunkedMin
   // device-clock brackets {first wave start, last wave end} of the timed nn_match launches
   unsigned long long* match_ts = nullptr;    // [kMatchSlots][2]
   size_t match_ts_used = 0;
@@ -290,9 +312,23 @@ size_t up_fc_g(Uploader& u, const HostParam& fc, int d) {
   return u.put(w);
 }
 
+// att_pool.hip (d = 64, 128): the per-point GEMM in front of the pooling writes ONE row per point, [ G = W1 fN (d columns, natural
+// order) | fN (d/2 columns) ]: its weight matrix is W1 = fc[:, :d/2] with an identity block underneath.  fN x 1.0 + zeros is
+// exact in the fp32 MFMA, so the second part is the normalised feature itself - the pooling kernel then gathers scores and
+// features of a neighbour through one address.
+size_t up_fc_p(Uploader& u, const HostParam& fc, int d) {
+  if (d != 64 && d != 128) return 0;
+  const int h = d / 2;
+  std::vector<float> w((size_t)(d + h) * h, 0.f);
+  for (int r = 0; r < d; ++r)
+    for (int k = 0; k < h; ++k) w[(size_t)r * h + k] = fc.data[(size_t)r * d + k];
+  for (int k = 0; k < h; ++k) w[(size_t)(d + k) * h + k] = 1.f;
+  return u.put(w);
+}
+
 struct RandlaOff {
   Mlp2dOff pre, mid, dec[4];
-  struct { Mlp2dOff mlp1, lfa1, lfa2, mlp2, skip, a1m, a2m; size_t fc1, fc2, fc1g, fc2g; } blk[4];
+  struct { Mlp2dOff mlp1, lfa1, lfa2, mlp2, skip, a1m, a2m; size_t fc1, fc2, fc1g, fc2g, fc1p, fc2p; } blk[4];
   size_t out_w; int dec_out;
   LinOff fc[3];
 };
@@ -305,10 +341,12 @@ RandlaOff up_randla(dsir_ctx* c, Uploader& u, const std::string& pre) {
     r.blk[i].lfa1 = up_mlp2d(c, u, p + ".lfa.mlp1");
     r.blk[i].fc1 = u.put(P(c, p + ".lfa.att_pooling_1.fc.weight").data);
     r.blk[i].fc1g = up_fc_g(u, P(c, p + ".lfa.att_pooling_1.fc.weight"), c->cfg.d_out[i]);
+    r.blk[i].fc1p = up_fc_p(u, P(c, p + ".lfa.att_pooling_1.fc.weight"), c->cfg.d_out[i]);
     r.blk[i].a1m = up_mlp2d(c, u, p + ".lfa.att_pooling_1.mlp");
     r.blk[i].lfa2 = up_mlp2d(c, u, p + ".lfa.mlp2");
     r.blk[i].fc2 = u.put(P(c, p + ".lfa.att_pooling_2.fc.weight").data);
     r.blk[i].fc2g = up_fc_g(u, P(c, p + ".lfa.att_pooling_2.fc.weight"), c->cfg.d_out[i]);
+    r.blk[i].fc2p = up_fc_p(u, P(c, p + ".lfa.att_pooling_2.fc.weight"), c->cfg.d_out[i]);
     r.blk[i].a2m = up_mlp2d(c, u, p + ".lfa.att_pooling_2.mlp");
     r.blk[i].mlp2 = up_mlp2d(c, u, p + ".mlp2");
     r.blk[i].skip = up_mlp2d(c, u, p + ".mlp_skip");
@@ -335,6 +373,9 @@ RandlaW bind_randla(const float* base, const RandlaOff& o, const dsir_cfg& g) {
     b.att2.fc = base + o.blk[i].fc2; b.att2.d = g.d_out[i]; b.att2.mlp = bind_mlp2d(base, o.blk[i].a2m);
     b.att1.fc_g = g.d_out[i] >= 64 ? base + o.blk[i].fc1g : nullptr;
     b.att2.fc_g = g.d_out[i] >= 64 ? base + o.blk[i].fc2g : nullptr;
+    const bool pooled = g.d_out[i] == 64 || g.d_out[i] == 128;
+    b.att1.fc_p = pooled ? base + o.blk[i].fc1p : nullptr;
+    b.att2.fc_p = pooled ? base + o.blk[i].fc2p : nullptr;
     b.d = g.d_out[i]; b.d_in = b.mlp1.cin;
   }
   r.mid = bind_mlp2d(base, o.mid);
@@ -345,6 +386,12 @@ RandlaW bind_randla(const float* base, const RandlaOff& o, const dsir_cfg& g) {
   return r;
 }
 
+// A/B switch: DSIR_NO_ATT_POOL = the round-3 EPI_ATT2 kernels (pw_stream.hip) for d = 64 / 128 instead of att_pool.hip
+bool att_pool_enabled() {
+  static const bool off = tuning_flag("DSIR_NO_ATT_POOL");
+  return !off;
+}
+
 // ------------------------------------------------------------------ schedule helpers
 struct Sched {
   dsir_ctx* c;
@@ -353,7 +400,7 @@ struct Sched {
 
   double* stats_slot(int groups) {
     double* p = c->stats + c->stats_top;
-    c->stats_top += (size_t)clouds * groups * 2;
+    c->stats_top += (size_t)clouds * groups * kGnWords;
     return p;
   }
   // the fp16 split of a weight matrix inside the context's blob (dsir_finalize_weights); off unless the split layers are on
@@ -409,7 +456,26 @@ struct Sched {
     Act y;
     y.p = c->ws.get<float>((size_t)clouds * n * w.d);
     y.C = w.d; y.rows = n;
-    static const bool no_att2 = getenv("DSIR_NO_ATT2") != nullptr;   // A/B switch
+    static const bool no_att2 = tuning_flag("DSIR_NO_ATT2");   // A/B switch
+    if (!no_att2 && att_pool_enabled() && w.fc_p && c->dweights16 && f.C * 2 == w.d && enc.C * 2 == w.d && !(s2 && s2_mode)) {
+      // att_pool.hip: gp = [W1 fN | fN] per point (exact-fp32 MFMA GEMM), then two points per wave with the softmax in registers
+      const int h = w.d / 2;
+      float* gp = c->ws.get<float>((size_t)clouds * n * 3 * h);
+      if (c->ws.overflow) return y;
+      GemmArgs g;
+      g.amode = A_SEGS; g.nseg = 1; g.seg[0] = seg_of(f);
+      g.W = w.fc_p; g.ldw = h; g.bias = nullptr; g.Cin = h; g.Cout = 3 * h; g.M = n; g.clouds = clouds;
+      g.epi = EPI_LINEAR; g.Y = gp; g.y_cloud_stride = (int64_t)n * 3 * h; g.ldy = 3 * h;
+      if (launch_pw_stream(g, st)) {
+        AttPoolArgs a;
+        a.enc = enc.p; a.enc_cs = (int64_t)enc.rows * enc.C; a.enc_gn = enc.gn; a.enc_act = enc.act;
+        a.gp = gp; a.gp_cs = (int64_t)n * 3 * h; a.neigh = neigh; a.neigh_cs = neigh_cs;
+        const size_t off = (size_t)(w.fc - c->dweights);
+        a.Wh = c->dweights16 + off; a.Wl = c->dweights16 + c->nweights + off; a.ldw = w.d; a.wcol0 = h;
+        a.Y = y.p; a.y_cs = (int64_t)n * w.d; a.n = n; a.clouds = clouds; a.KH = h;
+        if (launch_att_pool(a, st)) return y;
+      }
+    }
     if (!no_att2 && w.d >= 64 && w.fc_g && f.C * 2 == w.d && enc.C * 2 == w.d) {   // d = 16: the extra gathers cost more than the MFMAs saved
       // score GEMM split by linearity: fc [gather(f); enc] = gather(W1 f) + W2 enc  (kernels.h, EPI_ATT2).
       // G = W1 f runs on n rows instead of 16 n; the pooling launch contracts only the enc half.
@@ -485,8 +551,8 @@ int randla_forward(dsir_ctx* c, const RandlaW& w, const Seg& in0, const Seg* in1
   const int L = g.num_layers;
   hipStream_t st = c->stream;
   Sched s{c, st, py.clouds};
-  // 34 GroupNorm layers x clouds x <=8 groups x 2 doubles
-  const size_t stats_need = (size_t)40 * py.clouds * 16;
+  // 34 GroupNorm layers x clouds x <=8 groups x kGnWords words
+  const size_t stats_need = (size_t)40 * py.clouds * 8 * kGnWords;
   if (c->stats_prezeroed && c->stats_base + stats_need <= c->stats_cap) {
     c->stats_top = c->stats_base;               // zeroed by register_enqueue together with the other passes' regions
     c->stats_base += stats_need;
@@ -552,7 +618,7 @@ int randla_forward(dsir_ctx* c, const RandlaW& w, const Seg& in0, const Seg* in1
   }
   const int n0 = py.nl[0];
   bool fused = false;
-  static const bool no_head = getenv("DSIR_NO_HEAD") != nullptr;   // A/B switch
+  static const bool no_head = tuning_flag("DSIR_NO_HEAD");   // A/B switch
   if (logits_out && !no_head &&w.dec_out == 32 && g.out_feat_dim == 64 && w.fc[0].cout == 64 && w.fc[1].cout == 32) {
     // mlp_out + fc_label in one launch (head_mlp.hip); bit-identical to the four launches below
     HeadArgs h;
@@ -595,7 +661,7 @@ void run_att_proj(dsir_ctx* c, const float* xyz, int64_t xyz_cs, const float* sc
                   float* desc) {
   Sched s{c, c->stream, clouds};
   const NetW& w = c->net;
-  static const bool no_agg = getenv("DSIR_NO_AGG") != nullptr;   // A/B switch
+  static const bool no_agg = tuning_flag("DSIR_NO_AGG");   // A/B switch
   const LinW* m = w.mlp_att;
   if (!no_agg && m[0].cin == 4 && m[0].cout == 32 && m[1].cout == 64 && m[2].cout == 128 && m[3].cout == 256 &&
       m[4].cout == 64 && w.mlp_proj.cin == 64 && w.mlp_proj.cout == 64) {
@@ -635,10 +701,10 @@ int build_pyramid(dsir_ctx* c, const float* points, int stride, int clouds, int 
   for (int l = 0; l <= g.num_layers; ++l) { lv.nl[l] = p.nl[l]; lv.off[l] = p.off[l]; lv.soff[l] = p.soff[l]; }
   // every level's points are a prefix of the level above, hence of the input cloud (data_base.py:166-172): one launch for all
   launch_copy_xyz_levels(points, (int64_t)n * stride, stride, lv, clouds, xyz, xyz_cs, st);
-  static const bool no_grid = getenv("DSIR_NO_GRID") != nullptr;   // A/B switch
-  static const int grid_min = getenv("DSIR_GRID_MIN") ? atoi(getenv("DSIR_GRID_MIN")) : 1024;   // tuning hook
-  static const bool no_nn1_grid = getenv("DSIR_NO_NN1_GRID") != nullptr;   // A/B switch: brute-force interpolation search throughout
-  static const long long nn1_grid_min = getenv("DSIR_NN1_GRID_MIN") ? atoll(getenv("DSIR_NN1_GRID_MIN")) : 65536;   // tuning hook
+  static const bool no_grid = tuning_flag("DSIR_NO_GRID");   // A/B switch
+  static const int grid_min = (int)tuning_int("DSIR_GRID_MIN", 1024);   // tuning hook
+  static const bool no_nn1_grid = tuning_flag("DSIR_NO_NN1_GRID");   // A/B switch: brute-force interpolation search throughout
+  static const long long nn1_grid_min = tuning_int("DSIR_NN1_GRID_MIN", 65536);   // tuning hook
   // interpolation search of level l (support = level l + 1) through level l + 1's grid: when that level has one and the launch has
   // queries enough to fill the chip with one lane per query (same bits either way)
   auto nn1_by_grid = [&](int l) {
@@ -713,10 +779,10 @@ int dsir_create(int device, const dsir_cfg* cfg, dsir_ctx** out) {
   if (device < 0 || device >= ndev) return fail(nullptr, "device %d out of range (%d devices)", device, ndev);
   dsir_ctx* c = new dsir_ctx();
   c->device = device; c->cfg = *cfg;
-  c->screen_mode = getenv("DSIR_NO_SCREEN") ? 0 : 1;
-  if (const char* e = getenv("DSIR_PRUNE_MIN_K")) c->prune_min_points = atoi(e) > 0 ? atoi(e) : 0;   // A/B hook; 0 = off
-  if (const char* e = getenv("DSIR_PRUNE_MIN_ROWS")) c->prune_min_rows = atoll(e) > 0 ? atoll(e) : 0;   // tuning hook
-  c->agg_split = getenv("DSIR_AGG_F32") ? 0 : 1;
+  c->screen_mode = tuning_flag("DSIR_NO_SCREEN") ? 0 : 1;
+  if (const char* e = tuning_env("DSIR_PRUNE_MIN_K")) c->prune_min_points = atoi(e) > 0 ? atoi(e) : 0;   // A/B hook; 0 = off
+  if (const char* e = tuning_env("DSIR_PRUNE_MIN_ROWS")) c->prune_min_rows = atoll(e) > 0 ? atoll(e) : 0;   // tuning hook
+  c->agg_split = tuning_flag("DSIR_AGG_F32") ? 0 : 1;
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
     delete c;
     return fail(nullptr, "cannot initialise device %d", device);
@@ -750,7 +816,7 @@ int dsir_create(int device, const dsir_cfg* cfg, dsir_ctx** out) {
     delete c;
     return fail(nullptr, "cannot allocate %zu MiB of workspace", cap >> 20);
   }
-  c->stats_cap = (size_t)40 * clouds * 16 * 6;   // one registration's passes side by side: (2 + n_iter) P clouds for n_iter <= 10
+  c->stats_cap = (size_t)40 * clouds * 8 * kGnWords * 6;   // one registration's passes side by side: (2 + n_iter) P clouds for n_iter <= 10
   if (hipMalloc((void**)&c->stats, c->stats_cap * sizeof(double)) != hipSuccess) {
     hipFree(c->ws.base); hipStreamDestroy(c->stream);
     delete c;
@@ -771,7 +837,7 @@ void dsir_destroy(dsir_ctx* c) {
   hipSetDevice(c->device);
   hipStreamSynchronize(c->stream);
   for (auto& e : c->match_events) { hipEventDestroy(e.op0); hipEventDestroy(e.op1); hipEventDestroy(e.k0); hipEventDestroy(e.k1); }
-  if (c->graph_exec) hipGraphExecDestroy(c->graph_exec);
+  c->drop_graphs();
   if (c->dweights) hipFree(c->dweights);
   if (c->dweights16) hipFree(c->dweights16);
   if (c->match_ts) hipFree(c->match_ts);
@@ -782,15 +848,34 @@ void dsir_destroy(dsir_ctx* c) {
   delete c;
 }
 
+void dsir_set_tuning(int on) { g_tuning = on ? 1 : 0; }
+int dsir_tuning(void) { tuning_env("DSIR_TUNING"); return g_tuning == 1; }
+
 const char* dsir_last_error(const dsir_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
 void* dsir_stream(dsir_ctx* c) { return c ? (void*)c->stream : nullptr; }
 int dsir_set_stream(dsir_ctx* c, void* stream, int restore_own) {
   if (!c) return 1;
   HIP_OK(c, hipSetDevice(c->device));
-  // work already enqueued stays ordered on the stream it was enqueued on; a captured registration belongs to the old stream
-  if (c->graph_exec) { hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
-  c->graph_key.clear();
-  c->stream = restore_own ? c->own_stream : (hipStream_t)stream;     // NULL is a valid caller stream: the legacy default stream
+  hipStream_t next = restore_own ? c->own_stream : (hipStream_t)stream;     // NULL is a valid caller stream: the legacy default stream
+  if (next == c->stream) return 0;
+  // Every call of a context re-uses its ONE workspace arena from the start: launches on the new stream must not overtake work
+  // still running on the old one.  The new stream therefore waits (on the device, no host synchronisation) for everything
+  // enqueued on the old stream so far.  Exception: a stream under capture cannot wait on outside work - whoever captures
+  // synchronises before the capture begins (torch.cuda.graph does).
+  hipStreamCaptureStatus cap_new = hipStreamCaptureStatusNone, cap_old = hipStreamCaptureStatusNone;
+  hipStreamIsCapturing(next, &cap_new);
+  hipStreamIsCapturing(c->stream, &cap_old);
+  if (cap_new == hipStreamCaptureStatusNone && cap_old == hipStreamCaptureStatusNone) {
+    hipEvent_t ev = nullptr;
+    HIP_OK(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    hipError_t e = hipEventRecord(ev, c->stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(next, ev, 0);
+    hipEventDestroy(ev);
+    if (e != hipSuccess) return fail(c, "dsir_set_stream: ordering the new stream after the old one failed: %s", hipGetErrorString(e));
+  }
+  // a captured registration belongs to the old stream
+  c->drop_graphs();
+  c->stream = next;
   return 0;
 }
 int dsir_sync(dsir_ctx* c) {
@@ -840,8 +925,7 @@ int dsir_finalize_weights(dsir_ctx* c) {
   HIP_OK(c, hipSetDevice(c->device));
   HIP_OK(c, hipStreamSynchronize(c->stream));
   // a captured registration holds the addresses of the old weight blob: drop it, the next call re-captures
-  if (c->graph_exec) { hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
-  c->graph_key.clear();
+  c->drop_graphs();
   if (c->dweights) { hipFree(c->dweights); c->dweights = nullptr; }
   HIP_OK(c, hipMalloc((void**)&c->dweights, u.blob.size() * sizeof(float)));
   HIP_OK(c, hipMemcpy(c->dweights, u.blob.data(), u.blob.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -1026,7 +1110,8 @@ int dsir_kabsch(dsir_ctx* c, const float* src, const float* tgt, const float* w,
   KabschArgs a{};
   a.src = src; a.ref = tgt; a.idx = nullptr; a.w = w; a.src_stride = (int64_t)m * 3; a.ref_stride = (int64_t)m * 3;
   a.sigmoid = 0; a.pairs = pairs; a.m = m; a.T = T; a.invalid = invalid;
-  if (const size_t pb = kabsch_part_bytes(pairs, m)) {      // large clouds: the chunked reduction of dsir_register (kabsch.hip)
+  a.chunk_min = c->kabsch_chunked_min;
+  if (const size_t pb = kabsch_part_bytes(pairs, m, c->kabsch_chunked_min)) {      // large clouds: the chunked reduction of dsir_register (kabsch.hip)
     c->ws.top = 0; c->ws.overflow = false;
     a.part = c->ws.get<double>(pb / sizeof(double));
     if (c->ws.overflow) return fail(c, "dsir_kabsch: workspace exhausted");
@@ -1157,7 +1242,7 @@ static int register_enqueue(dsir_ctx* c, const dsir_pair_batch* in, int n_iter, 
   // memset instead of one per pass (a launch each: 22 us of a 3.6 ms single-pair registration)
   struct StatsGuard { dsir_ctx* c; ~StatsGuard() { c->stats_prezeroed = false; c->stats_base = 0; } } stats_guard{c};
   {
-    const size_t total = (size_t)40 * 16 * ((size_t)2 * P + (size_t)n_iter * P);
+    const size_t total = (size_t)40 * 8 * kGnWords * ((size_t)2 * P + (size_t)n_iter * P);
     if (total <= c->stats_cap) {
       HIP_OK(c, hipMemsetAsync(c->stats, 0, total * sizeof(double), st));
       c->stats_prezeroed = true;
@@ -1182,7 +1267,7 @@ static int register_enqueue(dsir_ctx* c, const dsir_pair_batch* in, int n_iter, 
   // both paths return the same bits, so the choice is free: small problems (latency-bound, e.g. one pair in flight) take
   // the single exhaustive kernel, large ones the three-kernel screened path.  dsir_enable_screen / DSIR_NO_SCREEN: A/B
   // switch to the exhaustive fp32 kernel throughout
-  static const long long screen_min = getenv("DSIR_SCREEN_MIN_WORK") ? atoll(getenv("DSIR_SCREEN_MIN_WORK")) : 200000000ll;   // A/B hook
+  static const long long screen_min = tuning_int("DSIR_SCREEN_MIN_WORK", 200000000ll);   // A/B hook
   const bool screen = c->screen_mode && !in->forced_idx && (int64_t)P * J * K >= screen_min;
   void *sc_ah = nullptr, *sc_al = nullptr, *sc_bh = nullptr, *sc_bl = nullptr, *sc_scratch = nullptr;
   float *sc_sa = nullptr, *sc_sb = nullptr;
@@ -1199,10 +1284,11 @@ static int register_enqueue(dsir_ctx* c, const dsir_pair_batch* in, int n_iter, 
                      nn_prune_supported(P, J, K);
   void* pr_scratch = prune ? ws.raw(nn_prune_scratch_bytes(P, J, K)) : nullptr;
   // chunk partials of the pose solve on large clouds (kabsch.hip)
-  double* kab_part = kabsch_part_bytes(P, J) ? ws.get<double>(kabsch_part_bytes(P, J) / sizeof(double)) : nullptr;
+  const size_t kab_bytes = kabsch_part_bytes(P, J, c->kabsch_chunked_min);
+  double* kab_part = kab_bytes ? ws.get<double>(kab_bytes / sizeof(double)) : nullptr;
   // persistent storage of the inlier model's position-encoding branch (EncCache), alive across the iterations
   EncCache enc_cache;
-  static const bool no_hoist = getenv("DSIR_NO_HOIST") != nullptr;   // A/B switch
+  static const bool no_hoist = tuning_flag("DSIR_NO_HOIST");   // A/B switch
   const bool hoist = !no_hoist && n_iter > 1;
   if (hoist) {
     size_t nstats = 0;
@@ -1210,25 +1296,25 @@ static int register_enqueue(dsir_ctx* c, const dsir_pair_batch* in, int n_iter, 
       const size_t rows = (size_t)P * ps.nl[l] * kKnn, ch = (size_t)g.d_out[l] / 2;
       enc_cache.enc_buf[l] = ws.get<float>(rows * ch);
       enc_cache.enc2_buf[l] = ws.get<float>(rows * ch);
-      static const bool no_s2 = getenv("DSIR_NO_S2") != nullptr;   // A/B switch: recompute the enc half of the scores every iteration
+      static const bool no_s2 = tuning_flag("DSIR_NO_S2");   // A/B switch: recompute the enc half of the scores every iteration
       // level 1 (d = 64: a 32-channel contraction) caches its score halves only for a few pairs in flight: with the chip full
       // re-reading 64 floats per row costs more HBM time than contracting 32 (same bits either way; +1.9 % pairs/s at 128
       // pairs per launch, -0.02 ms of single-pair latency with the cache)
-      static const int s2_min_d = getenv("DSIR_S2_MIN_D") ? atoi(getenv("DSIR_S2_MIN_D")) : 0;   // tuning hook: 0 = by launch size
+      static const int s2_min_d = (int)tuning_int("DSIR_S2_MIN_D", 0);   // tuning hook: 0 = by launch size
       // round 3: with the score contraction on the fp16 pipe, re-reading level 2's halves (2 x 5000 x 128 floats per cloud) also
       // costs more than contracting them when the chip is full: only level 3 keeps its cache there (+0.7 % pairs/s; 64: -0.7 %)
-      const int min_d = s2_min_d > 0 ? s2_min_d : (P <= 4 ? 64 : 256);
+      const int min_d = s2_min_d > 0 ? s2_min_d : ((P <= 4 && !att_pool_enabled()) ? 64 : 256);   // att_pool.hip (d = 64, 128) keeps no score cache
       if (g.d_out[l] >= 64 && g.d_out[l] >= min_d && !no_s2) {
         enc_cache.s2_buf[l][0] = ws.get<float>(rows * (size_t)g.d_out[l]);
         enc_cache.s2_buf[l][1] = ws.get<float>(rows * (size_t)g.d_out[l]);
       }
-      nstats += 2 * (size_t)P * 16;
+      nstats += 2 * (size_t)P * 8 * kGnWords;
     }
     double* cst = ws.get<double>(nstats);
     if (!ws.overflow) HIP_OK(c, hipMemsetAsync(cst, 0, nstats * sizeof(double), st));
     for (int l = 0; l < g.num_layers; ++l) {
-      enc_cache.enc_stats[l] = cst + (size_t)(2 * l) * P * 16;
-      enc_cache.enc2_stats[l] = cst + (size_t)(2 * l + 1) * P * 16;
+      enc_cache.enc_stats[l] = cst + (size_t)(2 * l) * P * 8 * kGnWords;
+      enc_cache.enc2_stats[l] = cst + (size_t)(2 * l + 1) * P * 8 * kGnWords;
     }
   }
   if (ws.overflow) return fail(c, "workspace exhausted (raise max_points / max_pairs)");
@@ -1298,7 +1384,7 @@ static int register_enqueue(dsir_ctx* c, const dsir_pair_batch* in, int n_iter, 
     a.T_cum = out->transforms + (size_t)it * 12; a.T_prev = it ? out->transforms + (size_t)(it - 1) * 12 : nullptr;
     a.T_stride = (int64_t)n_iter * 12;
     a.matched_out = (it == n_iter - 1) ? out->pt_ref_new : nullptr;
-    a.part = kab_part;
+    a.part = kab_part; a.chunk_min = c->kabsch_chunked_min;
     launch_kabsch(a, st);
   }
   if (c->ws.overflow) return fail(c, "workspace exhausted (raise max_points / max_pairs in dsir_cfg)");
@@ -1320,8 +1406,10 @@ int dsir_register(dsir_ctx* c, const dsir_pair_batch* in, int n_iter, const dsir
   std::memcpy(key.data(), in, sizeof(*in));
   std::memcpy(key.data() + sizeof(*in), out, sizeof(*out));
   std::memcpy(key.data() + sizeof(*in) + sizeof(*out), &n_iter, sizeof(int));
-  if (!c->graph_exec || key != c->graph_key) {
-    if (c->graph_exec) { hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
+  hipGraphExec_t exec = nullptr;
+  for (auto& g : c->graphs)
+    if (g.key == key) { exec = g.exec; break; }
+  if (!exec) {
     HIP_OK(c, hipStreamSynchronize(c->stream));
     HIP_OK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
     const int rc = register_enqueue(c, in, n_iter, out);
@@ -1329,12 +1417,17 @@ int dsir_register(dsir_ctx* c, const dsir_pair_batch* in, int n_iter, const dsir
     const hipError_t e = hipStreamEndCapture(c->stream, &graph);
     if (rc != 0) { if (graph) hipGraphDestroy(graph); return rc; }
     if (e != hipSuccess || !graph) return fail(c, "hipStreamEndCapture: %s", hipGetErrorString(e));
-    const hipError_t e2 = hipGraphInstantiate(&c->graph_exec, graph, nullptr, nullptr, 0);
+    const hipError_t e2 = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
     hipGraphDestroy(graph);
-    if (e2 != hipSuccess) { c->graph_exec = nullptr; return fail(c, "hipGraphInstantiate: %s", hipGetErrorString(e2)); }
-    c->graph_key = key;
+    if (e2 != hipSuccess) return fail(c, "hipGraphInstantiate: %s", hipGetErrorString(e2));
+    if (c->graphs.size() >= dsir_ctx::kMaxGraphs) {
+      HIP_OK(c, hipStreamSynchronize(c->stream));     // the evicted graph may still be replaying
+      hipGraphExecDestroy(c->graphs.front().exec);
+      c->graphs.erase(c->graphs.begin());
+    }
+    c->graphs.push_back({key, exec});
   }
-  HIP_OK(c, hipGraphLaunch(c->graph_exec, c->stream));
+  HIP_OK(c, hipGraphLaunch(exec, c->stream));
   return post(c);
 }
 
@@ -1467,7 +1560,7 @@ int dsir_align_loss_backward(dsir_ctx* c, const float* pt_src, const float* pt_r
 int dsir_enable_graph(dsir_ctx* c, int enable) {
   if (!c) return 1;
   c->use_graph = enable != 0;
-  if (!c->use_graph && c->graph_exec) { hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; c->graph_key.clear(); }
+  if (!c->use_graph) c->drop_graphs();
   return 0;
 }
 
@@ -1623,8 +1716,7 @@ int dsir_enable_agg_split(dsir_ctx* c, int enable) {
   if (!c) return 1;
   c->agg_split = enable != 0;
   // a captured registration has the choice baked in
-  if (c->graph_exec) { hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
-  c->graph_key.clear();
+  c->drop_graphs();
   return 0;
 }
 
@@ -1633,8 +1725,15 @@ int dsir_set_prune_thresholds(dsir_ctx* c, int min_points, int64_t min_rows) {
   c->prune_min_points = min_points > 0 ? min_points : 0;
   c->prune_min_rows = min_rows > 0 ? min_rows : 0;
   // a captured registration has the choice baked in
-  if (c->graph_exec) { hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
-  c->graph_key.clear();
+  c->drop_graphs();
+  return 0;
+}
+
+int dsir_set_kabsch_chunked_min(dsir_ctx* c, int min_points) {
+  if (!c) return 1;
+  c->kabsch_chunked_min = min_points > 0 ? min_points : 0;
+  // a captured registration has the choice baked in
+  c->drop_graphs();
   return 0;
 }
 
@@ -1642,8 +1741,7 @@ int dsir_enable_screen(dsir_ctx* c, int enable) {
   if (!c) return 1;
   c->screen_mode = enable != 0;
   // a captured registration has the choice baked in
-  if (c->graph_exec) { hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
-  c->graph_key.clear();
+  c->drop_graphs();
   return 0;
 }
 

@@ -60,9 +60,9 @@ __global__ __launch_bounds__(256) void head_mlp_kernel(const HeadArgs p) {
     const Seg& s = p.in;
     if (s.gn.stats) {
       const int g = tid / (32 / s.gn.groups);
-      const double* st = s.gn.stats + ((int64_t)cloud * s.gn.groups + g) * 2;
-      const double mean = st[0] * s.gn.inv_count;
-      double var = st[1] * s.gn.inv_count - mean * mean;
+      const double* st = s.gn.stats + ((int64_t)cloud * s.gn.groups + g) * kGnWords;
+      const double mean = gn_stat_get(st) * s.gn.inv_count;
+      double var = gn_stat_get(st + 2) * s.gn.inv_count - mean * mean;
       var = var > 0.0 ? var : 0.0;
       const double rstd = 1.0 / sqrt(var + 1e-5);
       const double scd = (double)s.gn.gamma[tid] * rstd;

@@ -349,19 +349,16 @@ __global__ __launch_bounds__(256) void kabsch_apply_kernel(const KabschArgs a) {
 
 }  // namespace
 
-// clouds of that many points and more take the chunked path; DSIR_KABSCH_CHUNKED_MIN (read per call: a test switches it) moves it
-static int chunked_min() {
-  const char* e = getenv("DSIR_KABSCH_CHUNKED_MIN");
-  return e ? atoi(e) : kKabschChunkedMin;
-}
+// clouds of that many points and more take the chunked path (dsir_set_kabsch_chunked_min moves the threshold of a context)
+static int chunked_min(int chunk_min) { return chunk_min > 0 ? chunk_min : kKabschChunkedMin; }
 
-size_t kabsch_part_bytes(int pairs, int m) {
-  return m >= chunked_min() ? (size_t)pairs * ((m + CHUNK - 1) / CHUNK) * 16 * sizeof(double) : 0;
+size_t kabsch_part_bytes(int pairs, int m, int chunk_min) {
+  return m >= chunked_min(chunk_min) ? (size_t)pairs * ((m + CHUNK - 1) / CHUNK) * 16 * sizeof(double) : 0;
 }
 
 void launch_kabsch(const KabschArgs& a, hipStream_t st) {
   if (a.pairs <= 0) return;
-  if (a.part && a.m >= chunked_min()) {
+  if (a.part && a.m >= chunked_min(a.chunk_min)) {
     // the choice depends on the cloud size alone: a pair's pose does not depend on what else is in the batch
     const int nch = (a.m + CHUNK - 1) / CHUNK;
     const dim3 grid(nch, a.pairs);

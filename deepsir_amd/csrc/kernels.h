@@ -2,15 +2,26 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace dsir {
 
 constexpr int kKnn = 16;  // neighbours per point (args.num_knn; one MFMA row tile)
 
+// Measurement / A-B switches (DSIR_* environment variables) are read through ONE gate (engine.hip): nullptr unless the gate is
+// open (DSIR_TUNING=1, or dsir_set_tuning(1) before the first call that reads a switch).
+const char* tuning_env(const char* name);
+inline bool tuning_flag(const char* name) { return tuning_env(name) != nullptr; }
+inline long long tuning_int(const char* name, long long dflt) { const char* e = tuning_env(name); return e ? atoll(e) : dflt; }
+
 // GroupNorm of the PRODUCER, applied lazily in the consumer's prologue:
 // the producer wrote raw conv outputs plus per-(cloud,group) sum / sum-of-squares.
+#ifndef DSIR_GN_WORDS_DEFINED
+#define DSIR_GN_WORDS_DEFINED
+constexpr int kGnWords = 4;   // 8-byte words per (cloud, group) statistics slot: device_utils.h, gn_block_commit / gn_stat_get
+#endif
 struct GnRef {
-  const double* stats;   // [clouds][groups][2]; nullptr => no normalisation
+  const double* stats;   // [clouds][groups][kGnWords] (integer counters, see device_utils.h); nullptr => no normalisation
   const float* gamma;    // [C]
   const float* beta;     // [C]
   int groups;
@@ -72,7 +83,7 @@ struct GemmArgs {
   float* Y = nullptr;           // [clouds][M (or M/16 for EPI_ATT)][ldy]
   int64_t y_cloud_stride = 0;
   int ldy = 0;
-  double* stats_out = nullptr;  // EPI_GN: [clouds][groups_out][2]
+  double* stats_out = nullptr;  // EPI_GN: [clouds][groups_out][kGnWords]
   int groups_out = 0;
   const float* residual = nullptr;  // EPI_LINEAR: added before the store
   int64_t res_cloud_stride = 0;
@@ -85,6 +96,27 @@ void launch_pw_gemm(const GemmArgs& a, hipStream_t st);
 bool launch_pw_stream(const GemmArgs& a, hipStream_t st);
 // wide-layer path, LDS-tiled 128/64 x 64 x 32 (pw_tile.hip): Cin a multiple of 32 in [64,768], Cout >= 64
 bool launch_pw_tile(const GemmArgs& a, hipStream_t st);
+
+// att_pool.hip - attentive pooling of the k = 16 layers of levels 1 / 2 (d = 64 / 128), score GEMM split by linearity: two points per
+// wave on v_mfma_f32_32x32x16_f16, softmax and weighted sum in registers (no cross-lane step)
+struct AttPoolArgs {
+  const float* enc = nullptr;        // E [clouds][n * 16][KH] raw conv outputs of the position-encoding branch
+  int64_t enc_cs = 0;
+  GnRef enc_gn = {nullptr, nullptr, nullptr, 0, 0.0};   // its lazy GroupNorm
+  int enc_act = 1;                   // LeakyReLU(0.2) after it
+  const float* gp = nullptr;         // [clouds][n][3 KH] = [ G = W1 fN (2 KH) | fN (KH) ]: the per-point GEMM with the identity block
+  int64_t gp_cs = 0;
+  const int32_t* neigh = nullptr;    // [clouds][n][16]
+  int64_t neigh_cs = 0;
+  const void* Wh = nullptr;          // fp16 split of fc [2 KH][ldw]; the contraction reads columns [wcol0, wcol0 + KH) (= W2)
+  const void* Wl = nullptr;
+  int ldw = 0, wcol0 = 0;
+  float* Y = nullptr;                // [clouds][n][2 KH]
+  int64_t y_cs = 0;
+  int n = 0, clouds = 0, KH = 0;
+  int grid_x = 0;                    // filled by the launcher
+};
+bool launch_att_pool(const AttPoolArgs& a, hipStream_t st);   // false => outside the envelope (caller takes the EPI_ATT2 kernels)
 
 // mlp_out + fc_label fused (head_mlp.hip): x[32] -> feat[64] -> 64 -> 32 -> ncls   (RandLANet.py:363-367)
 struct HeadArgs {
@@ -286,11 +318,12 @@ struct KabschArgs {
   float* matched_out;    // [pairs][m][3] gathered ref points (or nullptr)
   int ref_ld;            // floats between ref points (0 => 3)
   const int32_t* skip;   // [pairs] or nullptr: non-zero => this pair's update is the identity, src_out untouched (ICP)
-  double* part;          // kabsch_part_bytes(pairs, m) of scratch, or nullptr: clouds of kKabschChunkedMin points and more are then
-                         // reduced in chunks by several workgroups per pair (same formulas; the fp64 sums in another order)
+  double* part;          // kabsch_part_bytes(pairs, m, chunk_min) of scratch, or nullptr: clouds of chunk_min points and more are
+                         // then reduced in chunks by several workgroups per pair (same formulas; the fp64 sums in another order)
+  int chunk_min;         // 0 => kKabschChunkedMin
 };
 constexpr int kKabschChunkedMin = 16384;
-size_t kabsch_part_bytes(int pairs, int m);   // 0 below kKabschChunkedMin
+size_t kabsch_part_bytes(int pairs, int m, int chunk_min = 0);   // 0 below the threshold
 void launch_kabsch(const KabschArgs& a, hipStream_t st);
 
 // icp.hip — point-to-point ICP refinement (test.py:241-258 / open3d registration_icp), all pairs at once

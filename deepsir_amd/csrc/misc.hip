@@ -8,9 +8,9 @@ namespace {
 
 __device__ __forceinline__ void gn_scale_shift(const GnRef& g, int cloud, int c, int C, float& scale, float& shift) {
   const int grp = c / (C / g.groups);
-  const double* st = g.stats + ((int64_t)cloud * g.groups + grp) * 2;
-  const double mean = st[0] * g.inv_count;
-  double var = st[1] * g.inv_count - mean * mean;
+  const double* st = g.stats + ((int64_t)cloud * g.groups + grp) * kGnWords;
+  const double mean = gn_stat_get(st) * g.inv_count;
+  double var = gn_stat_get(st + 2) * g.inv_count - mean * mean;
   var = var > 0.0 ? var : 0.0;
   const double rstd = 1.0 / sqrt(var + 1e-5);
   const double sc = (double)g.gamma[c] * rstd;

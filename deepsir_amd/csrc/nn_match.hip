@@ -229,7 +229,7 @@ static void launch_core(const float* a, const float* b, const float* sa, const f
                         unsigned long long* tstamp, const int32_t* gate, int gate_min, const int32_t* rowlist = nullptr) {
   // geometry: 2 row tiles per wave (128-row blocks) once there is enough work, else 64-row blocks; the ref
   // range is split so that the grid is a whole number of residency rounds (256 CUs x 4 blocks: 34 KB LDS each)
-  static const int force_rt = getenv("DSIR_MATCH_RT") ? atoi(getenv("DSIR_MATCH_RT")) : 0;   // tuning hook
+  static const int force_rt = (int)tuning_int("DSIR_MATCH_RT", 0);   // tuning hook
   int rt = (int64_t)pairs * ((J + 127) / 128) >= 256 ? 2 : 1;
   if (force_rt == 1 || force_rt == 2 || force_rt == 4) rt = force_rt;
   if (rowlist) rt = 1;                          // few rows per pair: small row blocks, the ref range split as far as it goes
@@ -270,7 +270,7 @@ static void launch_core(const float* a, const float* b, const float* sa, const f
     eff *= (double)tiles / (double)(tiles_per * nsp);        // padding of the last split
     if (eff > best_eff + 1e-9) { best_eff = eff; splits = sp; }
   }
-  static const int force_splits = getenv("DSIR_MATCH_SPLITS") ? atoi(getenv("DSIR_MATCH_SPLITS")) : 0;   // tuning hook
+  static const int force_splits = (int)tuning_int("DSIR_MATCH_SPLITS", 0);   // tuning hook
   if (force_splits > 0) splits = force_splits < tiles ? force_splits : tiles;
   int cols = ((tiles + splits - 1) / splits) * BC;
   splits = (K + cols - 1) / cols;

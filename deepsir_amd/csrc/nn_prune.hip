@@ -272,10 +272,10 @@ int launch_prune_rows(const float* desc_s, const float* desc_r, const void* ah, 
   const int nrb = (J + rpb - 1) / rpb;
   const int64_t total = (int64_t)pairs * J;
   const int tbits = bits_for(nt);
-  static const bool id_rows = getenv("DSIR_PRUNE_ID_ROWS") != nullptr;     // measurement hook: rows in their natural order
-  static const bool no_lpt = getenv("DSIR_PRUNE_NO_LPT") != nullptr;       // A/B hook: items in row-block order
-  static const bool keep_all = getenv("DSIR_PRUNE_KEEP_ALL") != nullptr;   // measurement hook: every tile on every list (the mechanism's own cost)
-  static const bool no_tile_T = getenv("DSIR_PRUNE_NO_TILE_T") != nullptr; // A/B hook: upper bounds from the previous match only
+  static const bool id_rows = tuning_flag("DSIR_PRUNE_ID_ROWS");     // measurement hook: rows in their natural order
+  static const bool no_lpt = tuning_flag("DSIR_PRUNE_NO_LPT");       // A/B hook: items in row-block order
+  static const bool keep_all = tuning_flag("DSIR_PRUNE_KEEP_ALL");   // measurement hook: every tile on every list (the mechanism's own cost)
+  static const bool no_tile_T = tuning_flag("DSIR_PRUNE_NO_TILE_T"); // A/B hook: upper bounds from the previous match only
   launch_centroid_argmin(ah, al, L.ch, L.cl, L.cn2, pairs, J, nt, L.tstar, st);
   hipLaunchKernelGGL(row_prep_kernel, dim3(grid_for(total)), dim3(256), 0, st, desc_s, desc_r, sa, sb, idx_prev, L.tstar, J, K, tbits, total,
                      keep_all, L.k0, L.v0, L.T);

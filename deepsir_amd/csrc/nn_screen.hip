@@ -1025,7 +1025,7 @@ int nn_screen_cap() { return CAP; }
 // J = 5000) unless the padding of J to whole blocks costs more than that
 int nn_screen_rows_per_block(int J) {
   constexpr int NWV = DSIR_SCREEN_NWV;
-  static const int force_rt = getenv("DSIR_SCREEN_RT") ? atoi(getenv("DSIR_SCREEN_RT")) : DSIR_SCREEN_RT;   // A/B hook
+  static const int force_rt = (int)tuning_int("DSIR_SCREEN_RT", DSIR_SCREEN_RT);   // A/B hook
   auto padded = [&](int rt) { const int64_t r = NWV * 16 * rt; return ((J + r - 1) / r) * r; };
   const int RT = force_rt == 2 || force_rt == 4 ? force_rt : (0.88 * (double)padded(4) <= (double)padded(2) ? 4 : 2);
   return NWV * 16 * RT;
@@ -1088,7 +1088,7 @@ void launch_nn_screen(const float* a, const float* b, const void* ah, const void
   // Screening that is not selective (descriptors closer to each other than the bound width) leaves rows undecided: they
   // are searched by the exhaustive fp32 MFMA kernel - row by row through a list, or the whole pair once a quarter of its
   // rows is affected (then the pair also skips the screening in the remaining iterations of the registration).
-  static const int force_min = getenv("DSIR_SCREEN_OVF_MIN") ? atoi(getenv("DSIR_SCREEN_OVF_MIN")) : 0;   // tuning/test hook
+  static const int force_min = (int)tuning_int("DSIR_SCREEN_OVF_MIN", 0);   // tuning/test hook
   const int ovf_min = force_min > 0 ? force_min : J / 4 + 1;
   if (ev0) (void)hipEventRecord(ev0, st);
   {
@@ -1124,12 +1124,12 @@ void launch_nn_screen(const float* a, const float* b, const void* ah, const void
   // class collisions -> fewer rows for the exhaustive kernel) and costs one more prologue + epilogue per >= 128 tiles
   // (16384 points: +1.4 % pairs/s, 65536: +3.9 %; at 5000 points - 79 tiles - splitting loses 8 % of the kernel)
   while (splits * 2 <= 4 && tiles / (splits * 2) >= 128) splits *= 2;
-  static const int force_splits = getenv("DSIR_SCREEN_SPLITS") ? atoi(getenv("DSIR_SCREEN_SPLITS")) : 0;   // tuning hook
+  static const int force_splits = (int)tuning_int("DSIR_SCREEN_SPLITS", 0);   // tuning hook
   if (force_splits > 0) splits = force_splits < tiles ? force_splits : tiles;
   const int cols = ((tiles + splits - 1) / splits) * SBC;
   splits = (K + cols - 1) / cols;
   const int total = (int)((int64_t)rb_count * splits * pairs);
-  static const int persist = getenv("DSIR_SCREEN_PERSIST") ? atoi(getenv("DSIR_SCREEN_PERSIST")) : 0;   // workgroups per CU; 0 = one per item
+  static const int persist = (int)tuning_int("DSIR_SCREEN_PERSIST", 0);   // workgroups per CU; 0 = one per item
   const bool ordered = ord.tlist && ord.queue;         // launch_prune_rows fills every field or none
   const dim3 grid(ordered ? (unsigned)(total < resident ? total : resident)             // persistent, per-XCD item queues (screen_kernel)
                           : (unsigned)(persist > 0 && total > persist * resident ? persist * resident : total));
@@ -1153,7 +1153,7 @@ void launch_nn_screen(const float* a, const float* b, const void* ah, const void
   hipLaunchKernelGGL(unpack_listed_kernel, dim3((J + 255) / 256, pairs), dim3(256), 0, st, packed, ovf, ovf_min, rowlist, J, idx);
   if (ev1) (void)hipEventRecord(ev1, st);
   if (acc) hipLaunchKernelGGL(screen_account_kernel, dim3(1), dim3(256), 0, st, ovf, pairs, ovf_min, J, acc);
-  static const bool debug = getenv("DSIR_SCREEN_DEBUG") != nullptr;   // diagnostic: rows left to the exhaustive kernel (synchronises)
+  static const bool debug = tuning_flag("DSIR_SCREEN_DEBUG");   // diagnostic: rows left to the exhaustive kernel (synchronises)
   if (debug) {
     std::vector<int32_t> h(pairs);
     (void)hipMemcpyAsync(h.data(), ovf, (size_t)pairs * 4, hipMemcpyDeviceToHost, st);

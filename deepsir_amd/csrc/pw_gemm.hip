@@ -108,9 +108,9 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const GemmArgs p) {
       float scale = 1.f, shift = 0.f;
       if (s.gn.stats) {
         const int g = lc / (s.C / s.gn.groups);
-        const double* st = s.gn.stats + ((int64_t)cloud * s.gn.groups + g) * 2;
-        const double mean = st[0] * s.gn.inv_count;
-        double var = st[1] * s.gn.inv_count - mean * mean;
+        const double* st = s.gn.stats + ((int64_t)cloud * s.gn.groups + g) * kGnWords;
+        const double mean = gn_stat_get(st) * s.gn.inv_count;
+        double var = gn_stat_get(st + 2) * s.gn.inv_count - mean * mean;
         var = var > 0.0 ? var : 0.0;
         const double rstd = 1.0 / sqrt(var + 1e-5);
         const double sc = (double)s.gn.gamma[lc] * rstd;
@@ -213,13 +213,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const GemmArgs p) {
       s_red[tid * 2 + 1] = c2;
     }
     __syncthreads();
-    if (tid < BN && (tid % gw) == 0 && n0 + tid < p.Cout) {
-      double g1 = 0.0, g2 = 0.0;
-      for (int c = 0; c < gw && tid + c < BN; ++c) { g1 += (double)s_red[(tid + c) * 2]; g2 += (double)s_red[(tid + c) * 2 + 1]; }
-      double* st = p.stats_out + ((int64_t)cloud * p.groups_out + (n0 + tid) / gw) * 2;
-      atomicAdd(st, g1);
-      atomicAdd(st + 1, g2);
-    }
+    gn_block_commit(s_red, n0, min(BN, p.Cout - n0), gw, p.stats_out + (int64_t)cloud * p.groups_out * kGnWords);
   } else if (EPI == EPI_ACT || EPI == EPI_LINEAR) {
     float* Y = p.Y + cloud * p.y_cloud_stride;
 #pragma unroll
@@ -305,9 +299,9 @@ void launch_bn(const GemmArgs& a, hipStream_t st) {
 
 void launch_pw_gemm(const GemmArgs& a, hipStream_t st) {
   if (a.M <= 0 || a.clouds <= 0) return;
-  static const bool no_stream = getenv("DSIR_NO_STREAM") != nullptr;   // A/B switch for tests and profiling
+  static const bool no_stream = tuning_flag("DSIR_NO_STREAM");   // A/B switch for tests and profiling
   if (!no_stream && launch_pw_stream(a, st)) return;
-  static const bool no_tile = getenv("DSIR_NO_TILE") != nullptr;
+  static const bool no_tile = tuning_flag("DSIR_NO_TILE");
   if (!no_tile && launch_pw_tile(a, st)) return;
   if (a.amode == A_LSE) {
     launch_bn<EPI_GN, A_LSE>(a, st);

@@ -106,9 +106,9 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const GemmArgs p) {
       float scale = 1.f, shift = 0.f;
       if (s.gn.stats) {
         const int g = c / (s.C / s.gn.groups);
-        const double* st = s.gn.stats + ((int64_t)cloud * s.gn.groups + g) * 2;
-        const double mean = st[0] * s.gn.inv_count;
-        double var = st[1] * s.gn.inv_count - mean * mean;
+        const double* st = s.gn.stats + ((int64_t)cloud * s.gn.groups + g) * kGnWords;
+        const double mean = gn_stat_get(st) * s.gn.inv_count;
+        double var = gn_stat_get(st + 2) * s.gn.inv_count - mean * mean;
         var = var > 0.0 ? var : 0.0;
         const double rstd = 1.0 / sqrt(var + 1e-5);
         const double scd = (double)s.gn.gamma[c] * rstd;
@@ -128,9 +128,9 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const GemmArgs p) {
         const int lc = (c < p.seg[0].C) ? c : c - p.seg[0].C;
         if (s.gn.stats) {
           const int g = lc / (s.C / s.gn.groups);
-          const double* st = s.gn.stats + ((int64_t)cloud * s.gn.groups + g) * 2;
-          const double mean = st[0] * s.gn.inv_count;
-          double var = st[1] * s.gn.inv_count - mean * mean;
+          const double* st = s.gn.stats + ((int64_t)cloud * s.gn.groups + g) * kGnWords;
+          const double mean = gn_stat_get(st) * s.gn.inv_count;
+          double var = gn_stat_get(st + 2) * s.gn.inv_count - mean * mean;
           var = var > 0.0 ? var : 0.0;
           const double rstd = 1.0 / sqrt(var + 1e-5);
           const double scd = (double)s.gn.gamma[lc] * rstd;
@@ -515,13 +515,8 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const GemmArgs p) {
       s_red[tid * 2 + 1] = c2;
     }
     __syncthreads();
-    if (tid < BN && (tid % gw) == 0 && n0 + tid < p.Cout) {
-      double d1 = 0.0, d2 = 0.0;
-      for (int c = 0; c < gw && tid + c < BN; ++c) { d1 += (double)s_red[(tid + c) * 2]; d2 += (double)s_red[(tid + c) * 2 + 1]; }
-      double* st = p.stats_out + ((int64_t)cloud * p.groups_out + (n0 + tid) / gw) * 2;
-      atomicAdd(st, d1);
-      atomicAdd(st + 1, d2);
-    }
+    // ONE atomic instruction per workgroup for all its groups (device_utils.h, gn_block_commit)
+    gn_block_commit(s_red, n0, min(BN, p.Cout - n0), gw, p.stats_out + (int64_t)cloud * p.groups_out * kGnWords);
   }
 }
 
@@ -536,7 +531,7 @@ void launch_s(const GemmArgs& a, hipStream_t st) {
   // small layers: at least `floor_blocks` workgroups per cloud so that a single pair still spreads over the
   // chip; DSIR_STREAM_MIN_BLOCKS trades batch-1 latency (more, shorter waves) against throughput at large
   // batches (fewer waves, per-wave setup amortised over more tiles)
-  static const int floor_blocks = getenv("DSIR_STREAM_MIN_BLOCKS") ? atoi(getenv("DSIR_STREAM_MIN_BLOCKS")) : 16;
+  static const int floor_blocks = (int)tuning_int("DSIR_STREAM_MIN_BLOCKS", 16);
   if (blocks * gy < floor_blocks) {
     const int want = (floor_blocks + gy - 1) / gy, most = (ntiles + 3) / 4;
     blocks = want < most ? want : most;

@@ -83,6 +83,7 @@ __global__ __launch_bounds__(256) void pw_tile_kernel(const GemmArgs p) {
   __shared__ float s_sh[MAXC];
   __shared__ float s_fsc[EPI == EPI_ATT2 ? 128 : 1];   // EPI_ATT2: GroupNorm scale/shift of the gathered-feature half
   __shared__ float s_fsh[EPI == EPI_ATT2 ? 128 : 1];
+  __shared__ float s_gn[EPI == EPI_GN ? 4 * BN * 2 : 1];   // GroupNorm partial sums [wave][column][sum, sum of squares]
 
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform
   const int fr = lane & 15, fq = lane >> 4;
@@ -96,9 +97,9 @@ __global__ __launch_bounds__(256) void pw_tile_kernel(const GemmArgs p) {
       float scale = 1.f, shift = 0.f;
       if (s.gn.stats) {
         const int g = c / (s.C / s.gn.groups);
-        const double* st = s.gn.stats + ((int64_t)cloud * s.gn.groups + g) * 2;
-        const double mean = st[0] * s.gn.inv_count;
-        double var = st[1] * s.gn.inv_count - mean * mean;
+        const double* st = s.gn.stats + ((int64_t)cloud * s.gn.groups + g) * kGnWords;
+        const double mean = gn_stat_get(st) * s.gn.inv_count;
+        double var = gn_stat_get(st + 2) * s.gn.inv_count - mean * mean;
         var = var > 0.0 ? var : 0.0;
         const double rstd = 1.0 / sqrt(var + 1e-5);
         const double scd = (double)s.gn.gamma[c] * rstd;
@@ -116,9 +117,9 @@ __global__ __launch_bounds__(256) void pw_tile_kernel(const GemmArgs p) {
     float scale = 1.f, shift = 0.f;
     if (s.gn.stats) {
       const int g = lc / (s.C / s.gn.groups);
-      const double* st = s.gn.stats + ((int64_t)cloud * s.gn.groups + g) * 2;
-      const double mean = st[0] * s.gn.inv_count;
-      double var = st[1] * s.gn.inv_count - mean * mean;
+      const double* st = s.gn.stats + ((int64_t)cloud * s.gn.groups + g) * kGnWords;
+      const double mean = gn_stat_get(st) * s.gn.inv_count;
+      double var = gn_stat_get(st + 2) * s.gn.inv_count - mean * mean;
       var = var > 0.0 ? var : 0.0;
       const double rstd = 1.0 / sqrt(var + 1e-5);
       const double scd = (double)s.gn.gamma[lc] * rstd;
@@ -334,30 +335,25 @@ __global__ __launch_bounds__(256) void pw_tile_kernel(const GemmArgs p) {
           }
         }
     }
-    const int gw = p.Cout / p.groups_out;     // 8, 16, 32 or 64 channels per group
-    const int lw = gw < 16 ? gw : 16;
+    // per-wave column sums (the four lane groups hold different rows of the same column) -> LDS -> the waves' sums in a fixed
+    // order -> ONE atomic instruction per workgroup (device_utils.h, gn_block_commit)
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       s1[t] += __shfl_xor(s1[t], 16); s1[t] += __shfl_xor(s1[t], 32);
       s2[t] += __shfl_xor(s2[t], 16); s2[t] += __shfl_xor(s2[t], 32);
-      for (int o = 1; o < lw; o <<= 1) { s1[t] += __shfl_xor(s1[t], o); s2[t] += __shfl_xor(s2[t], o); }
-    }
-    if (fq == 0 && (fr % lw) == 0 && r0 < p.M) {
-      const int tpg = gw > 16 ? gw / 16 : 1;
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        if ((t % tpg) != 0) continue;
-        const int col = n0 + 16 * t + fr;
-        if (col >= p.Cout) continue;
-        double d1 = 0.0, d2 = 0.0;
-#pragma unroll
-        for (int u = 0; u < NT; ++u)
-          if (u >= t && u < t + tpg) { d1 += (double)s1[u]; d2 += (double)s2[u]; }
-        double* st = p.stats_out + ((int64_t)cloud * p.groups_out + col / gw) * 2;
-        atomicAdd(st, d1);
-        atomicAdd(st + 1, d2);
+      if (fq == 0) {
+        s_gn[(w * BN + 16 * t + fr) * 2] = s1[t];
+        s_gn[(w * BN + 16 * t + fr) * 2 + 1] = s2[t];
       }
     }
+    __syncthreads();
+    if (tid < 2 * BN) {
+      const float v = (s_gn[tid] + s_gn[2 * BN + tid]) + (s_gn[4 * BN + tid] + s_gn[6 * BN + tid]);
+      s_gn[tid] = v;          // wave 0's slots are re-used: each thread touches only its own entry
+    }
+    __syncthreads();
+    const int ncols = min(BN, p.Cout - n0);
+    gn_block_commit(s_gn, n0, ncols, p.Cout / p.groups_out, p.stats_out + (int64_t)cloud * p.groups_out * kGnWords);
   } else if (EPI == EPI_ACT || EPI == EPI_LINEAR) {
     float* Y = p.Y + cloud * p.y_cloud_stride;
 #pragma unroll
@@ -453,6 +449,7 @@ __global__ __launch_bounds__(256) void pw_tile_small_kernel(const GemmArgs p) {
   __shared__ _Float16 WsH[H ? 2 : 1][2][H ? BN * LDH : 8];
   __shared__ float s_sc[MAXC];
   __shared__ float s_sh[MAXC];
+  __shared__ float s_gn[EPI == EPI_GN ? 2 * BN * 2 : 1];   // GroupNorm partial sums [row half of the block][column][sum, sum of squares]
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = w & 1, wc = w >> 1;
   const int fr = lane & 15, fq = lane >> 4;
@@ -466,9 +463,9 @@ __global__ __launch_bounds__(256) void pw_tile_small_kernel(const GemmArgs p) {
     float scale = 1.f, shift = 0.f;
     if (s.gn.stats) {
       const int g = lc / (s.C / s.gn.groups);
-      const double* st = s.gn.stats + ((int64_t)cloud * s.gn.groups + g) * 2;
-      const double mean = st[0] * s.gn.inv_count;
-      double var = st[1] * s.gn.inv_count - mean * mean;
+      const double* st = s.gn.stats + ((int64_t)cloud * s.gn.groups + g) * kGnWords;
+      const double mean = gn_stat_get(st) * s.gn.inv_count;
+      double var = gn_stat_get(st + 2) * s.gn.inv_count - mean * mean;
       var = var > 0.0 ? var : 0.0;
       const double rstd = 1.0 / sqrt(var + 1e-5);
       const double scd = (double)s.gn.gamma[lc] * rstd;
@@ -626,23 +623,29 @@ __global__ __launch_bounds__(256) void pw_tile_small_kernel(const GemmArgs p) {
       }
     }
     if (EPI == EPI_GN) {
-      const int gw = p.Cout / p.groups_out;     // 8, 16, 32 or 64 channels per group
-      const int lw = gw < 16 ? gw : 16;
       s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
       s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
-      for (int o = 1; o < lw; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
-      if (fq == 0 && (fr % lw) == 0 && m0 + 16 * RTS * wr < p.M && col < p.Cout) {
-        double* st = p.stats_out + ((int64_t)cloud * p.groups_out + col / gw) * 2;
-        atomicAdd(st, (double)s1);
-        atomicAdd(st + 1, (double)s2);
+      if (fq == 0) {
+        s_gn[(wr * BN + 16 * (NTW * wc + t) + fr) * 2] = s1;
+        s_gn[(wr * BN + 16 * (NTW * wc + t) + fr) * 2 + 1] = s2;
       }
     }
+  }
+  if (EPI == EPI_GN) {
+    // the two row halves' sums in a fixed order, then ONE atomic instruction per workgroup (device_utils.h, gn_block_commit)
+    __syncthreads();
+    if (tid < 2 * BN) {
+      const float v = s_gn[tid] + s_gn[2 * BN + tid];
+      s_gn[tid] = v;
+    }
+    __syncthreads();
+    gn_block_commit(s_gn, n0, min(BN, p.Cout - n0), p.Cout / p.groups_out, p.stats_out + (int64_t)cloud * p.groups_out * kGnWords);
   }
 }
 
 // fp16-split contraction when the caller supplied split weights (GemmArgs::Wh / Wl); DSIR_TILE_F32: the exact-fp32 kernels
 inline bool use_split(const GemmArgs& a) {
-  static const bool f32 = getenv("DSIR_TILE_F32") != nullptr;   // A/B switch
+  static const bool f32 = tuning_flag("DSIR_TILE_F32");   // A/B switch
   return !f32 && a.Wh && a.Wl;
 }
 
@@ -696,16 +699,16 @@ bool seg_ok(const Seg& s) {
 bool launch_pw_tile(const GemmArgs& a, hipStream_t st) {
   // Cout >= 64 - or >= 32 with the fp16-split contraction, where the unused half of the 64-column tile costs next to nothing
   // (the level-0 decoder layer 160 -> 32, otherwise left to the generic pw_gemm.hip kernel)
-  static const int min_cout_h = getenv("DSIR_TILE_MIN_COUT") ? atoi(getenv("DSIR_TILE_MIN_COUT")) : 32;   // A/B hook
+  static const int min_cout_h = (int)tuning_int("DSIR_TILE_MIN_COUT", 32);   // A/B hook
   if (a.amode != A_SEGS || a.Cin < 64 || a.Cin > MAXC || (a.Cin % BK) != 0 || a.Cout < (use_split(a) ? min_cout_h : 64)) return false;
   if (!seg_ok(a.seg[0]) || (a.nseg > 1 && (!seg_ok(a.seg[1]) || (a.seg[0].C % 4) != 0))) return false;
   if ((reinterpret_cast<uintptr_t>(a.W) % 16) != 0) return false;
   if (a.epi == EPI_GN && ((a.Cout / a.groups_out) % 8) != 0) return false;
   // rows per block: a function of M only (batch-invariant tiling)
-  static const int small_m = getenv("DSIR_TILE_SMALL_M") ? atoi(getenv("DSIR_TILE_SMALL_M")) : 320;   // tuning hook; 0 = off
+  static const int small_m = (int)tuning_int("DSIR_TILE_SMALL_M", 320);   // tuning hook; 0 = off
   if (a.M <= small_m && (a.epi == EPI_GN || a.epi == EPI_ACT || a.epi == EPI_LINEAR)) {
     // 64-row blocks (two row tiles per wave: W fragments reused twice) when they pad no more than 32-row blocks
-    static const int rt2_min = getenv("DSIR_TILE_SMALL_RT2") ? atoi(getenv("DSIR_TILE_SMALL_RT2")) : 128;   // tuning hook
+    static const int rt2_min = (int)tuning_int("DSIR_TILE_SMALL_RT2", 128);   // tuning hook
     const int p32 = ((a.M + 31) / 32) * 32, p64 = ((a.M + 63) / 64) * 64;
     if (a.M >= rt2_min && p64 == p32) return launch_small_e<2>(a, st);
     return launch_small_e<1>(a, st);

@@ -29,9 +29,10 @@ def shard_sizes(num_items: int, world: int) -> List[int]:
 def gather_results(local: torch.Tensor, dist=None, sizes: Optional[Sequence[int]] = None) -> torch.Tensor:
     """all_gather per-pair results along dim 0.  ``sizes`` = number of valid rows
     per rank when shards are unequal (rows are padded to the maximum for the
-    collective and trimmed afterwards).  With ``dist`` None (single process) this
-    is the identity."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    collective and trimmed afterwards).  With ``dist`` None or no process group this
+    is the identity; with an initialised group the collective RUNS, also at world
+    size 1 (one rank gathering from itself: the same RCCL call path as N ranks)."""
+    if dist is None or not dist.is_initialized():
         return local if sizes is None else local[: sizes[0]]
     world = dist.get_world_size()
     on_gpu = local.is_cuda

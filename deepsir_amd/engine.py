@@ -481,7 +481,13 @@ class Engine:
         return {"losses": d, "grad_logits": grad, "transforms": T}
 
     def enable_graph(self, on=True):
-        """Replay dsir_register through a captured hipGraph (same buffers on every call)."""
+        """Replay dsir_register through a captured hipGraph (same buffers on every call; one graph per call signature)."""
+        if on:
+            from . import graph_replay_safe
+            if not graph_replay_safe():
+                raise EngineError("hipGraph replay needs DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 in the environment BEFORE the process "
+                                  "first touches the GPU (this ROCm's graph packet capture replays wrongly; deepsir_amd/__init__.py): "
+                                  "import deepsir_amd before creating CUDA tensors, or export the variable")
         self._call(self.lib.dsir_enable_graph(self.h, 1 if on else 0))
 
     def enable_match_timer(self, on=True):
@@ -525,6 +531,10 @@ class Engine:
         """A/B switch: the pruned search runs for ref clouds of min_points points and more (0 = never) in launches of min_rows src
         rows and more; same bits either way (include/dsir.h, dsir_set_prune_thresholds)."""
         self._call(self.lib.dsir_set_prune_thresholds(self.h, int(min_points), int(min_rows)))
+
+    def set_kabsch_chunked_min(self, min_points: int = 0):
+        """A/B switch: clouds of min_points points and more solve their pose in chunks (include/dsir.h); <= 0: the default."""
+        self._call(self.lib.dsir_set_kabsch_chunked_min(self.h, int(min_points)))
 
     def match_timer_device(self, reset=True):
         """(total ms, launches) of the timed nn_match launches on the device clock (first wave start .. last wave end)."""

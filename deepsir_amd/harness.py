@@ -25,9 +25,12 @@ from .metrics import THRESHOLDS, rte_rre
 @torch.no_grad()
 def inference_align(pairs: Sequence[Dict[str, np.ndarray]], model, num_reg_iter: int = 5, dataset_type: str = "3DMatch",
                     batch: int = 1, device: Optional[torch.device] = None, dist=None, pose_opt: Optional[str] = None,
-                    voxel_size: float = 0.3):
+                    voxel_size: float = 0.3, in_flight: int = 1):
     """pairs: sequence of dicts with ``points_src/points_ref [1,N,C]``, ``transform_gt [1,3,4]`` and optionally the
     pyramid tensors and ``others`` (as the reference's collate, data_base.py:196-219).
+    ``in_flight`` > 1: the reference's one-pair-per-call loop fed AHEAD - the pairs go one by one to a
+    ``deepsir_amd.serve.PairServer`` that keeps that many requests outstanding (same results bit for bit; the per-pair
+    time is then the shard's wall time divided by its size).
     Returns (pred_transforms_all [n_pairs, n_iter+1, 3, 4], stats [n_pairs, 5]) gathered over ranks."""
     device = device or torch.device("cuda", torch.cuda.current_device())
     rte_t, rre_t = THRESHOLDS[dataset_type]
@@ -37,7 +40,29 @@ def inference_align(pairs: Sequence[Dict[str, np.ndarray]], model, num_reg_iter:
     preds: List[np.ndarray] = []
     stats = np.zeros((len(mine), 5))
     opt = (num_reg_iter, True)
-    for b0 in range(0, len(mine), batch):
+    if in_flight > 1:
+        if pose_opt is not None:
+            raise ValueError("in_flight > 1 serves the registration alone (pose_opt must be None)")
+        datas = [_stack(pairs, [i], device) for i in mine]
+        n_max = max([max(d["points_src"].shape[1], d["points_ref"].shape[1]) for d in datas], default=1024)
+        srv = model.serve(max_points=n_max, max_in_flight=in_flight, n_iter=num_reg_iter, want_aux=False)
+        torch.cuda.synchronize(device)
+        t0 = time.time()
+        res = srv.run_closed_loop(((d["points_src"].float(), d["points_ref"].float()) for d in datas), in_flight)
+        torch.cuda.synchronize(device)
+        dt = (time.time() - t0) / max(len(mine), 1)
+        srv.close()
+        for row, (i, d, r) in enumerate(zip(mine, datas, res)):
+            T = r["transforms"].cpu().numpy()
+            preds.append(np.concatenate([T, T[-1:]], 0)[None])            # pose_optimization == identity (test.py:215-216)
+            stats[row, :3] = rte_rre(T[-1], d["transform_gt"].cpu().numpy()[0], rte_t, rre_t)
+            stats[row, 3] = dt
+            others = pairs[i].get("others")
+            stats[row, 4] = _seq_id(others[0]["seq"]) if others else -1
+        mine_batches = range(0)
+    else:
+        mine_batches = range(0, len(mine), batch)
+    for b0 in mine_batches:
         ids = mine[b0:b0 + batch]
         data = _stack(pairs, ids, device)
         torch.cuda.synchronize(device)
@@ -48,14 +73,14 @@ def inference_align(pairs: Sequence[Dict[str, np.ndarray]], model, num_reg_iter:
         if pose_opt == "icp":
             # pose_optimization with use_icp (test.py:241-258; off in the reference): point-to-point ICP on the raw clouds,
             # correspondence radius 2 x voxel size (test.py:219), open3d's default criteria
-            T_opt, _ = model._engine.icp_refine(data["points_src"].float(), data["points_ref"].float(),
+            T_opt, _ = _aux_engine(model, data).icp_refine(data["points_src"].float(), data["points_ref"].float(),
                                                 transforms[-1].contiguous(), 2.0 * voxel_size)
             transforms.append(T_opt)
         elif pose_opt == "tune":
             # pose_optimization with use_tune (test.py:218-239; off in the reference): Adam fine-tune of the 6-D-rotation
             # pose on the last iteration's correspondences, weights = sigmoid of its inlier logits, distances in units
             # of 2 x voxel size (test.py:219, :238)
-            T_opt, _ = model._engine.pose_finetune(endpoints["pt_src"].float(), endpoints["pt_ref_new"].float(),
+            T_opt, _ = _aux_engine(model, data).pose_finetune(endpoints["pt_src"].float(), endpoints["pt_ref_new"].float(),
                                                    transforms[-1].contiguous(), weights=endpoints["perm_matrices"][-1],
                                                    weights_are_logits=True, quantization_size=2.0 * voxel_size)
             transforms.append(T_opt)
@@ -78,6 +103,13 @@ def inference_align(pairs: Sequence[Dict[str, np.ndarray]], model, num_reg_iter:
         pred = gather_results(torch.from_numpy(pred).to(device), dist, sizes).cpu().numpy()
         stats = gather_results(torch.from_numpy(stats).to(device), dist, sizes).cpu().numpy()
     return pred, stats
+
+
+def _aux_engine(model, data):
+    """The plain engine behind the drop-in model for the operators next to the path (ICP, fine-tune): ``forward`` may have run on
+    the model's server or pool instead."""
+    n = max(int(data["points_src"].shape[1]), int(data["points_ref"].shape[1]))
+    return model._ensure_engine(n, int(data["points_src"].shape[0]))
 
 
 def summarize(stats: np.ndarray) -> Dict[str, float]:

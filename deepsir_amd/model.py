@@ -23,8 +23,10 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from collections.abc import Sequence
+
 from .arch import NetConfig, network_specs
-from .engine import Engine, EngineError
+from .engine import Engine, EngineError, EnginePool
 
 _PYR_KEYS = ("xyz", "neigh_idx", "sub_idx", "interp_idx")
 
@@ -33,17 +35,84 @@ class _Node(nn.Module):
     """Name-space node of the checkpoint tree (no computation)."""
 
 
-def _attach(root: nn.Module, dotted: str, tensor: torch.Tensor):
+def _attach(root: nn.Module, dotted: str, tensor: torch.Tensor, trainable: bool, requires_grad: bool):
+    """Trainable tensors are ``nn.Parameter``s under the reference's names and in its registration order, so that
+    ``optim.Adam(my_model.parameters(), lr)`` (reference train.py:323) constructs and ``named_parameters()`` reads as the
+    reference's; BatchNorm running statistics stay buffers."""
     parts = dotted.split(".")
     m = root
     for p in parts[:-1]:
         if p not in m._modules:
             m.add_module(p, _Node())
         m = m._modules[p]
-    m.register_buffer(parts[-1], tensor)
+    if trainable:
+        m.register_parameter(parts[-1], nn.Parameter(tensor, requires_grad=requires_grad))
+    else:
+        m.register_buffer(parts[-1], tensor)
+
+
+def _requires_grad(pipeline: str, name: str) -> bool:
+    """freeze_model / freeze_model_2 (reference model.py:196-207): 'label' trains the extractor; 'feat' freezes it; 'align'
+    also freezes the aggregation layers and trains the inlier model alone."""
+    top = name.split(".", 1)[0]
+    if pipeline == "label":
+        return True
+    if pipeline == "feat":
+        return top != "feat_extractor"
+    return top == "inlier_model"
+
+
+class _LazyPredPairs(Sequence):
+    """``endpoints['pred_pairs']``: per iteration an int32 CPU tensor [B, J, 2] of (src row, matched ref row) as the reference
+    builds it (model.py:603-606).  The device-to-host copy - a device synchronisation - is deferred until an element is READ:
+    a caller that only wants the poses never waits for it."""
+
+    def __init__(self, idx_dev: torch.Tensor):
+        self._idx, self._items = idx_dev, None          # [n_iter, B, J] int32 on the device
+
+    def _materialise(self):
+        if self._items is None:
+            idx = self._idx.cpu()
+            n, B, J = idx.shape
+            ar = torch.arange(J, dtype=torch.int32)[None, :, None].expand(B, J, 1)
+            self._items = [torch.cat([ar, idx[i][:, :, None]], dim=2) for i in range(n)]
+            self._idx = None
+        return self._items
+
+    def __len__(self):
+        return len(self._items) if self._items is not None else int(self._idx.shape[0])
+
+    def __getitem__(self, i):
+        return self._materialise()[i]
+
+
+class _LazyFlag:
+    """``endpoints['invalid_gradient']`` (model.py:61-64): truth value read from the device only when asked for."""
+
+    def __init__(self, invalid_dev: torch.Tensor):
+        self._t, self._v = invalid_dev, None
+
+    def __bool__(self):
+        if self._v is None:
+            self._v = bool((self._t & 1).any().item())   # bit 0 = SVD failure
+            self._t = None
+        return self._v
+
+    def __eq__(self, other):
+        return bool(self) == other
+
+    def __repr__(self):
+        return repr(bool(self))
 
 
 class Network(nn.Module):
+    POOL_MIN_PAIRS = 64
+    """Batches of that many pairs and more run on an ``EnginePool`` (two HIP streams): same bits, higher throughput."""
+    SERVE_MAX_PAIRS = 8
+    """Batches of up to that many pairs (the reference evaluates ONE, test.py:56) go through a ``PairServer``: the launch
+    sequence replayed from a captured hipGraph on one of two engines in turn, no host synchronisation in ``forward`` - the
+    results are ordered on torch's current stream, consecutive calls overlap until the caller reads a result."""
+
     def __init__(self, args):
         super().__init__()
         self.cfg = NetConfig.from_args(args)
@@ -57,27 +126,78 @@ class Network(nn.Module):
         self.clip_weight_thresh = getattr(args, "clip_weight_thresh", 0.0)
         for spec in network_specs(self.cfg):
             dtype = torch.int64 if spec.kind == "bn_count" else torch.float32
-            _attach(self, spec.name, torch.zeros(spec.shape, dtype=dtype))
+            trainable = spec.kind not in ("bn_mean", "bn_var", "bn_count")
+            _attach(self, spec.name, torch.zeros(spec.shape, dtype=dtype), trainable, _requires_grad(self.pipeline, spec.name))
         self._engine: Optional[Engine] = None
+        self._pool: Optional[EnginePool] = None
         self._dirty = True
+        self._pool_dirty = True
         self._max_points = 0
         self._max_pairs = 0
+        self._pool_points = 0
+        self._pool_pairs = 0
+        self._seen_version = -1
+        self._server = None
+        self._server_dirty = True
 
     # ---- checkpoint plumbing
     def load_state_dict(self, state_dict, strict: bool = True):
         r = super().load_state_dict(state_dict, strict=strict)
-        self._dirty = True
+        self._dirty = self._pool_dirty = self._server_dirty = True
         self._trainer = self._frozen_trainers = self._stepper = self._stepper_key = None     # they hold the previous weights
         return r
 
     def _device_index(self) -> int:
-        dev = next(self.buffers()).device
+        dev = next(self.parameters()).device
         if dev.type != "cuda":
             raise EngineError("Network is on the CPU: this engine has no CPU path; call .to('cuda') / .cuda() first")
         return dev.index or 0
 
+    def _check_weights_touched(self):
+        """An optimiser (or any in-place write) that changed a parameter bumps its version counter: the engines reload."""
+        v = sum(p._version for p in self.parameters()) + sum(b._version for b in self.buffers())
+        if v != self._seen_version:
+            self._dirty = self._pool_dirty = self._server_dirty = True
+            self._seen_version = v
+
+    def _ensure_pool(self, n_points: int, pairs: int) -> EnginePool:
+        dev = self._device_index()
+        self._check_weights_touched()
+        if self._pool is None or n_points > self._pool_points or pairs > self._pool_pairs:
+            if self._pool is not None:
+                self._pool.close()
+            self._pool_points = max(self._pool_points, n_points, 1024)
+            self._pool_pairs = max(self._pool_pairs, pairs)
+            self._pool = EnginePool(self.cfg, dev, self._pool_points, self._pool_pairs, streams=2)
+            self._pool_dirty = True
+        if self._pool_dirty:
+            self._pool.load_state_dict({k: v for k, v in self.state_dict().items()})
+            self._pool_dirty = False
+        return self._pool
+
+    def _ensure_server(self, n_points: int, n_iter: int):
+        from .serve import PairServer
+        dev = self._device_index()
+        self._check_weights_touched()
+        srv = getattr(self, "_server", None)
+        if srv is None or n_points > srv.max_points or self._server_dirty or srv.n_iter != n_iter:
+            if srv is not None:
+                srv.close()
+            self._server = srv = PairServer(self.cfg, {k: v for k, v in self.state_dict().items()}, dev, max(n_points, 1024),
+                                            2 * self.SERVE_MAX_PAIRS, 2, n_iter, True)
+            self._server_dirty = False
+        return srv
+
+    def serve(self, max_points: int = 5000, max_in_flight: int = 8, engines: int = 2, n_iter: Optional[int] = None, want_aux: bool = True):
+        """A ``deepsir_amd.serve.PairServer`` on this network's weights: K single-pair registrations in flight
+        (the reference's batch-1 evaluation mode, test.py:56, fed ahead)."""
+        from .serve import PairServer
+        return PairServer(self.cfg, {k: v for k, v in self.state_dict().items()}, self._device_index(), max_points, max_in_flight,
+                          engines, self.cfg.num_reg_iter if n_iter is None else n_iter, want_aux)
+
     def _ensure_engine(self, n_points: int, pairs: int) -> Engine:
         dev = self._device_index()
+        self._check_weights_touched()
         if self._engine is None or n_points > self._max_points or pairs > self._max_pairs:
             if self._engine is not None:
                 self._engine.close()
@@ -109,22 +229,30 @@ class Network(nn.Module):
         src, ref = data["points_src"], data["points_ref"]
         B, J, _ = src.shape
         K = ref.shape[1]
-        eng = self._ensure_engine(max(J, K), B)
         have = all(f"points_{s}_{k}" in data for s in ("src", "ref") for k in _PYR_KEYS)
         pyr = {f"points_{s}_{k}": data[f"points_{s}_{k}"] for s in ("src", "ref") for k in _PYR_KEYS} if have else None
         if self.pipeline != "align":
-            return self._forward_pair(eng, src, ref, pyr)
+            return self._forward_pair(self._ensure_engine(max(J, K), B), src, ref, pyr)
         num_reg_iter, _clip_weight = opt  # clip_weight is ignored by the reference too (model.py:581-582)
+        if B <= self.SERVE_MAX_PAIRS and pyr is None and src.is_cuda:
+            out = self._ensure_server(max(J, K), int(num_reg_iter)).submit_batch(src.float(), ref.float()).result(wait="stream")
+            return self._align_outputs(out, src, ref, int(num_reg_iter))
+        # large batches: two engines on two HIP streams (EnginePool) - same bits, the throughput configuration of bench.py
+        eng = self._ensure_pool(max(J, K), B) if B >= self.POOL_MIN_PAIRS else self._ensure_engine(max(J, K), B)
+        if pyr is not None and isinstance(eng, EnginePool):
+            pyr = {k: (v if v.dtype != torch.int64 else v.to(torch.int32)) for k, v in pyr.items()}
         out = eng.register(src.float(), ref.float(), int(num_reg_iter), pyramids=pyr)
+        return self._align_outputs(out, src, ref, int(num_reg_iter))
+
+    @staticmethod
+    def _align_outputs(out, src, ref, num_reg_iter: int):
         transforms: List[torch.Tensor] = [out["transforms"][:, i].contiguous() for i in range(num_reg_iter)]
-        idx_cpu = out["idx"].cpu()
-        ar = torch.arange(J, dtype=torch.int32)[None, :, None].expand(B, J, 1)
         endpoints = {
             "pt_src": src[:, :, :3].contiguous(),
             "pt_ref": ref[:, :, :3].contiguous(),
             "perm_matrices": [out["logits"][i] for i in range(num_reg_iter)],
-            "pred_pairs": [torch.cat([ar, idx_cpu[i][:, :, None]], dim=2) for i in range(num_reg_iter)],
-            "invalid_gradient": bool((out["invalid"] & 1).any().item()),   # bit 0 = SVD failure (model.py:61-64)
+            "pred_pairs": _LazyPredPairs(out["idx"]),          # CPU tensors like the reference's, copied when first read
+            "invalid_gradient": _LazyFlag(out["invalid"]),     # model.py:61-64; read from the device when tested
             "pt_ref_new": out["pt_ref_new"],
         }
         return transforms, endpoints
@@ -220,6 +348,7 @@ class Network(nn.Module):
             new.update({k: v.detach().cpu().numpy().reshape(ft._shapes[k]) for k, v in ft.buffers.items()})
         with torch.no_grad():
             own = dict(self.named_buffers())
+            own.update(dict(self.named_parameters()))
             for k, v in new.items():
                 own[k].copy_(torch.from_numpy(np.ascontiguousarray(v)).to(own[k].device))
         self._dirty = True

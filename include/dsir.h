@@ -69,8 +69,10 @@ int dsir_sync(dsir_ctx* ctx);
 /* Order every later call of this context on a CALLER-OWNED hipStream_t instead (restore_own != 0: back to the context's own
  * stream; a NULL hip_stream with restore_own == 0 is the legacy default stream, which is what torch's default stream is) - e.g.
  * the host framework's current stream, so that the engine's operators interleave with the caller's kernels without host
- * synchronisation and can be captured into the caller's hipGraph.  The context never destroys a caller's stream; work enqueued earlier stays
- * on the stream it was enqueued on (synchronise before switching if the two must be ordered). */
+ * synchronisation and can be captured into the caller's hipGraph.  The context never destroys a caller's stream.  Work enqueued earlier stays
+ * on the stream it was enqueued on, and the new stream WAITS for it on the device (an event recorded on the old stream): every
+ * call of a context re-uses its one workspace arena, so launches on the new stream must not overtake the old stream's.  The
+ * one exception is a stream under capture, which cannot wait on outside work: synchronise before the capture begins. */
 int dsir_set_stream(dsir_ctx* ctx, void* hip_stream, int restore_own);
 int dsir_num_weights(const dsir_ctx* ctx);
 /* i-th expected state-dict key and its element count (for host-side validation). */
@@ -285,7 +287,11 @@ int dsir_align_loss_backward(dsir_ctx* ctx, const float* pt_src, const float* pt
                              double* losses, float* grad_logits);
 
 /* Launch-bound small batches: capture the whole dsir_register launch sequence into a hipGraph once per
- * call signature (sizes and buffer addresses) and replay it.  Off by default. */
+ * call signature (sizes and buffer addresses) and replay it; the context keeps the graphs of its 16 most recent signatures
+ * (a server that coalesces 1 .. K single-pair requests per call replays K graphs in turn).  Off by default.
+ * ROCm 7.x: the process must run with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 (in the environment before the HIP runtime
+ * initialises): the runtime's graph packet capture replays a captured registration wrongly from its third launch on once
+ * the host has waited between launches (tools/graph_replay_check.py).  The Python host sets it on import. */
 int dsir_enable_graph(dsir_ctx* ctx, int enable);
 
 /* Test/measurement hooks. */
@@ -297,7 +303,7 @@ int dsir_match_timer(dsir_ctx* ctx, int reset, double* total_ms, int64_t* launch
  * the exhaustive path runs) bracketed on its own: op_ms = every kernel of the operation, kernel_ms = that kernel. */
 int dsir_match_timer2(dsir_ctx* ctx, int reset, double* op_ms, double* kernel_ms, int64_t* launches);
 /* A/B switch (measurement): 0 = dsir_register always takes the exhaustive exact-fp32 arg-min kernel, 1 (default) = the
- * fp16-screened path for large problems.  Both return the same bits.  Initialised from DSIR_NO_SCREEN. */
+ * fp16-screened path for large problems.  Both return the same bits.  Initialised from DSIR_NO_SCREEN (behind the tuning gate, below). */
 int dsir_enable_screen(dsir_ctx* ctx, int enable);
 /* A/B switch (measurement / test): 1 (default) = the five wide layers of the aggregation chain (mlp_att 32 -> 64 -> 128 -> 256 ->
  * 64, mlp_proj; network/model.py:223-233) run as fp16-split products on the fp16 matrix pipe (csrc/agg_chain_h.hip: each fp32
@@ -329,6 +335,19 @@ int dsir_prune_stats(dsir_ctx* ctx, int reset, int64_t* out);
  * launch does not fill the chip with work items and the preparation is pure cost).  Pruned and unpruned searches return the
  * same bits: only products that cannot hold a row's arg-min - nor tie with it - are skipped. */
 int dsir_set_prune_thresholds(dsir_ctx* ctx, int min_points, int64_t min_rows);
+/* A/B switch (test): clouds of `min_points` points and more solve their pose in chunks over several workgroups per pair
+ * (csrc/kabsch.hip; default 16384, <= 0 restores it), in dsir_register and dsir_kabsch.  Same formulas either way; the fp64
+ * partial sums are taken in another order. */
+int dsir_set_kabsch_chunked_min(dsir_ctx* ctx, int min_points);
+
+/* The tuning gate.  The library has a number of measurement / A-B switches named DSIR_* (kernel-family selection, tile
+ * geometry, thresholds).  They are environment variables, read in ONE function (csrc/engine.hip,
+ * tuning_env) and ONLY while the gate is open: DSIR_TUNING=1 in the environment, or dsir_set_tuning(1) called before the
+ * first library call that reads a switch (most are read once per process).  With the gate closed - the default - every
+ * DSIR_* variable is ignored, so a stray one in a user's environment cannot change what runs.  dsir_tuning() reports
+ * the gate's state.  Every variant behind a switch is the HIP path; none is a fallback. */
+void dsir_set_tuning(int on);
+int dsir_tuning(void);
 
 /* Diagnostics of the fp16 screening (csrc/nn_screen.hip) on ONE pair, all pointers DEVICE memory: for every (row, column)
  * the screening's lower bound L, its upper bound U = L + 2 d and the exact fp32 distance D of dsir_nn_match

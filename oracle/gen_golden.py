@@ -18,6 +18,7 @@ points: ``Network(args)``, ``load_state_dict``, ``net(data, (n_iter, True))``
 from __future__ import annotations
 
 import argparse
+import copy
 import hashlib
 import json
 import os
@@ -155,6 +156,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
     ap.add_argument("--threads", type=int, default=1)
+    ap.add_argument("--keys-only", action="store_true", help="only (re)write state_dict_keys.json (keys, shapes, parameter list)")
     a = ap.parse_args()
     torch.set_num_threads(a.threads)
     os.makedirs(GOLD, exist_ok=True)
@@ -162,8 +164,19 @@ def main():
     net, ref_model, ref_match, args = build_reference(a.ref, 3)
 
     keys = [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in net.state_dict().items()]
+    # what ``optim.Adam(my_model.parameters(), lr)`` (train.py:323) is handed, per pipeline: names in order + requires_grad
+    # (freeze_model / freeze_model_2, model.py:196-207)
+    params = {}
+    for pipe in ("align", "feat", "label"):
+        pargs = copy.copy(args)
+        pargs.pipeline, pargs.num_sub = pipe, (-1 if pipe == "align" else 512)
+        pargs.thres_radius = 1.0   # only read by the training loss that Network.__init__ constructs (loss.py:498)
+        pnet = ref_model.Network(pargs)
+        params[pipe] = [[k, bool(v.requires_grad)] for k, v in pnet.named_parameters()]
     with open(os.path.join(GOLD, "state_dict_keys.json"), "w") as f:
-        json.dump({"feat_len": 3, "keys": keys}, f, indent=0)
+        json.dump({"feat_len": 3, "keys": keys, "parameters": params}, f, indent=0)
+    if a.keys_only:
+        return
 
     np.savez_compressed(os.path.join(GOLD, "kabsch_cases.npz"), **kabsch_cases(ref_model))
 

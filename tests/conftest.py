@@ -2,6 +2,8 @@ import json
 import os
 import sys
 
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")   # before the GPU is touched: deepsir_amd/__init__.py
+
 import numpy as np
 import pytest
 

@@ -33,3 +33,26 @@ def test_generator_is_deterministic_and_complete():
 def test_level_sizes():
     assert level_sizes(5000, (4, 4, 4, 4)) == [5000, 1250, 312, 78, 19]
     assert level_sizes(2048, (4, 4, 4, 4)) == [2048, 512, 128, 32, 8]
+
+
+def test_network_parameters_match_the_reference_list():
+    """``optim.Adam(my_model.parameters(), lr)`` (reference train.py:323) must construct on the drop-in: trainable tensors are
+    nn.Parameters under the reference's names, in its order, with its requires_grad flags (freeze_model / freeze_model_2,
+    model.py:196-207) - captured from the imported reference by oracle/gen_golden.py for all three pipelines."""
+    import types
+    import torch
+    from deepsir_amd.model import Network
+    with open(os.path.join(GOLD, "state_dict_keys.json")) as f:
+        ref = json.load(f)
+    for pipe, want in ref["parameters"].items():
+        args = types.SimpleNamespace(pipeline=pipe, feat_len=ref["feat_len"], num_sub=-1 if pipe == "align" else 512)
+        net = Network(args)
+        got = [[k, bool(v.requires_grad)] for k, v in net.named_parameters()]
+        assert got == want, pipe
+        assert len(list(net.parameters())) == len(want) == {"align": 340, "feat": 185, "label": 155}[pipe]
+        opt = torch.optim.Adam(net.parameters(), lr=1e-3)           # "optimizer got an empty parameter list" before
+        assert sum(len(g["params"]) for g in opt.param_groups) == len(want)
+        # buffers = the BatchNorm running statistics only; parameters + buffers = the state-dict
+        assert len(list(net.buffers())) + len(want) == len(net.state_dict())
+    sd_keys = [k for k, _, _ in ref["keys"]]
+    assert list(Network(types.SimpleNamespace(pipeline="align", feat_len=3, num_sub=-1)).state_dict().keys()) == sd_keys

@@ -79,3 +79,53 @@ def test_two_ranks_on_one_gpu_match_single_process(tmp_path):
     assert a["pred"].shape == b["pred"].shape == (6, 4, 3, 4)
     assert np.array_equal(a["pred"], b["pred"])
     assert np.array_equal(a["stats"][:, :3], b["stats"][:, :3])
+
+
+def _world1_worker(backend, port, q):
+    """One rank gathering from itself through an initialised process group: the collective itself must run."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if backend == "nccl":
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)   # RCCL, before any other GPU work
+    else:
+        dev = torch.device("cpu")
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    calls = []
+    real = dist.all_gather
+    dist.all_gather = lambda out, x, *a, **k: (calls.append(tuple(x.shape)), real(out, x, *a, **k))[1]
+    local = torch.arange(7 * 5 * 12, dtype=torch.float32, device=dev).reshape(7, 5, 3, 4)      # [pairs, n_iter, 3, 4]
+    same = gather_results(local, dist)
+    padded = gather_results(local[:5], dist, sizes=[5])
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+    ok = bool(torch.equal(same, local)) and bool(torch.equal(padded, local[:5])) and same.device == local.device
+    q.put((ok, calls, dist.get_backend()))
+    dist.destroy_process_group()
+
+
+def _run_world1(backend):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_world1_worker, args=(backend, port, q))
+    p.start()
+    ok, calls, name = q.get(timeout=300)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert ok and name == backend
+    assert calls == [(7, 5, 3, 4), (5, 5, 3, 4)], calls      # both gathers went through the collective
+
+
+def test_world_size_one_still_runs_the_collective():
+    _run_world1("gloo")
+
+
+@pytest.mark.gpu
+def test_rccl_world_size_one_gather():
+    """backend "nccl" IS RCCL on ROCm: the padded all_gather of the [pairs, n_iter, 3, 4] results through a one-rank RCCL
+    communicator on the test box's GPU returns its input (the library is loaded and the collective executes)."""
+    _run_world1("nccl")

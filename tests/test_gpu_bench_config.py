@@ -211,7 +211,7 @@ def test_hoisted_loop_invariants_are_bit_identical(tmp_path):
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = {}
-    for name, extra in (("hoisted", {}), ("no_s2", {"DSIR_NO_S2": "1"}), ("no_hoist", {"DSIR_NO_HOIST": "1"})):
+    for name, extra in (("hoisted", {}), ("no_s2", {"DSIR_TUNING": "1", "DSIR_NO_S2": "1"}), ("no_hoist", {"DSIR_TUNING": "1", "DSIR_NO_HOIST": "1"})):
         out = str(tmp_path / f"{name}.npz")
         env = {k: v for k, v in os.environ.items() if k not in ("DSIR_NO_S2", "DSIR_NO_HOIST")}
         env.update(extra)
@@ -253,3 +253,69 @@ def test_engine_on_the_callers_stream_gives_the_same_bits():
         assert torch.equal(want[k], got[k]) and torch.equal(want[k], got2[k]) and torch.equal(want[k], again[k]), k
     assert torch.isfinite(desc).all()
     eng.close()
+
+
+def test_alternating_torch_streams_share_the_workspace_safely():
+    """A context re-uses ONE workspace arena in every call.  With ``use_torch_stream`` the wrapper re-binds the context to
+    torch's current stream whenever it changed: the new stream must then wait (on the device) for the launches still running
+    on the old one (dsir_set_stream, include/dsir.h) - back-to-back calls on two alternating streams, no host synchronisation
+    in between, return the bits of the serial run."""
+    from deepsir_amd.arch import NetConfig
+    from deepsir_amd.engine import Engine
+    from deepsir_amd.synth import make_batch
+    from deepsir_amd.weights import generate_state_dict
+    cfg = NetConfig(feat_len=3)
+    eng = Engine(cfg, 0, max_points=5000, max_pairs=4)
+    eng.load_state_dict(generate_state_dict(cfg, 4))
+    sets = []
+    for k in range(2):
+        b = make_batch(5000, [41 + 4 * k + i for i in range(4)], 3)
+        sets.append((torch.from_numpy(b["points_src"]).cuda(), torch.from_numpy(b["points_ref"]).cuda()))
+    want = [eng.register(s, r, 3) for s, r in sets]
+    eng.use_torch_stream(True)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for st in streams:
+        st.wait_stream(torch.cuda.current_stream())
+    got = []
+    for rep in range(6):                      # 12 calls, alternating streams and inputs, nothing synchronised in between
+        for k in range(2):
+            with torch.cuda.stream(streams[k]):
+                got.append((k, eng.register(sets[k][0], sets[k][1], 3, sync=False)))
+    torch.cuda.synchronize()
+    eng.use_torch_stream(False)
+    for k, o in got:
+        for key in ("transforms", "idx", "logits"):
+            assert torch.equal(want[k][key], o[key]), (k, key)
+    eng.close()
+
+
+def test_groupnorm_statistics_do_not_depend_on_arrival_order():
+    """GroupNorm statistics of a layer meet across workgroups in INTEGER atomics (csrc/device_utils.h, gn_stat_add): the totals
+    - hence every bit downstream - cannot depend on the order in which workgroups arrive.  One 32-pair registration repeated 200
+    times on two concurrently running engines (EnginePool, 2 HIP streams, kernels of both interleaving on the CUs): identical
+    correspondences, logits and poses every time; the two halves of the batch also equal a single-engine run."""
+    from deepsir_amd.arch import NetConfig
+    from deepsir_amd.engine import Engine, EnginePool
+    from deepsir_amd.synth import make_batch
+    from deepsir_amd.weights import generate_state_dict
+    cfg = NetConfig(feat_len=3)
+    sd = generate_state_dict(cfg, 0)
+    P, N, n_iter = 32, 5000, 3
+    b = make_batch(N, [20_000 + i for i in range(P)], 3)
+    src, ref = cu(b["points_src"]), cu(b["points_ref"])
+    pool = EnginePool(cfg, 0, max_points=N, max_pairs=P, streams=2)
+    pool.load_state_dict(sd)
+    first = pool.register(src, ref, n_iter)
+    keep = {k: first[k].clone() for k in ("transforms", "idx", "logits")}
+    differing = 0
+    for rep in range(200):
+        out = pool.register(src, ref, n_iter)
+        differing += int(any(not torch.equal(out[k], keep[k]) for k in keep))
+    pool.close()
+    assert differing == 0, f"{differing} of 200 repeats differ"
+    eng = Engine(cfg, 0, max_points=N, max_pairs=P)
+    eng.load_state_dict(sd)
+    one = eng.register(src, ref, n_iter)
+    eng.close()
+    for k in keep:
+        assert torch.equal(one[k], keep[k]), k

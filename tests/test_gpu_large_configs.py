@@ -114,7 +114,7 @@ def test_large_register_screened_equals_exhaustive(tmp_path, pairs, n, feat_len,
     """Long ref ranges (256 / 1024 column tiles: split over 2 - 4 workgroups per range by launch_nn_screen): the screened
     registration and the exhaustive one (DSIR_NO_SCREEN=1, second process) agree bit for bit over 5 iterations."""
     outs = []
-    for name, extra in (("screened", {}), ("exhaustive", {"DSIR_NO_SCREEN": "1"})):
+    for name, extra in (("screened", {}), ("exhaustive", {"DSIR_TUNING": "1", "DSIR_NO_SCREEN": "1"})):
         out = str(tmp_path / f"{name}.npz")
         env = dict(os.environ, **extra)
         for k in ("DSIR_SCREEN_OVF_MIN", "DSIR_SCREEN_SPLITS", "DSIR_SCREEN_RT"):

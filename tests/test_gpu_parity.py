@@ -237,7 +237,7 @@ def test_kabsch_golden_cases():
 def test_kabsch_chunked_reduction_on_large_clouds(m):
     """Clouds of >= 16384 points are reduced in chunks of 4096 points by several workgroups per pair (csrc/kabsch.hip): against
     the oracle's solve (fp64 SVD, model.py:22-66) within 5e-6 rad / 5e-6 m, and against the one-workgroup kernel on the same
-    input (DSIR_KABSCH_CHUNKED_MIN moves the threshold) within 1e-6 - same formulas, the fp64 partial sums in another order."""
+    input (dsir_set_kabsch_chunked_min moves the threshold) within 1e-6 - same formulas, the fp64 partial sums in another order."""
     import os
     from deepsir_amd.arch import NetConfig
     from deepsir_amd.weights import generate_state_dict
@@ -259,11 +259,11 @@ def test_kabsch_chunked_reduction_on_large_clouds(m):
     w[0, : m // 3] = 0.0                                   # a third of the points of pair 0 without weight
     T_chunked, bad = eng.kabsch(cu(src), cu(tgt), cu(w))
     assert not bool(bad.any())
-    os.environ["DSIR_KABSCH_CHUNKED_MIN"] = str(1 << 30)
+    eng.set_kabsch_chunked_min(1 << 30)
     try:
         T_single, bad1 = eng.kabsch(cu(src), cu(tgt), cu(w))
     finally:
-        del os.environ["DSIR_KABSCH_CHUNKED_MIN"]
+        eng.set_kabsch_chunked_min(0)
     assert not bool(bad1.any())
     assert_pose_close(T_chunked.cpu().numpy(), T_single.cpu().numpy(), 1e-6, 1e-6, f"chunked vs one workgroup, m = {m}")
     ref = np.stack([OracleNet.kabsch(torch.from_numpy(src[p:p + 1]), torch.from_numpy(tgt[p:p + 1]), torch.from_numpy(w[p:p + 1, :, None]))[0].numpy()[0]
@@ -528,7 +528,7 @@ def test_network_dropin_api():
     assert len(transforms) == 5 and tuple(transforms[0].shape) == (1, 3, 4) and transforms[0].is_cuda
     assert tuple(ep["pred_pairs"][0].shape) == (1, 2048, 2) and ep["pred_pairs"][0].dtype == torch.int32
     assert not ep["pred_pairs"][0].is_cuda and tuple(ep["perm_matrices"][0].shape) == (1, 2048)
-    assert ep["invalid_gradient"] is False
+    assert bool(ep["invalid_gradient"]) is False          # read lazily from the device (deepsir_amd/model.py, _LazyFlag)
     agree = (ep["pred_pairs"][0][0, :, 1].numpy() == g["idx"][0, 0]).mean()
     assert agree > 0.99
     if all((ep["pred_pairs"][i][0, :, 1].numpy() == g["idx"][0, i]).all() for i in range(5)):
@@ -710,7 +710,7 @@ def test_register_screened_equals_exhaustive(tmp_path):
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
-    for name, extra in (("screened", {}), ("exhaustive", {"DSIR_NO_SCREEN": "1"})):
+    for name, extra in (("screened", {}), ("exhaustive", {"DSIR_TUNING": "1", "DSIR_NO_SCREEN": "1"})):
         out = str(tmp_path / f"{name}.npz")
         env = dict(os.environ, **extra)
         env.pop("DSIR_SCREEN_OVF_MIN", None)
