@@ -1,23 +1,24 @@
-// Attentive pooling (reference network/RandLANet.py:140-157) for the k = 16 layers of pyramid levels 1 / 2 (d = 64 / 128):
+// Attentive pooling (reference network/RandLANet.py:140-157) for the k = 16 layers of pyramid levels 0 - 2.  Levels 1 / 2 (d = 64 / 128):
 //   y[i][c] = sum_k softmax_k(S[k][c]) X[k][c],   X[k] = [ fN[nb(i,k)] ; E[i,k] ],   S[k] = fc X[k]
 // with the score GEMM split by linearity: S[k] = G[nb(i,k)] + W2 E[i,k], G = W1 fN a per-POINT GEMM made
-// beforehand.  Round 4: the previous kernels (pw_stream.hip EPI_ATT2) were bound by VALU issue - ~350 vector instructions per
-// point, most of them the cross-lane softmax butterflies of a 16 x 16 accumulator tile, gather address arithmetic and
-// operand plumbing (PMC: 58 % VALU + 30 % MFMA busy).  This kernel is organised around the ACCUMULATOR LAYOUT instead:
+// beforehand.  Round 4: the previous kernels (pw_stream.hip EPI_ATT2) spent ~350 vector instructions per point, most of them
+// the cross-lane softmax butterflies of a 16 x 16 accumulator tile, gather address arithmetic and operand plumbing (PMC: 58 %
+// VALU + 30 % MFMA busy).  This kernel is organised around the ACCUMULATOR LAYOUT instead:
 //   * a wave owns units of TWO points = 32 rows = one row tile of v_mfma_f32_32x32x16_f16.  A-row m carries neighbour
 //     k = 4 (m >> 3) + (m & 3) of point (m >> 2) & 1: the accumulator rows a lane holds - (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5),
 //     cdna_hip_programming.md section 3 - are then exactly the 16 neighbours of ONE point (lane half = point, register =
 //     neighbour).  The softmax over the neighbours and the weighted sum run in registers: no cross-lane instruction at all;
-//   * a lane's column is lane & 31: every gathered operand of the epilogue - G[nb][c], fN[nb][c] - is one dword load whose 32
-//     lanes read 128 contiguous bytes of the neighbour's row.  G and fN live in ONE row buffer gp = [G (d) | fN (d/2)] written
-//     by the per-point GEMM (its weight matrix carries an identity block, engine.hip::up_fc_p: fN x 1.0 is exact in the fp32
-//     MFMA), so one address per neighbour serves all three loads through immediate offsets;
+//   * a block owns 64 output columns; lane c = lane & 31 owns the ADJACENT pair 64 cb + 2 c + {0, 1} - tile t of the two MFMA
+//     column tiles is "column 2 c + t" (a column permutation costs nothing: it only selects the weight rows of the B fragment).
+//     Everything the epilogue gathers for one neighbour - the pair's G values and, for columns of the gathered-feature half, the
+//     pair's fN values - is then ONE 16-byte load: the per-point GEMM writes rows gp[point] = 32 lanes x [G0 G1 X0 X1] per
+//     column block (its weight matrix carries the permutation and an identity block, engine.hip::up_fc_p; fN x 1.0 is exact in
+//     the fp32 MFMA).  16 wide gathers per unit instead of 48 dword ones;
 //   * the contraction W2 E runs on the fp16 matrix pipe at fp32 accuracy (x = fp16(x) + fp16(x - fp16(x)), three MFMAs per
-//     product: agg_chain_h.hip); weights split at load (GemmArgs-style blob offsets);
+//     product: agg_chain_h.hip); weights split at load, B fragments in registers (d = 64) or in LDS (d = 128);
 //   * E (normalised: the producer's GroupNorm + LeakyReLU applied while the A operand is formed) reaches the epilogue's
-//     column layout through a wave-private LDS tile [32][KH + 8] (conflict-free dword reads);
+//     column layout through a wave-private LDS tile [32][KH + 8];
 //   * software pipeline: the next unit's neighbour indices and E rows are in flight during the current unit's epilogue.
-// A block owns 64 columns: the 32 of the gathered-feature half that start at 32 cb and the matching 32 of the enc half.
 #include "kernels.h"
 #include "device_utils.h"
 
@@ -41,12 +42,14 @@ template <int KH>   // enc channels per row = d / 2: 32 (level 1) or 64 (level 2
 __global__ __launch_bounds__(256) void att_pool_kernel(const AttPoolArgs p) {
   constexpr int KC = KH / 2;     // channels of its row a lane holds: [h KC, (h + 1) KC), 8 of them per k-step
   constexpr int NS = KH / 16;    // k-steps
-  constexpr int LD = KH + 8;     // LDS row stride in floats: rows 4 apart land 32 banks apart
-  constexpr int NCB = KH / 32;   // column blocks
-  constexpr uint32_t ROWB = 3u * KH * 4u;   // bytes per row of gp
+  constexpr int LD = KH + 8;     // LDS row stride in floats
+  constexpr int NCB = KH / 32;   // column blocks of 64 = d / 64
+  constexpr bool WLDS = KH > 32; // B fragments in LDS instead of registers (64 VGPRs at d = 128)
+  constexpr uint32_t ROWB = 4u * KH * 4u;   // bytes per row of gp: d / 64 blocks x 32 lanes x 4 floats
   __shared__ float s_sc[KH];
   __shared__ float s_sh[KH];
   __shared__ __attribute__((aligned(16))) float s_t[4][32 * LD];
+  __shared__ h8 s_w[WLDS ? 2 * NS * 2 * 64 : 1];   // [tile][k-step][high | low][lane]
 
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m = lane & 31, h = lane >> 5;
@@ -56,51 +59,60 @@ __global__ __launch_bounds__(256) void att_pool_kernel(const AttPoolArgs p) {
   const int cloud = wi / (p.grid_x * NCB);
   const int d = 2 * KH;
 
-  // GroupNorm (+ LeakyReLU) of the producer of E, per channel
-  for (int c = tid; c < KH; c += 256) {
-    float scale = 1.f, shift = 0.f;
-    if (p.enc_gn.stats) {
-      const int g = c / (KH / p.enc_gn.groups);
-      const double* st = p.enc_gn.stats + ((int64_t)cloud * p.enc_gn.groups + g) * kGnWords;
-      const double mean = gn_stat_get(st) * p.enc_gn.inv_count;
-      double var = gn_stat_get(st + 2) * p.enc_gn.inv_count - mean * mean;
-      var = var > 0.0 ? var : 0.0;
-      const double rstd = 1.0 / sqrt(var + 1e-5);
-      const double scd = (double)p.enc_gn.gamma[c] * rstd;
-      scale = (float)scd;
-      shift = (float)((double)p.enc_gn.beta[c] - mean * scd);
+  // GroupNorm (+ LeakyReLU) of the producer of E, per channel -> LDS.  A dependent chain (statistics load, fixed-point decode, fp64
+  // arithmetic) that opens every workgroup: it runs after the weight fragments and the first unit's loads have been issued.
+  auto stats_to_lds = [&]() {
+    for (int c = tid; c < KH; c += 256) {
+      float scale = 1.f, shift = 0.f;
+      if (p.enc_gn.stats) {
+        const int g = c / (KH / p.enc_gn.groups);
+        const double* st = p.enc_gn.stats + ((int64_t)cloud * p.enc_gn.groups + g) * kGnWords;
+        const double mean = gn_stat_get(st) * p.enc_gn.inv_count;
+        double var = gn_stat_get(st + 2) * p.enc_gn.inv_count - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        const double rstd = gn_rstd(var);
+        const double scd = (double)p.enc_gn.gamma[c] * rstd;
+        scale = (float)scd;
+        shift = (float)((double)p.enc_gn.beta[c] - mean * scd);
+      }
+      s_sc[c] = scale;
+      s_sh[c] = shift;
     }
-    s_sc[c] = scale;
-    s_sh[c] = shift;
-  }
-  __syncthreads();
+  };
 
-  // B fragments: tile 0 = columns 32 cb + m of the gathered-feature half, tile 1 = the same of the enc half; the k index of step s,
-  // lane half h, element j is channel h KC + 8 s + j of E (any bijection serves as long as A and B agree: this one makes a
-  // lane's A chunk contiguous)
+  // B fragments: tile t = output columns 64 cb + 2 m + t; the k index of step s, lane half h, element j is channel h KC + 8 s + j
+  // of E (any bijection serves as long as A and B agree: this one makes a lane's A chunk contiguous)
+  const int col0 = 64 * cb + 2 * m;
   const _Float16* Wh = reinterpret_cast<const _Float16*>(p.Wh);
   const _Float16* Wl = reinterpret_cast<const _Float16*>(p.Wl);
-  h8 wh[2][NS], wl[2][NS];
+  h8 wh[WLDS ? 1 : 2][WLDS ? 1 : NS], wl[WLDS ? 1 : 2][WLDS ? 1 : NS];
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
-    const int col = t * KH + 32 * cb + m;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-      const int64_t o = (int64_t)col * p.ldw + p.wcol0 + h * KC + 8 * s;
-      wh[t][s] = *reinterpret_cast<const h8*>(Wh + o);
-      wl[t][s] = *reinterpret_cast<const h8*>(Wl + o);
+      const int64_t o = (int64_t)(col0 + t) * p.ldw + p.wcol0 + h * KC + 8 * s;
+      if (WLDS) {
+        if (w == 0) {
+          s_w[((t * NS + s) * 2 + 0) * 64 + lane] = *reinterpret_cast<const h8*>(Wh + o);
+          s_w[((t * NS + s) * 2 + 1) * 64 + lane] = *reinterpret_cast<const h8*>(Wl + o);
+        }
+      } else {
+        wh[t][s] = *reinterpret_cast<const h8*>(Wh + o);
+        wl[t][s] = *reinterpret_cast<const h8*>(Wl + o);
+      }
     }
   }
+
   const float slope = p.enc_act ? 0.2f : 1.f;
   const int pm = (m >> 2) & 1, km = ((m >> 3) << 2) | (m & 3);      // the (point, neighbour) of this lane's A row
   const float* encb = p.enc + cloud * p.enc_cs + h * KC;
   const int32_t* nbb = p.neigh + cloud * p.neigh_cs;
-  const float* gpb = p.gp + cloud * p.gp_cs;      // [G columns of the gathered-feature half | of the enc half | fN]
-  const float* gpbE = gpb + KH;
-  const float* gpbX = gpb + 2 * KH;
+  const float* gpb = p.gp + cloud * p.gp_cs;
   float* Yb = p.Y + cloud * p.y_cs;
   float* T = &s_t[w][0];
-  const uint32_t coff = 4u * (uint32_t)(32 * cb + m);
+  const uint32_t coff = 16u * (uint32_t)(32 * cb + m);     // this lane's [G0 G1 X0 X1] inside a row of gp
+  const bool fhalf = col0 < KH;                            // its column pair lies in the gathered-feature half
+  const int tcol = fhalf ? 0 : col0 - KH;                  // ... else: the pair's columns in E
 
   const int units = (p.n + 1) >> 1;
   const int nw = p.grid_x * 4;
@@ -125,17 +137,14 @@ __global__ __launch_bounds__(256) void att_pool_kernel(const AttPoolArgs p) {
     }
   };
   if (u < units) load_unit(u);
+  stats_to_lds();
+  __syncthreads();
   while (u < units) {
-    // ---- gathers of the first tile's epilogue (scores' G half and the pooled features): issued first, consumed last.
-    // One 32-bit offset per neighbour, wave-uniform bases: global_load_dword v, v_off, s[base]
-    uint32_t off[16];
-    float gF[16], xF[16];
+    // ---- the epilogue's gathers, one 16-byte load per neighbour: issued first, consumed last
+    float4 g4[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      off[i] = __umul24((uint32_t)nb[i], ROWB) + coff;
-      gF[i] = ld_f32(gpb, off[i]);
-      xF[i] = ld_f32(gpbX, off[i]);
-    }
+    for (int i = 0; i < 16; ++i)
+      g4[i] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(gpb) + (__umul24((uint32_t)nb[i], ROWB) + coff));
     // ---- A operand: normalise (GroupNorm + LeakyReLU of the producer), keep fp32 for the pooled operand, split for the MFMAs
     h8 ah[NS], al[NS];
 #pragma unroll
@@ -163,24 +172,22 @@ __global__ __launch_bounds__(256) void att_pool_kernel(const AttPoolArgs p) {
       for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], wh[t][s], acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], wl[t][s], acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], wh[t][s], acc[t], 0, 0, 0);
+        const h8 bh = WLDS ? s_w[((t * NS + s) * 2 + 0) * 64 + lane] : wh[WLDS ? 0 : t][WLDS ? 0 : s];
+        const h8 bl = WLDS ? s_w[((t * NS + s) * 2 + 1) * 64 + lane] : wl[WLDS ? 0 : t][WLDS ? 0 : s];
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], bh, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bl, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bh, acc[t], 0, 0, 0);
       }
     }
     __builtin_amdgcn_wave_barrier();
-    // ---- the second tile's G rows: in flight during the first tile's epilogue
-    float gE[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) gE[i] = ld_f32(gpbE, off[i]);
-    // ---- epilogue: register i of the accumulator = neighbour i of point (lane >> 5), column lane & 31
+    // ---- epilogue: register i of the accumulator = neighbour i of point (lane >> 5), columns col0 + {0, 1}
     constexpr float L2E = 1.44269504088896340736f;
     float y[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       float sc[16];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) sc[i] = acc[t][i] + (t == 0 ? gF[i] : gE[i]);
+      for (int i = 0; i < 16; ++i) sc[i] = acc[t][i] + (t == 0 ? g4[i].x : g4[i].y);
       float mx = fmaxf(sc[0], sc[1]);
 #pragma unroll
       for (int i = 2; i < 16; i += 2) mx = fmaxf(mx, fmaxf(sc[i], sc[i + 1]));     // v_max3_f32
@@ -190,17 +197,166 @@ __global__ __launch_bounds__(256) void att_pool_kernel(const AttPoolArgs p) {
       for (int i = 0; i < 16; ++i) {
         // softmax numerator e^(s - max) = 2^(s log2e - max log2e): one fma + v_exp_f32 (1 ulp), arguments <= 0 up to rounding
         const float e = __builtin_amdgcn_exp2f(fmaf(sc[i], L2E, ml));
-        const float x = t == 0 ? xF[i] : T[(8 * (i >> 2) + 4 * h + (i & 3)) * LD + 32 * cb + m];
+        const float xe = T[(8 * (i >> 2) + 4 * h + (i & 3)) * LD + tcol + t];
+        const float x = fhalf ? (t == 0 ? g4[i].z : g4[i].w) : xe;
         se += e;
         o = fmaf(x, e, o);
       }
       y[t] = o * __builtin_amdgcn_rcpf(se);      // se >= ~1: the max term contributes 2^0
     }
-    if (pt < p.n) {
-      st_f32(Yb, 4u * ((uint32_t)pt * (uint32_t)d) + coff, y[0]);
-      st_f32(Yb, 4u * ((uint32_t)pt * (uint32_t)d + (uint32_t)KH) + coff, y[1]);
+    if (pt < p.n) *reinterpret_cast<float2*>(Yb + (uint32_t)pt * (uint32_t)d + (uint32_t)col0) = make_float2(y[0], y[1]);
+    __builtin_amdgcn_wave_barrier();
+    u = un;
+  }
+}
+
+
+// ---------------------------------------------------------------- level 0 (d = 16): the unsplit form, fc [gather(f) ; enc]
+// The score GEMM contracts all 16 channels [fN[nb] (8) ; E (8)] (splitting it by linearity would gather 64 more bytes per row
+// than it saves).  Same organisation as above with one more twist, because only 16 of a 32-wide MFMA tile's columns exist:
+// a unit is FOUR points = two row tiles A (points 4u, 4u + 1) and B (4u + 2, 4u + 3), and both accumulate into ONE
+// accumulator - tile A against the weights placed in columns 0 .. 15 of the B operand (zeros elsewhere), tile B against the
+// same weights placed in columns 16 .. 31.  C[m][c < 16] is then tile A's result and C[m][c >= 16] tile B's: every lane of
+// the wave owns (point, column) work in the epilogue, no accumulator is moved between lanes.  Lane half h = 0 forms the
+// gathered-feature part of an A row (one index load, one 32-byte row gather, the producer's GroupNorm + LeakyReLU), h = 1
+// the E part; the normalised values double as the pooled operand through the LDS tile.  Round 3's kernel (pw_stream.hip
+// EPI_ATT, exact-fp32 16 x 16 x 4 MFMAs) ran the matrix pipe 79 % and the vector ALU 57 % busy; this one issues 6 fp16 MFMAs
+// (192 cycles) and ~250 vector instructions per four points.
+__global__ __launch_bounds__(256) void att_pool16_kernel(const AttPool16Args p) {
+  constexpr int LD = 20;                  // LDS row stride (floats): rows 4 apart land 16 banks apart
+  constexpr int TB = 32 * LD + 32;        // tile B's offset: 32 banks away from tile A
+  __shared__ float s_sc[16];
+  __shared__ float s_sh[16];
+  __shared__ __attribute__((aligned(16))) float s_t[4][TB + 32 * LD];
+
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 31, h = lane >> 5;
+  const int wi = xcd_contiguous(blockIdx.x, gridDim.x);
+  const int bx = wi % p.grid_x;
+  const int cloud = wi / p.grid_x;
+
+  float sc[8], sh[8];
+  const float slope = (h ? p.enc_act : p.f_act) ? 0.2f : 1.f;
+
+  // B fragments: lane (c = m, h) holds W[col][8 h + j]; tile A's weights live in columns 0 .. 15, tile B's in 16 .. 31
+  h8 whA, wlA, whB, wlB;
+  {
+    const _Float16* Wh = reinterpret_cast<const _Float16*>(p.Wh);
+    const _Float16* Wl = reinterpret_cast<const _Float16*>(p.Wl);
+    const int col = m & 15;
+    const h8 vh = *reinterpret_cast<const h8*>(Wh + col * p.ldw + 8 * h);
+    const h8 vl = *reinterpret_cast<const h8*>(Wl + col * p.ldw + 8 * h);
+    h8 z;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) z[j] = (_Float16)0.f;
+    whA = m < 16 ? vh : z; wlA = m < 16 ? vl : z;
+    whB = m < 16 ? z : vh; wlB = m < 16 ? z : vl;
+  }
+  const int pm = (m >> 2) & 1, km = ((m >> 3) << 2) | (m & 3);      // the (point, neighbour) of this lane's A row
+  const float* fb = p.f + cloud * p.f_cs;
+  const float* eb = p.enc + cloud * p.enc_cs;
+  const int32_t* nbb = p.neigh + cloud * p.neigh_cs;
+  float* Yb = p.Y + cloud * p.y_cs;
+  float* T = &s_t[w][0];
+  const int etile = m >> 4, ecol = m & 15;                          // the epilogue's (tile, column) of this lane
+
+  const int units = (p.n + 3) >> 2;
+  const int nw = p.grid_x * 4;
+  int u = bx * 4 + w;
+
+  // pipeline: rows of unit u + nw and indices of unit u + 2 nw are in flight while unit u is computed
+  auto point_of = [&](int uu, int tile) { return min(4 * uu + 2 * tile + pm, p.n - 1); };
+  auto load_idx = [&](int uu, int (&j)[2]) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) j[t] = nbb[(uint32_t)point_of(uu, t) * 16u + (uint32_t)km];
+  };
+  auto load_rows = [&](int uu, const int (&j)[2], float (&a)[2][8]) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const float* src = h ? eb + ((uint32_t)(point_of(uu, t) * 16 + km)) * 8u : fb + (uint32_t)j[t] * (uint32_t)p.f_ld;
+      const float4 v0 = *reinterpret_cast<const float4*>(src), v1 = *reinterpret_cast<const float4*>(src + 4);
+      a[t][0] = v0.x; a[t][1] = v0.y; a[t][2] = v0.z; a[t][3] = v0.w; a[t][4] = v1.x; a[t][5] = v1.y; a[t][6] = v1.z; a[t][7] = v1.w;
+    }
+  };
+  float a[2][8], an[2][8];
+  int jn[2] = {0, 0};
+  if (u < units) {
+    int j0[2];
+    load_idx(u, j0);
+    load_rows(u, j0, a);
+    if (u + nw < units) load_idx(u + nw, jn);
+  }
+  // GroupNorm scale / shift of both operand halves: decoded while the first unit's loads are in flight
+  if (tid < 16) {
+    const GnRef& g = tid < 8 ? p.f_gn : p.enc_gn;
+    const int c = tid & 7;
+    float scale = 1.f, shift = 0.f;
+    if (g.stats) {
+      const int grp = c / (8 / g.groups);
+      const double* st = g.stats + ((int64_t)cloud * g.groups + grp) * kGnWords;
+      const double mean = gn_stat_get(st) * g.inv_count;
+      double var = gn_stat_get(st + 2) * g.inv_count - mean * mean;
+      var = var > 0.0 ? var : 0.0;
+      const double rstd = gn_rstd(var);
+      const double scd = (double)g.gamma[c] * rstd;
+      scale = (float)scd;
+      shift = (float)((double)g.beta[c] - mean * scd);
+    }
+    s_sc[tid] = scale;
+    s_sh[tid] = shift;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { sc[j] = s_sc[8 * h + j]; sh[j] = s_sh[8 * h + j]; }
+  while (u < units) {
+    const int un = u + nw;
+    if (un < units) {
+      load_rows(un, jn, an);
+      if (un + nw < units) load_idx(un + nw, jn);
+    }
+    // ---- A operands of both tiles: normalise, keep fp32 in LDS for the pooled operand, split for the MFMAs
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float v = fmaf(a[t][j], sc[j], sh[j]);
+        a[t][j] = fmaxf(v, slope * v);
+      }
+      float* row = &T[t * TB + m * LD + 8 * h];
+      *reinterpret_cast<float4*>(row) = make_float4(a[t][0], a[t][1], a[t][2], a[t][3]);
+      *reinterpret_cast<float4*>(row + 4) = make_float4(a[t][4], a[t][5], a[t][6], a[t][7]);
+      h8 ah, al;
+      split8f(a[t], ah, al);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, t ? whB : whA, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, t ? wlB : wlA, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, t ? whB : whA, acc, 0, 0, 0);
     }
     __builtin_amdgcn_wave_barrier();
+    // ---- epilogue: register i = neighbour i of point 4 u + 2 etile + h, column ecol
+    constexpr float L2E = 1.44269504088896340736f;
+    float mx = fmaxf(acc[0], acc[1]);
+#pragma unroll
+    for (int i = 2; i < 16; i += 2) mx = fmaxf(mx, fmaxf(acc[i], acc[i + 1]));
+    const float ml = -mx * L2E;
+    float se = 0.f, o = 0.f;
+    const float* Tc = &T[etile * TB + 4 * h * LD + ecol];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float e = __builtin_amdgcn_exp2f(fmaf(acc[i], L2E, ml));
+      const float x = Tc[(8 * (i >> 2) + (i & 3)) * LD];
+      se += e;
+      o = fmaf(x, e, o);
+    }
+    const int pt = 4 * u + 2 * etile + h;
+    if (pt < p.n) Yb[(uint32_t)pt * 16u + (uint32_t)ecol] = o * __builtin_amdgcn_rcpf(se);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[t][j] = an[t][j];
     u = un;
   }
 }
@@ -231,14 +387,37 @@ bool launch_att_pool(const AttPoolArgs& a, hipStream_t st) {
   if (!a.Wh || !a.Wl || !a.enc || !a.gp || !a.neigh || !a.Y) return false;
   if ((a.ldw % 8) != 0 || (a.wcol0 % 8) != 0 || (reinterpret_cast<uintptr_t>(a.Wh) % 16) != 0 || (reinterpret_cast<uintptr_t>(a.Wl) % 16) != 0) return false;
   if ((reinterpret_cast<uintptr_t>(a.enc) % 16) != 0 || (a.enc_cs % 4) != 0 || (reinterpret_cast<uintptr_t>(a.neigh) % 16) != 0 || (a.neigh_cs % 4) != 0) return false;
+  if ((reinterpret_cast<uintptr_t>(a.gp) % 16) != 0 || (a.gp_cs % 4) != 0 || (reinterpret_cast<uintptr_t>(a.Y) % 8) != 0 || (a.y_cs % 2) != 0) return false;
   if (a.enc_gn.stats && (a.KH % a.enc_gn.groups) != 0) return false;
-  // 32-bit byte offsets inside a cloud
-  if ((int64_t)a.n * 16 * a.KH * 4 >= ((int64_t)1 << 32) || (int64_t)a.n * 3 * a.KH * 4 >= ((int64_t)1 << 32)) return false;
+  // 24-bit neighbour indices and 32-bit byte offsets inside a cloud
+  if (a.n >= (1 << 24) || (int64_t)a.n * 16 * a.KH * 4 >= ((int64_t)1 << 32) || (int64_t)a.n * 4 * a.KH * 4 >= ((int64_t)1 << 32)) return false;
   switch (a.KH) {
     case 32: launch_k<32>(a, st); return true;
     case 64: launch_k<64>(a, st); return true;
     default: return false;
   }
+}
+
+bool launch_att_pool16(const AttPool16Args& a, hipStream_t st) {
+  if (a.n <= 0 || a.clouds <= 0) return true;
+  if (!a.Wh || !a.Wl || !a.f || !a.enc || !a.neigh || !a.Y) return false;
+  if ((a.ldw % 8) != 0 || (reinterpret_cast<uintptr_t>(a.Wh) % 16) != 0 || (reinterpret_cast<uintptr_t>(a.Wl) % 16) != 0) return false;
+  if ((reinterpret_cast<uintptr_t>(a.f) % 16) != 0 || (a.f_cs % 4) != 0 || (a.f_ld % 4) != 0 || (reinterpret_cast<uintptr_t>(a.enc) % 16) != 0 || (a.enc_cs % 4) != 0) return false;
+  if ((a.f_gn.stats && (8 % a.f_gn.groups) != 0) || (a.enc_gn.stats && (8 % a.enc_gn.groups) != 0)) return false;
+  if ((int64_t)a.n * 16 * 8 * 4 >= ((int64_t)1 << 32)) return false;
+  const int units = (a.n + 3) / 4;
+  int blocks = (units + 31) / 32;       // ~8 units per wave; no cross-workgroup reduction: the grid may follow the launch size
+  const int64_t total = (int64_t)blocks * a.clouds;
+  if (total < 512) {
+    const int want = (int)((512 + (int64_t)a.clouds - 1) / (int64_t)a.clouds), most = (units + 3) / 4;
+    const int nb = want < most ? want : most;
+    if (nb > blocks) blocks = nb;
+  }
+  if (blocks < 1) blocks = 1;
+  AttPool16Args b = a;
+  b.grid_x = blocks;
+  hipLaunchKernelGGL(att_pool16_kernel, dim3((unsigned)((int64_t)blocks * a.clouds)), dim3(256), 0, st, b);
+  return true;
 }
 
 }  // namespace dsir

@@ -65,45 +65,56 @@ __device__ __forceinline__ float exp_neg(float x) {
 }
 
 // ------------------------------------------------------------------ GroupNorm statistics across workgroups: DETERMINISTIC
-// The per-(cloud, group) sums of x and x^2 meet in INTEGER atomics: every contribution v (a workgroup's or a wave's partial
-// sum, fp64) is split by a pure function into floor(v) and the 40-bit fixed-point fraction (v - floor(v)) 2^40 - both exact
-// integers - which are added to two 64-bit counters.  Integer addition is associative and commutative, so the totals, hence
-// every scale / shift derived from them, do not depend on the order in which workgroups arrive (a floating-point atomicAdd
-// does).  Absolute error per contribution <= 2^-41, i.e. <= 2^-41 on a mean or a variance (contributions <= elements):
-// eight orders of magnitude below GroupNorm's eps = 1e-5.  Range |v| < 9e18; the fractions of up to 2^20 contributions
-// stay below 2^60.  A non-finite or out-of-range contribution sets bit 63 of the fraction counter: the statistic then reads
-// NaN, as the floating-point sum did.  Slot layout per (cloud, group), kGnWords 8-byte words: {floor, fraction} of the sum
-// of x, then of the sum of x^2.  Zeroed by the host before the producing launch (one memset per registration).
-// One word of a contribution: limb 0 = floor(v), limb 1 = the 40-bit fraction (both as the 64-bit pattern that is added).
-__device__ __forceinline__ unsigned long long gn_stat_limb(double v, int limb) {
-  const double f = floor(v);
-  return limb ? (unsigned long long)__double2ll_rn((v - f) * 1099511627776.0)   // 2^40; v - f is exact, in [0, 1)
-              : (unsigned long long)(long long)f;
+// The per-(cloud, group) sums of x and x^2 meet across workgroups in atomics whose result cannot depend on the arrival order:
+// every contribution v (a workgroup's partial sum, fp64) is split by a pure function into two INTEGER-VALUED doubles,
+//     L1 = rint(v 2^-24)          and          L0 = rint((v - L1 2^24) 2^16),        v = L1 2^24 + L0 2^-16 + r, |r| <= 2^-17,
+// which are added to two fp64 counters with the hardware's fp64 atomic add.  |L0| <= 2^39 and (for |v| < 2^64) |L1| < 2^40, so
+// with at most 2^12 contributions per statistic every partial sum stays an integer below 2^53 - where IEEE addition is EXACT,
+// hence associative and commutative: the totals are the same bits under every order (an atomic add of the raw fp64 partial
+// sums, as up to round 3, rounds differently under different orders).  Integer counters do the same but gfx950 has no
+// conversion between fp64 and 64-bit integers; decoding them at the head of every consumer workgroup cost 2 % of the step,
+// this form costs a multiply-add.  Absolute error per contribution <= 2^-17; a layer's mean and variance carry at most
+// (workgroups x 2^-17) / elements <= 6e-9 - eps of GroupNorm is 1e-5.  A non-finite contribution makes L1 non-finite and the
+// statistic NaN / Inf, as the plain sum did.  Slot layout per (cloud, group), kGnWords doubles: {L1, L0} sums of x, then of
+// x^2; zeroed by the host before the producing launch (one memset per registration).
+__device__ __forceinline__ double gn_stat_limb(double v, int limb) {
+  const double l1 = rint(v * 0x1p-24);
+  return limb ? rint(fma(-l1, 0x1p24, v) * 0x1p16) : l1;
 }
 // A workgroup's contribution to the statistics of the column range [n0, n0 + ncols) it owns, from its per-column fp32 partial
 // sums part[col * 2 + {0: sum x, 1: sum x^2}] (LDS, complete and barrier-separated from this call).  Atomic INSTRUCTIONS are
 // what the chip rations (about one wave-instruction per 50 ns per CU, MI355X_MICROARCH.md), so the whole contribution - every
-// group the range touches x {sum, sum of squares} x {floor, fraction} - leaves in ONE instruction: lane = (group, statistic,
-// limb).  Columns of a group are added in ascending order, in fp64.  Call with all threads of the block.
+// group the range touches x {sum, sum of squares} x {L1, L0} - leaves in one instruction per wave that holds any of it.
+// The order of every addition is fixed by the column index alone.  Call with ALL 256 threads of the block.
 __device__ __forceinline__ void gn_block_commit(const float* part, int n0, int ncols, int gw, double* stats_cloud) {
   const int g0 = n0 / gw, ng = (n0 + ncols - 1) / gw - g0 + 1;
-  const int t = threadIdx.x;
-  if (t < ng * 4) {
-    const int g = g0 + (t >> 2), stat = (t >> 1) & 1, limb = t & 1;
+  // 16 lanes per (group, statistic): lane j adds columns j, j + 16, ... of the group in ascending order, then a fixed butterfly
+  // over the 16 lanes (a serial loop over up to 64 columns was the longest dependent chain of a workgroup's tail)
+  const int t = threadIdx.x, j = t & 15;
+  for (int q = t >> 4; q < ((ng * 2 + 15) & ~15); q += 16) {   // q = (group, statistic); one trip unless a range holds > 8 groups
+    const bool live = q < ng * 2;
+    const int g = g0 + (q >> 1), stat = q & 1;
     const int c0 = max(g * gw, n0) - n0, c1 = min((g + 1) * gw, n0 + ncols) - n0;
     double d = 0.0;
-    for (int c = c0; c < c1; ++c) d += (double)part[c * 2 + stat];
-    unsigned long long* s = reinterpret_cast<unsigned long long*>(stats_cloud) + (int64_t)g * kGnWords + 2 * stat + limb;
-    if (fabs(d) < 9.0e18) atomicAdd(s, gn_stat_limb(d, limb));
-    else if (limb) atomicOr(s, 1ull << 63);          // non-finite or out of range: the statistic reads NaN
+    if (live)
+      for (int c = c0 + j; c < c1; c += 16) d += (double)part[c * 2 + stat];
+    d += __shfl_xor(d, 1); d += __shfl_xor(d, 2); d += __shfl_xor(d, 4); d += __shfl_xor(d, 8);
+    if (live && j < 2)                                       // lanes 0 / 1 of the quad carry the two limbs
+      unsafeAtomicAdd(stats_cloud + (int64_t)g * kGnWords + 2 * stat + j, gn_stat_limb(d, j));   // global_atomic_add_f64, integer-valued operands
   }
 }
-__device__ __forceinline__ double gn_stat_get(const double* slot) {
-  const long long hi = reinterpret_cast<const long long*>(slot)[0];
-  const unsigned long long lo = reinterpret_cast<const unsigned long long*>(slot)[1];
-  if (lo >> 63) return __longlong_as_double(0x7ff8000000000000ll);
-  return (double)hi + (double)lo * (1.0 / 1099511627776.0);
+// 1 / sqrt(var + eps) of GroupNorm (eps = 1e-5, RandLANet.py:93): the hardware's v_rsq_f64 seed (about 2^-27 relative) and two
+// Newton steps in fp64 (error squared twice: far below 2^-52), a dozen instructions instead of the ~40 of a correctly rounded
+// square root followed by a correctly rounded division - this chain opens EVERY consumer workgroup.  The scale / shift derived
+// from it are rounded to fp32 afterwards.
+__device__ __forceinline__ double gn_rstd(double var) {
+  const double v = var + 1e-5;
+  double r = __builtin_amdgcn_rsq(v);
+  r = fma(r, fma(-0.5 * v * r, r, 0.5), r);
+  r = fma(r, fma(-0.5 * v * r, r, 0.5), r);
+  return r;
 }
+__device__ __forceinline__ double gn_stat_get(const double* slot) { return fma(slot[0], 0x1p24, slot[1] * 0x1p-16); }
 
 // Butterfly steps across the four 16-lane rows of a wave with the gfx950 VALU lane swaps instead of ds_bpermute
 // (no LDS round trip, no lgkmcnt wait).  v_permlane16_swap exchanges the odd rows of its first operand with the

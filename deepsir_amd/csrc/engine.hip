@@ -312,17 +312,24 @@ size_t up_fc_g(Uploader& u, const HostParam& fc, int d) {
   return u.put(w);
 }
 
-// att_pool.hip (d = 64, 128): the per-point GEMM in front of the pooling writes ONE row per point, [ G = W1 fN (d columns, natural
-// order) | fN (d/2 columns) ]: its weight matrix is W1 = fc[:, :d/2] with an identity block underneath.  fN x 1.0 + zeros is
-// exact in the fp32 MFMA, so the second part is the normalised feature itself - the pooling kernel then gathers scores and
-// features of a neighbour through one address.
+// att_pool.hip (d = 64, 128): the per-point GEMM in front of the pooling writes ONE row per point in the pooling kernel's gather
+// order: per 64-column block cb and lane c (0 .. 31) the four floats [G[col], G[col + 1], X0, X1], col = 64 cb + 2 c, G = W1 fN
+// (W1 = fc[:, :d/2]) and X = fN[col], fN[col + 1] where the column pair lies in the gathered-feature half (col < d/2), else 0.
+// Its weight matrix is therefore W1's rows in that order with identity / zero rows in between: fN x 1.0 + zeros is exact in
+// the fp32 MFMA, so X is the normalised feature itself - everything the pooling gathers of a neighbour is one 16-byte load.
 size_t up_fc_p(Uploader& u, const HostParam& fc, int d) {
   if (d != 64 && d != 128) return 0;
   const int h = d / 2;
-  std::vector<float> w((size_t)(d + h) * h, 0.f);
-  for (int r = 0; r < d; ++r)
-    for (int k = 0; k < h; ++k) w[(size_t)r * h + k] = fc.data[(size_t)r * d + k];
-  for (int k = 0; k < h; ++k) w[(size_t)(d + k) * h + k] = 1.f;
+  std::vector<float> w((size_t)(2 * d) * h, 0.f);
+  for (int cb = 0; cb < d / 64; ++cb)
+    for (int c = 0; c < 32; ++c) {
+      const int col = 64 * cb + 2 * c;
+      const size_t r0 = (size_t)(128 * cb + 4 * c);
+      for (int t = 0; t < 2; ++t) {
+        for (int k = 0; k < h; ++k) w[(r0 + t) * h + k] = fc.data[(size_t)(col + t) * d + k];
+        if (col + t < h) w[(r0 + 2 + t) * h + (col + t)] = 1.f;
+      }
+    }
   return u.put(w);
 }
 
@@ -458,18 +465,19 @@ struct Sched {
     y.C = w.d; y.rows = n;
     static const bool no_att2 = tuning_flag("DSIR_NO_ATT2");   // A/B switch
     if (!no_att2 && att_pool_enabled() && w.fc_p && c->dweights16 && f.C * 2 == w.d && enc.C * 2 == w.d && !(s2 && s2_mode)) {
-      // att_pool.hip: gp = [W1 fN | fN] per point (exact-fp32 MFMA GEMM), then two points per wave with the softmax in registers
+      // att_pool.hip: gp = the scores' G half and the features in the pooling's gather order (exact-fp32 MFMA GEMM, up_fc_p), then
+      // two points per wave with the softmax in registers
       const int h = w.d / 2;
-      float* gp = c->ws.get<float>((size_t)clouds * n * 3 * h);
+      float* gp = c->ws.get<float>((size_t)clouds * n * 4 * h);
       if (c->ws.overflow) return y;
       GemmArgs g;
       g.amode = A_SEGS; g.nseg = 1; g.seg[0] = seg_of(f);
-      g.W = w.fc_p; g.ldw = h; g.bias = nullptr; g.Cin = h; g.Cout = 3 * h; g.M = n; g.clouds = clouds;
-      g.epi = EPI_LINEAR; g.Y = gp; g.y_cloud_stride = (int64_t)n * 3 * h; g.ldy = 3 * h;
+      g.W = w.fc_p; g.ldw = h; g.bias = nullptr; g.Cin = h; g.Cout = 4 * h; g.M = n; g.clouds = clouds;
+      g.epi = EPI_LINEAR; g.Y = gp; g.y_cloud_stride = (int64_t)n * 4 * h; g.ldy = 4 * h;
       if (launch_pw_stream(g, st)) {
         AttPoolArgs a;
         a.enc = enc.p; a.enc_cs = (int64_t)enc.rows * enc.C; a.enc_gn = enc.gn; a.enc_act = enc.act;
-        a.gp = gp; a.gp_cs = (int64_t)n * 3 * h; a.neigh = neigh; a.neigh_cs = neigh_cs;
+        a.gp = gp; a.gp_cs = (int64_t)n * 4 * h; a.neigh = neigh; a.neigh_cs = neigh_cs;
         const size_t off = (size_t)(w.fc - c->dweights);
         a.Wh = c->dweights16 + off; a.Wl = c->dweights16 + c->nweights + off; a.ldw = w.d; a.wcol0 = h;
         a.Y = y.p; a.y_cs = (int64_t)n * w.d; a.n = n; a.clouds = clouds; a.KH = h;
@@ -496,6 +504,17 @@ struct Sched {
       split_of(a2);
       // G's column order is the consumer's (up_fc_g): d <= 128 belongs to pw_stream.hip, d = 256 to pw_tile.hip
       if (w.d <= 128 ? launch_pw_stream(a2, st) : launch_pw_tile(a2, st)) return y;
+    }
+    if (att_pool_enabled() && w.d == 16 && f.C == 8 && enc.C == 8 && c->dweights16 && w.fc >= c->dweights && w.fc < c->dweights + c->nweights) {
+      // att_pool.hip, level 0: four points per wave, fp16-split scores, softmax in registers
+      AttPool16Args a;
+      a.f = f.p; a.f_cs = (int64_t)f.rows * f.C; a.f_ld = f.C; a.f_gn = f.gn; a.f_act = f.act;
+      a.enc = enc.p; a.enc_cs = (int64_t)enc.rows * enc.C; a.enc_gn = enc.gn; a.enc_act = enc.act;
+      a.neigh = neigh; a.neigh_cs = neigh_cs;
+      const size_t off = (size_t)(w.fc - c->dweights);
+      a.Wh = c->dweights16 + off; a.Wl = c->dweights16 + c->nweights + off; a.ldw = w.d;
+      a.Y = y.p; a.y_cs = (int64_t)n * w.d; a.n = n; a.clouds = clouds;
+      if (!c->ws.overflow && launch_att_pool16(a, st)) return y;
     }
     GemmArgs a;
     a.amode = A_SEGS; a.nseg = 2;

@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void head_mlp_kernel(const HeadArgs p) {
       const double mean = gn_stat_get(st) * s.gn.inv_count;
       double var = gn_stat_get(st + 2) * s.gn.inv_count - mean * mean;
       var = var > 0.0 ? var : 0.0;
-      const double rstd = 1.0 / sqrt(var + 1e-5);
+      const double rstd = gn_rstd(var);
       const double scd = (double)s.gn.gamma[tid] * rstd;
       scale = (float)scd;
       shift = (float)((double)s.gn.beta[tid] - mean * scd);

@@ -21,7 +21,7 @@ inline long long tuning_int(const char* name, long long dflt) { const char* e = 
 constexpr int kGnWords = 4;   // 8-byte words per (cloud, group) statistics slot: device_utils.h, gn_block_commit / gn_stat_get
 #endif
 struct GnRef {
-  const double* stats;   // [clouds][groups][kGnWords] (integer counters, see device_utils.h); nullptr => no normalisation
+  const double* stats;   // [clouds][groups][kGnWords] (two integer-valued fp64 limbs per sum, device_utils.h); nullptr => no normalisation
   const float* gamma;    // [C]
   const float* beta;     // [C]
   int groups;
@@ -104,7 +104,7 @@ struct AttPoolArgs {
   int64_t enc_cs = 0;
   GnRef enc_gn = {nullptr, nullptr, nullptr, 0, 0.0};   // its lazy GroupNorm
   int enc_act = 1;                   // LeakyReLU(0.2) after it
-  const float* gp = nullptr;         // [clouds][n][3 KH] = [ G = W1 fN (2 KH) | fN (KH) ]: the per-point GEMM with the identity block
+  const float* gp = nullptr;         // [clouds][n][4 KH]: per 64-column block and lane c: [G[col], G[col+1], X0, X1], col = 64 cb + 2 c (engine.hip, up_fc_p)
   int64_t gp_cs = 0;
   const int32_t* neigh = nullptr;    // [clouds][n][16]
   int64_t neigh_cs = 0;
@@ -117,6 +117,25 @@ struct AttPoolArgs {
   int grid_x = 0;                    // filled by the launcher
 };
 bool launch_att_pool(const AttPoolArgs& a, hipStream_t st);   // false => outside the envelope (caller takes the EPI_ATT2 kernels)
+// level 0 (d = 16), unsplit: scores = fc [gather(f) ; E] with both halves 8 channels wide; four points per wave
+struct AttPool16Args {
+  const float* f = nullptr;          // [clouds][n][f_ld], 8 channels used: the features that are gathered (raw conv outputs)
+  int64_t f_cs = 0; int f_ld = 8;
+  GnRef f_gn = {nullptr, nullptr, nullptr, 0, 0.0}; int f_act = 1;
+  const float* enc = nullptr;        // E [clouds][n * 16][8]
+  int64_t enc_cs = 0;
+  GnRef enc_gn = {nullptr, nullptr, nullptr, 0, 0.0}; int enc_act = 1;
+  const int32_t* neigh = nullptr;    // [clouds][n][16]
+  int64_t neigh_cs = 0;
+  const void* Wh = nullptr;          // fp16 split of fc [16][ldw]
+  const void* Wl = nullptr;
+  int ldw = 16;
+  float* Y = nullptr;                // [clouds][n][16]
+  int64_t y_cs = 0;
+  int n = 0, clouds = 0;
+  int grid_x = 0;                    // filled by the launcher
+};
+bool launch_att_pool16(const AttPool16Args& a, hipStream_t st);
 
 // mlp_out + fc_label fused (head_mlp.hip): x[32] -> feat[64] -> 64 -> 32 -> ncls   (RandLANet.py:363-367)
 struct HeadArgs {

@@ -12,7 +12,7 @@ __device__ __forceinline__ void gn_scale_shift(const GnRef& g, int cloud, int c,
   const double mean = gn_stat_get(st) * g.inv_count;
   double var = gn_stat_get(st + 2) * g.inv_count - mean * mean;
   var = var > 0.0 ? var : 0.0;
-  const double rstd = 1.0 / sqrt(var + 1e-5);
+  const double rstd = gn_rstd(var);
   const double sc = (double)g.gamma[c] * rstd;
   scale = (float)sc;
   shift = (float)((double)g.beta[c] - mean * sc);

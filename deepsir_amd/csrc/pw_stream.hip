@@ -100,50 +100,6 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const GemmArgs p) {
   const int n0 = by * BN;
   const int ldw = p.ldw ? p.ldw : p.Cin;
 
-  if (EPI == EPI_ATT2) {
-    const Seg& s = p.fseg;
-    for (int c = tid; c < s.C; c += 256) {
-      float scale = 1.f, shift = 0.f;
-      if (s.gn.stats) {
-        const int g = c / (s.C / s.gn.groups);
-        const double* st = s.gn.stats + ((int64_t)cloud * s.gn.groups + g) * kGnWords;
-        const double mean = gn_stat_get(st) * s.gn.inv_count;
-        double var = gn_stat_get(st + 2) * s.gn.inv_count - mean * mean;
-        var = var > 0.0 ? var : 0.0;
-        const double rstd = 1.0 / sqrt(var + 1e-5);
-        const double scd = (double)s.gn.gamma[c] * rstd;
-        scale = (float)scd;
-        shift = (float)((double)s.gn.beta[c] - mean * scd);
-      }
-      s_fsc[c] = scale;
-      s_fsh[c] = shift;
-    }
-  }
-
-  if (MODE != S_LSE) {
-    for (int c = tid; c < CP; c += 256) {
-      float scale = 1.f, shift = 0.f;
-      if (c < p.Cin) {
-        const Seg& s = (c < p.seg[0].C) ? p.seg[0] : p.seg[1];
-        const int lc = (c < p.seg[0].C) ? c : c - p.seg[0].C;
-        if (s.gn.stats) {
-          const int g = lc / (s.C / s.gn.groups);
-          const double* st = s.gn.stats + ((int64_t)cloud * s.gn.groups + g) * kGnWords;
-          const double mean = gn_stat_get(st) * s.gn.inv_count;
-          double var = gn_stat_get(st + 2) * s.gn.inv_count - mean * mean;
-          var = var > 0.0 ? var : 0.0;
-          const double rstd = 1.0 / sqrt(var + 1e-5);
-          const double scd = (double)s.gn.gamma[lc] * rstd;
-          scale = (float)scd;
-          shift = (float)((double)s.gn.beta[lc] - mean * scd);
-        }
-      }
-      s_sc[c] = scale;
-      s_sh[c] = shift;
-    }
-    __syncthreads();
-  }
-
   // first column of the block's t-th 16-column tile.  EPI_ATT2 (Cout = 2 Cin = 8 KQ, NT = 4): a block owns 32 columns
   // of the gathered-feature half and the matching 32 of the enc half, so "tile t pools a gathered feature" is the
   // compile-time condition t < NT/2 for every block
@@ -151,11 +107,9 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const GemmArgs p) {
     if (EPI == EPI_ATT2) return t < NT / 2 ? (n0 >> 1) + 16 * t : p.fseg.C + (n0 >> 1) + 16 * (t - NT / 2);
     return n0 + 16 * t;
   };
-  // lane-constant pieces
+  // The weight fragments are fetched FIRST: their global loads are in flight while the GroupNorm statistics below are decoded
+  // (a dependent chain of fp64 arithmetic that opens every workgroup).
   const int c_lo = fq * KQ;                       // first channel of this lane's chunk
-  float sc[KQ], sh[KQ];
-#pragma unroll
-  for (int j = 0; j < KQ; ++j) { sc[j] = (MODE != S_LSE) ? s_sc[c_lo + j] : 1.f; sh[j] = (MODE != S_LSE) ? s_sh[c_lo + j] : 0.f; }
   float wf[NT][KQ];
   float bv[NT];
 #pragma unroll
@@ -176,6 +130,61 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const GemmArgs p) {
     }
     bv[t] = (p.bias && col < p.Cout) ? p.bias[col] : 0.f;
   }
+  // GroupNorm scale / shift of the operands -> LDS.  A dependent chain (statistics load, fixed-point decode, fp64 arithmetic, barrier)
+  // that opens every workgroup: in vector mode it runs AFTER the first tile group's loads have been issued (below).
+  auto stats_to_lds = [&]() {
+    if (EPI == EPI_ATT2) {
+      const Seg& s = p.fseg;
+      for (int c = tid; c < s.C; c += 256) {
+        float scale = 1.f, shift = 0.f;
+        if (s.gn.stats) {
+          const int g = c / (s.C / s.gn.groups);
+          const double* st = s.gn.stats + ((int64_t)cloud * s.gn.groups + g) * kGnWords;
+          const double mean = gn_stat_get(st) * s.gn.inv_count;
+          double var = gn_stat_get(st + 2) * s.gn.inv_count - mean * mean;
+          var = var > 0.0 ? var : 0.0;
+          const double rstd = gn_rstd(var);
+          const double scd = (double)s.gn.gamma[c] * rstd;
+          scale = (float)scd;
+          shift = (float)((double)s.gn.beta[c] - mean * scd);
+        }
+        s_fsc[c] = scale;
+        s_fsh[c] = shift;
+      }
+    }
+
+    if (MODE != S_LSE) {
+      for (int c = tid; c < CP; c += 256) {
+        float scale = 1.f, shift = 0.f;
+        if (c < p.Cin) {
+          const Seg& s = (c < p.seg[0].C) ? p.seg[0] : p.seg[1];
+          const int lc = (c < p.seg[0].C) ? c : c - p.seg[0].C;
+          if (s.gn.stats) {
+            const int g = lc / (s.C / s.gn.groups);
+            const double* st = s.gn.stats + ((int64_t)cloud * s.gn.groups + g) * kGnWords;
+            const double mean = gn_stat_get(st) * s.gn.inv_count;
+            double var = gn_stat_get(st + 2) * s.gn.inv_count - mean * mean;
+            var = var > 0.0 ? var : 0.0;
+            const double rstd = gn_rstd(var);
+            const double scd = (double)s.gn.gamma[lc] * rstd;
+            scale = (float)scd;
+            shift = (float)((double)s.gn.beta[lc] - mean * scd);
+          }
+        }
+        s_sc[c] = scale;
+        s_sh[c] = shift;
+      }
+      __syncthreads();
+    }
+  };
+  if (MODE != S_VEC) stats_to_lds();      // the element-wise and position-encoding loaders normalise while they load
+  // lane-constant pieces
+  float sc[KQ], sh[KQ];
+  auto fill_scale_shift = [&]() {
+#pragma unroll
+    for (int j = 0; j < KQ; ++j) { sc[j] = (MODE != S_LSE) ? s_sc[c_lo + j] : 1.f; sh[j] = (MODE != S_LSE) ? s_sh[c_lo + j] : 0.f; }
+  };
+  if (MODE != S_VEC) fill_scale_shift();
   h8 wh[kSplit ? NT : 1][NS], wl[kSplit ? NT : 1][NS];   // kSplit: the weight fragments as fp16 pairs (wf is dead after this)
   if (kSplit) {
 #pragma unroll
@@ -482,6 +491,7 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const GemmArgs p) {
     Group ga, gb;
     int t0 = wave0;
     if (t0 < ntiles) issue_group(ga, t0);
+    if (MODE == S_VEC) { stats_to_lds(); fill_scale_shift(); }     // the first group's loads are in flight meanwhile
     while (t0 < ntiles) {
       const int t1 = t0 + gstride;
       if (t1 < ntiles) issue_group(gb, t1);

@@ -91,44 +91,48 @@ __global__ __launch_bounds__(256) void pw_tile_kernel(const GemmArgs p) {
   const int m0 = blockIdx.x * BM;
   const int n0 = blockIdx.y * BN;
 
-  if (EPI == EPI_ATT2) {
-    const Seg& s = p.fseg;
-    for (int c = tid; c < s.C; c += 256) {
+  // GroupNorm scale / shift of the operands -> LDS: a dependent chain (statistics load, fixed-point decode, fp64 arithmetic) that opens
+  // every workgroup - it runs after the first K chunk's global loads have been issued (below)
+  auto stats_to_lds = [&]() {
+    if (EPI == EPI_ATT2) {
+      const Seg& s = p.fseg;
+      for (int c = tid; c < s.C; c += 256) {
+        float scale = 1.f, shift = 0.f;
+        if (s.gn.stats) {
+          const int g = c / (s.C / s.gn.groups);
+          const double* st = s.gn.stats + ((int64_t)cloud * s.gn.groups + g) * kGnWords;
+          const double mean = gn_stat_get(st) * s.gn.inv_count;
+          double var = gn_stat_get(st + 2) * s.gn.inv_count - mean * mean;
+          var = var > 0.0 ? var : 0.0;
+          const double rstd = gn_rstd(var);
+          const double scd = (double)s.gn.gamma[c] * rstd;
+          scale = (float)scd;
+          shift = (float)((double)s.gn.beta[c] - mean * scd);
+        }
+        s_fsc[c] = scale;
+        s_fsh[c] = shift;
+      }
+    }
+
+    for (int c = tid; c < p.Cin; c += 256) {
+      const Seg& s = (c < p.seg[0].C) ? p.seg[0] : p.seg[1];
+      const int lc = (c < p.seg[0].C) ? c : c - p.seg[0].C;
       float scale = 1.f, shift = 0.f;
       if (s.gn.stats) {
-        const int g = c / (s.C / s.gn.groups);
+        const int g = lc / (s.C / s.gn.groups);
         const double* st = s.gn.stats + ((int64_t)cloud * s.gn.groups + g) * kGnWords;
         const double mean = gn_stat_get(st) * s.gn.inv_count;
         double var = gn_stat_get(st + 2) * s.gn.inv_count - mean * mean;
         var = var > 0.0 ? var : 0.0;
-        const double rstd = 1.0 / sqrt(var + 1e-5);
-        const double scd = (double)s.gn.gamma[c] * rstd;
+        const double rstd = gn_rstd(var);
+        const double scd = (double)s.gn.gamma[lc] * rstd;
         scale = (float)scd;
-        shift = (float)((double)s.gn.beta[c] - mean * scd);
+        shift = (float)((double)s.gn.beta[lc] - mean * scd);
       }
-      s_fsc[c] = scale;
-      s_fsh[c] = shift;
+      s_sc[c] = scale;
+      s_sh[c] = shift;
     }
-  }
-
-  for (int c = tid; c < p.Cin; c += 256) {
-    const Seg& s = (c < p.seg[0].C) ? p.seg[0] : p.seg[1];
-    const int lc = (c < p.seg[0].C) ? c : c - p.seg[0].C;
-    float scale = 1.f, shift = 0.f;
-    if (s.gn.stats) {
-      const int g = lc / (s.C / s.gn.groups);
-      const double* st = s.gn.stats + ((int64_t)cloud * s.gn.groups + g) * kGnWords;
-      const double mean = gn_stat_get(st) * s.gn.inv_count;
-      double var = gn_stat_get(st + 2) * s.gn.inv_count - mean * mean;
-      var = var > 0.0 ? var : 0.0;
-      const double rstd = 1.0 / sqrt(var + 1e-5);
-      const double scd = (double)s.gn.gamma[lc] * rstd;
-      scale = (float)scd;
-      shift = (float)((double)s.gn.beta[lc] - mean * scd);
-    }
-    s_sc[c] = scale;
-    s_sh[c] = shift;
-  }
+  };
 
   // staging assignment: thread -> 4 consecutive channels (tid & 7) of rows (tid >> 3) + 32 i
   const int c4 = (tid & 7) * 4;
@@ -150,7 +154,6 @@ __global__ __launch_bounds__(256) void pw_tile_kernel(const GemmArgs p) {
   }
   const int C0 = p.seg[0].C;
   const int act0 = p.seg[0].act, act1 = p.nseg > 1 ? p.seg[1].act : 0;
-  __syncthreads();   // s_sc / s_sh ready
 
   float4 ra[AV], rw[H ? 1 : 2];
   h4 rwh[H ? 2 : 1], rwl[H ? 2 : 1];
@@ -205,6 +208,10 @@ __global__ __launch_bounds__(256) void pw_tile_kernel(const GemmArgs p) {
     }
   };
 
+  if (SC != 2) gload(0);     // in flight while the statistics are decoded
+  stats_to_lds();
+  __syncthreads();           // s_sc / s_sh ready
+
   f32x4 acc[RT][NT];
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)
@@ -255,7 +262,6 @@ __global__ __launch_bounds__(256) void pw_tile_kernel(const GemmArgs p) {
       }
     }
   } else {
-    gload(0);
     lstore(0, 0);
     __syncthreads();
   }
@@ -457,24 +463,6 @@ __global__ __launch_bounds__(256) void pw_tile_small_kernel(const GemmArgs p) {
   const int m0 = blockIdx.x * BM;
   const int n0 = blockIdx.y * BN;
 
-  for (int c = tid; c < p.Cin; c += 256) {
-    const Seg& s = (c < p.seg[0].C) ? p.seg[0] : p.seg[1];
-    const int lc = (c < p.seg[0].C) ? c : c - p.seg[0].C;
-    float scale = 1.f, shift = 0.f;
-    if (s.gn.stats) {
-      const int g = lc / (s.C / s.gn.groups);
-      const double* st = s.gn.stats + ((int64_t)cloud * s.gn.groups + g) * kGnWords;
-      const double mean = gn_stat_get(st) * s.gn.inv_count;
-      double var = gn_stat_get(st + 2) * s.gn.inv_count - mean * mean;
-      var = var > 0.0 ? var : 0.0;
-      const double rstd = 1.0 / sqrt(var + 1e-5);
-      const double scd = (double)s.gn.gamma[lc] * rstd;
-      scale = (float)scd;
-      shift = (float)((double)s.gn.beta[lc] - mean * scd);
-    }
-    s_sc[c] = scale;
-    s_sh[c] = shift;
-  }
   // staging: thread -> 4 consecutive channels (tid & 7) of A rows (tid >> 3) + 32 i and of W rows (tid >> 3), (tid >> 3) + 32
   const int c4 = (tid & 7) * 4;
   const int sr0 = tid >> 3;
@@ -493,7 +481,6 @@ __global__ __launch_bounds__(256) void pw_tile_small_kernel(const GemmArgs p) {
   }
   const int C0 = p.seg[0].C;
   const int act0 = p.seg[0].act, act1 = p.nseg > 1 ? p.seg[1].act : 0;
-  __syncthreads();
 
   // two register sets: a chunk is fetched two iterations before it is stored to LDS (a chunk's 8 MFMA steps hide only a
   // fraction of one L2 round trip; with a single launch on the chip - batch 1 - the K loop runs at load latency)
@@ -591,6 +578,27 @@ __global__ __launch_bounds__(256) void pw_tile_small_kernel(const GemmArgs p) {
     __syncthreads();
   };
   gload(preA, 0);
+  // GroupNorm scale / shift of the operands -> LDS: a dependent chain (statistics load, fixed-point decode, fp64 arithmetic) that opens
+  // every workgroup - decoded while the first chunk's global loads are in flight
+  for (int c = tid; c < p.Cin; c += 256) {
+    const Seg& s = (c < p.seg[0].C) ? p.seg[0] : p.seg[1];
+    const int lc = (c < p.seg[0].C) ? c : c - p.seg[0].C;
+    float scale = 1.f, shift = 0.f;
+    if (s.gn.stats) {
+      const int g = lc / (s.C / s.gn.groups);
+      const double* st = s.gn.stats + ((int64_t)cloud * s.gn.groups + g) * kGnWords;
+      const double mean = gn_stat_get(st) * s.gn.inv_count;
+      double var = gn_stat_get(st + 2) * s.gn.inv_count - mean * mean;
+      var = var > 0.0 ? var : 0.0;
+      const double rstd = gn_rstd(var);
+      const double scd = (double)s.gn.gamma[lc] * rstd;
+      scale = (float)scd;
+      shift = (float)((double)s.gn.beta[lc] - mean * scd);
+    }
+    s_sc[c] = scale;
+    s_sh[c] = shift;
+  }
+  __syncthreads();           // s_sc / s_sh ready
   lstore(preA, 0, 0);
   gload(preA, 1);
   gload(preB, 2);
