@@ -750,6 +750,16 @@ def main():
                                         "bytes_per_step": j["hbm_bytes_per_step"], "source": j.get("method")}
             except Exception:
                 pass
+        # the step's top kernels with their own rooflines (tools/kernel_table.py over the committed rocprofv3 summaries of this build)
+        kt = os.path.join(ROOT, "profiles", "r04_kernel_table.json")
+        if os.path.exists(kt) and (P_launch, N, n_iter) == (128, 5000, 5):
+            try:
+                with open(kt) as f:
+                    j = json.load(f)
+                roof["kernels"] = j["kernels"]
+                roof["kernels_note"] = j.get("note")
+            except Exception:
+                pass
         line["roofline"] = roof
         if sstats["rows_searched"]:
             line["screening"] = {"searches": sstats["screened_searches"], "undecided_row_rate": round(sstats["rows_undecided"] / sstats["rows_searched"], 5),

@@ -38,7 +38,9 @@ __device__ __forceinline__ void split8f(const float* x, h8& h, h8& l) {
   }
 }
 
-template <int KH>   // enc channels per row = d / 2: 32 (level 1) or 64 (level 2)
+// UV: E is not in memory - a row is rebuilt as a[c] dist + U[j][c] + V[i][c] from the per-point tables of lse_uv.hip (two gathered
+// table rows that live in L2 instead of a streamed HBM row; the neighbour index of the A row is fetched two units ahead)
+template <int KH, bool UV = false>   // enc channels per row = d / 2: 32 (level 1) or 64 (level 2)
 __global__ __launch_bounds__(256) void att_pool_kernel(const AttPoolArgs p) {
   constexpr int KC = KH / 2;     // channels of its row a lane holds: [h KC, (h + 1) KC), 8 of them per k-step
   constexpr int NS = KH / 16;    // k-steps
@@ -118,15 +120,37 @@ __global__ __launch_bounds__(256) void att_pool_kernel(const AttPoolArgs p) {
   const int nw = p.grid_x * 4;
   int u = bx * 4 + w;
 
-  float a[KC];          // this lane's raw E chunk of the CURRENT unit
+  float a[KC];          // this lane's raw E chunk of the CURRENT unit (UV: the U part)
+  float av[UV ? KC : 1], ad = 0.f, wa[UV ? KC : 1];     // UV: the V part, dist of the row, a[c] of this lane's channels
+  int ja = 0;                                           // UV: neighbour index of this lane's A row, one unit further ahead
+  const float* uvb = UV ? p.uv + cloud * p.uv_cs + h * KC : nullptr;
+  const float* distb = UV ? p.dist + cloud * p.dist_cs : nullptr;
+  if (UV) {
+#pragma unroll
+    for (int c = 0; c < KC; ++c) wa[c] = p.w8[(h * KC + c) * 8];
+  }
+  auto load_ja = [&](int uu) { ja = nbb[(uint32_t)min(2 * uu + pm, p.n - 1) * 16u + (uint32_t)km]; };
   int nb[16];           // the 16 neighbours of this lane's point
   auto load_unit = [&](int uu) {
     const int pa = min(2 * uu + pm, p.n - 1);                       // clamped: results of a padding point are never stored
-    const float* src = encb + ((uint32_t)(pa * 16 + km)) * (uint32_t)KH;
+    if (UV) {
+      const float* su = uvb + (uint32_t)ja * (uint32_t)(2 * KH);
+      const float* sv = uvb + (uint32_t)pa * (uint32_t)(2 * KH) + KH;
 #pragma unroll
-    for (int q = 0; q < KC / 4; ++q) {
-      const float4 v = *reinterpret_cast<const float4*>(src + 4 * q);
-      a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
+      for (int q = 0; q < KC / 4; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(su + 4 * q);
+        a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
+        const float4 z = *reinterpret_cast<const float4*>(sv + 4 * q);
+        av[UV ? 4 * q : 0] = z.x; av[UV ? 4 * q + 1 : 0] = z.y; av[UV ? 4 * q + 2 : 0] = z.z; av[UV ? 4 * q + 3 : 0] = z.w;
+      }
+      ad = distb[(uint32_t)(pa * 16 + km)];
+    } else {
+      const float* src = encb + ((uint32_t)(pa * 16 + km)) * (uint32_t)KH;
+#pragma unroll
+      for (int q = 0; q < KC / 4; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(src + 4 * q);
+        a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
+      }
     }
     const int pe = min(2 * uu + h, p.n - 1);
     const int4* ip = reinterpret_cast<const int4*>(nbb + (uint32_t)pe * 16u);
@@ -136,7 +160,11 @@ __global__ __launch_bounds__(256) void att_pool_kernel(const AttPoolArgs p) {
       nb[4 * q] = v.x; nb[4 * q + 1] = v.y; nb[4 * q + 2] = v.z; nb[4 * q + 3] = v.w;
     }
   };
-  if (u < units) load_unit(u);
+  if (u < units) {
+    if (UV) load_ja(u);
+    load_unit(u);
+    if (UV && u + nw < units) load_ja(u + nw);
+  }
   stats_to_lds();
   __syncthreads();
   while (u < units) {
@@ -152,6 +180,7 @@ __global__ __launch_bounds__(256) void att_pool_kernel(const AttPoolArgs p) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int c = 8 * s + j;
+        if (UV) a[c] = __fadd_rn(fmaf(wa[UV ? c : 0], ad, a[c]), av[UV ? c : 0]);     // the row of lfa.mlp1, as lse_uv.hip formed it
         const float v = fmaf(a[c], s_sc[h * KC + c], s_sh[h * KC + c]);
         a[c] = fmaxf(v, slope * v);
       }
@@ -163,7 +192,10 @@ __global__ __launch_bounds__(256) void att_pool_kernel(const AttPoolArgs p) {
     // ---- next unit's rows and indices: in flight during the MFMAs and the epilogue
     const int pt = 2 * u + h;
     const int un = u + nw;
-    if (un < units) load_unit(un);
+    if (un < units) {
+      load_unit(un);
+      if (UV && un + nw < units) load_ja(un + nw);
+    }
     // ---- scores of the enc half: 3 fp16 MFMAs per (tile, k-step)
     f32x16 acc[2];
 #pragma unroll
@@ -222,6 +254,7 @@ __global__ __launch_bounds__(256) void att_pool_kernel(const AttPoolArgs p) {
 // the E part; the normalised values double as the pooled operand through the LDS tile.  Round 3's kernel (pw_stream.hip
 // EPI_ATT, exact-fp32 16 x 16 x 4 MFMAs) ran the matrix pipe 79 % and the vector ALU 57 % busy; this one issues 6 fp16 MFMAs
 // (192 cycles) and ~250 vector instructions per four points.
+template <bool UV>   // UV: the E half of an A row rebuilt from the per-point tables of lse_uv.hip (see att_pool_kernel)
 __global__ __launch_bounds__(256) void att_pool16_kernel(const AttPool16Args p) {
   constexpr int LD = 20;                  // LDS row stride (floats): rows 4 apart land 16 banks apart
   constexpr int TB = 32 * LD + 32;        // tile B's offset: 32 banks away from tile A
@@ -270,20 +303,35 @@ __global__ __launch_bounds__(256) void att_pool16_kernel(const AttPool16Args p) 
 #pragma unroll
     for (int t = 0; t < 2; ++t) j[t] = nbb[(uint32_t)point_of(uu, t) * 16u + (uint32_t)km];
   };
-  auto load_rows = [&](int uu, const int (&j)[2], float (&a)[2][8]) {
+  const float* uvb = UV ? p.uv + cloud * p.uv_cs : nullptr;
+  const float* distb = UV ? p.dist + cloud * p.dist_cs : nullptr;
+  float wa[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) wa[c] = UV ? p.w8[c * 8] : 0.f;
+  // one pair of 16-byte loads per tile serves both lane halves through per-lane addresses: h = 0 the gathered feature row, h = 1
+  // the E row (UV: the neighbour's U row; its V row and dist follow in a second pair that only the h = 1 lanes use)
+  auto load_rows = [&](int uu, const int (&j)[2], float (&a)[2][8], float (&v)[2][8], float (&dd)[2]) {
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      const float* src = h ? eb + ((uint32_t)(point_of(uu, t) * 16 + km)) * 8u : fb + (uint32_t)j[t] * (uint32_t)p.f_ld;
+      const int pt = point_of(uu, t);
+      const float* src = h ? (UV ? uvb + (uint32_t)j[t] * 16u : eb + ((uint32_t)(pt * 16 + km)) * 8u) : fb + (uint32_t)j[t] * (uint32_t)p.f_ld;
       const float4 v0 = *reinterpret_cast<const float4*>(src), v1 = *reinterpret_cast<const float4*>(src + 4);
       a[t][0] = v0.x; a[t][1] = v0.y; a[t][2] = v0.z; a[t][3] = v0.w; a[t][4] = v1.x; a[t][5] = v1.y; a[t][6] = v1.z; a[t][7] = v1.w;
+      if (UV) {
+        const float* sv = uvb + (uint32_t)pt * 16u + 8u;
+        const float4 z0 = *reinterpret_cast<const float4*>(sv), z1 = *reinterpret_cast<const float4*>(sv + 4);
+        v[t][0] = z0.x; v[t][1] = z0.y; v[t][2] = z0.z; v[t][3] = z0.w; v[t][4] = z1.x; v[t][5] = z1.y; v[t][6] = z1.z; v[t][7] = z1.w;
+        dd[t] = distb[(uint32_t)(pt * 16 + km)];
+      }
     }
   };
   float a[2][8], an[2][8];
+  float av[2][8], avn[2][8], ad[2] = {0.f, 0.f}, adn[2] = {0.f, 0.f};
   int jn[2] = {0, 0};
   if (u < units) {
     int j0[2];
     load_idx(u, j0);
-    load_rows(u, j0, a);
+    load_rows(u, j0, a, av, ad);
     if (u + nw < units) load_idx(u + nw, jn);
   }
   // GroupNorm scale / shift of both operand halves: decoded while the first unit's loads are in flight
@@ -311,7 +359,7 @@ __global__ __launch_bounds__(256) void att_pool16_kernel(const AttPool16Args p) 
   while (u < units) {
     const int un = u + nw;
     if (un < units) {
-      load_rows(un, jn, an);
+      load_rows(un, jn, an, avn, adn);
       if (un + nw < units) load_idx(un + nw, jn);
     }
     // ---- A operands of both tiles: normalise, keep fp32 in LDS for the pooled operand, split for the MFMAs
@@ -322,6 +370,10 @@ __global__ __launch_bounds__(256) void att_pool16_kernel(const AttPool16Args p) 
     for (int t = 0; t < 2; ++t) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
+        if (UV) {        // the row of lfa.mlp1, as lse_uv.hip formed it (lanes of the E half)
+          const float e = __fadd_rn(fmaf(wa[j], ad[t], a[t][j]), av[t][j]);
+          a[t][j] = h ? e : a[t][j];
+        }
         const float v = fmaf(a[t][j], sc[j], sh[j]);
         a[t][j] = fmaxf(v, slope * v);
       }
@@ -354,9 +406,11 @@ __global__ __launch_bounds__(256) void att_pool16_kernel(const AttPool16Args p) 
     if (pt < p.n) Yb[(uint32_t)pt * 16u + (uint32_t)ecol] = o * __builtin_amdgcn_rcpf(se);
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < 2; ++t) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) a[t][j] = an[t][j];
+      for (int j = 0; j < 8; ++j) { a[t][j] = an[t][j]; av[t][j] = avn[t][j]; }
+      ad[t] = adn[t];
+    }
     u = un;
   }
 }
@@ -377,16 +431,19 @@ void launch_k(const AttPoolArgs& a, hipStream_t st) {
   if (blocks < 1) blocks = 1;
   AttPoolArgs b = a;
   b.grid_x = blocks;
-  hipLaunchKernelGGL((att_pool_kernel<KH>), dim3((unsigned)((int64_t)blocks * ncb * a.clouds)), dim3(256), 0, st, b);
+  const dim3 grid((unsigned)((int64_t)blocks * ncb * a.clouds));
+  if (a.enc) hipLaunchKernelGGL((att_pool_kernel<KH, false>), grid, dim3(256), 0, st, b);
+  else if (KH == 32) hipLaunchKernelGGL((att_pool_kernel<KH == 32 ? 32 : 64, KH == 32>), grid, dim3(256), 0, st, b);
 }
 
 }  // namespace
 
 bool launch_att_pool(const AttPoolArgs& a, hipStream_t st) {
   if (a.n <= 0 || a.clouds <= 0) return true;
-  if (!a.Wh || !a.Wl || !a.enc || !a.gp || !a.neigh || !a.Y) return false;
+  if (!a.Wh || !a.Wl || !a.gp || !a.neigh || !a.Y) return false;
+  if (!a.enc && (a.KH != 32 || !a.uv || !a.dist || !a.w8 || (reinterpret_cast<uintptr_t>(a.uv) % 16) != 0 || (a.uv_cs % 4) != 0)) return false;
   if ((a.ldw % 8) != 0 || (a.wcol0 % 8) != 0 || (reinterpret_cast<uintptr_t>(a.Wh) % 16) != 0 || (reinterpret_cast<uintptr_t>(a.Wl) % 16) != 0) return false;
-  if ((reinterpret_cast<uintptr_t>(a.enc) % 16) != 0 || (a.enc_cs % 4) != 0 || (reinterpret_cast<uintptr_t>(a.neigh) % 16) != 0 || (a.neigh_cs % 4) != 0) return false;
+  if ((a.enc && ((reinterpret_cast<uintptr_t>(a.enc) % 16) != 0 || (a.enc_cs % 4) != 0)) || (reinterpret_cast<uintptr_t>(a.neigh) % 16) != 0 || (a.neigh_cs % 4) != 0) return false;
   if ((reinterpret_cast<uintptr_t>(a.gp) % 16) != 0 || (a.gp_cs % 4) != 0 || (reinterpret_cast<uintptr_t>(a.Y) % 8) != 0 || (a.y_cs % 2) != 0) return false;
   if (a.enc_gn.stats && (a.KH % a.enc_gn.groups) != 0) return false;
   // 24-bit neighbour indices and 32-bit byte offsets inside a cloud
@@ -400,9 +457,10 @@ bool launch_att_pool(const AttPoolArgs& a, hipStream_t st) {
 
 bool launch_att_pool16(const AttPool16Args& a, hipStream_t st) {
   if (a.n <= 0 || a.clouds <= 0) return true;
-  if (!a.Wh || !a.Wl || !a.f || !a.enc || !a.neigh || !a.Y) return false;
+  if (!a.Wh || !a.Wl || !a.f || !a.neigh || !a.Y) return false;
+  if (!a.enc && (!a.uv || !a.dist || !a.w8 || (reinterpret_cast<uintptr_t>(a.uv) % 16) != 0 || (a.uv_cs % 4) != 0)) return false;
   if ((a.ldw % 8) != 0 || (reinterpret_cast<uintptr_t>(a.Wh) % 16) != 0 || (reinterpret_cast<uintptr_t>(a.Wl) % 16) != 0) return false;
-  if ((reinterpret_cast<uintptr_t>(a.f) % 16) != 0 || (a.f_cs % 4) != 0 || (a.f_ld % 4) != 0 || (reinterpret_cast<uintptr_t>(a.enc) % 16) != 0 || (a.enc_cs % 4) != 0) return false;
+  if ((reinterpret_cast<uintptr_t>(a.f) % 16) != 0 || (a.f_cs % 4) != 0 || (a.f_ld % 4) != 0 || (a.enc && ((reinterpret_cast<uintptr_t>(a.enc) % 16) != 0 || (a.enc_cs % 4) != 0))) return false;
   if ((a.f_gn.stats && (8 % a.f_gn.groups) != 0) || (a.enc_gn.stats && (8 % a.enc_gn.groups) != 0)) return false;
   if ((int64_t)a.n * 16 * 8 * 4 >= ((int64_t)1 << 32)) return false;
   const int units = (a.n + 3) / 4;
@@ -416,7 +474,8 @@ bool launch_att_pool16(const AttPool16Args& a, hipStream_t st) {
   if (blocks < 1) blocks = 1;
   AttPool16Args b = a;
   b.grid_x = blocks;
-  hipLaunchKernelGGL(att_pool16_kernel, dim3((unsigned)((int64_t)blocks * a.clouds)), dim3(256), 0, st, b);
+  if (a.enc) hipLaunchKernelGGL(att_pool16_kernel<false>, dim3((unsigned)((int64_t)blocks * a.clouds)), dim3(256), 0, st, b);
+  else hipLaunchKernelGGL(att_pool16_kernel<true>, dim3((unsigned)((int64_t)blocks * a.clouds)), dim3(256), 0, st, b);
   return true;
 }
 

@@ -46,7 +46,7 @@ struct HostParam {
 
 struct Mlp2dW { const float *W = nullptr, *b = nullptr, *gamma = nullptr, *beta = nullptr; int cin = 0, cout = 0, groups = 0; };
 struct AttW { const float* fc = nullptr; const float* fc_g = nullptr; const float* fc_p = nullptr; int d = 0; Mlp2dW mlp; };   // fc_g: up_fc_g, fc_p: up_fc_p
-struct BlockW { Mlp2dW mlp1, lfa1, lfa2, mlp2, skip; AttW att1, att2; int d_in = 0, d = 0; };
+struct BlockW { Mlp2dW mlp1, lfa1, lfa2, mlp2, skip; AttW att1, att2; int d_in = 0, d = 0; const float* lse_w8 = nullptr; };   // lse_w8: up_lse_uv
 struct LinW { const float *W = nullptr, *b = nullptr; int cin = 0, cout = 0; };
 struct RandlaW { Mlp2dW pre; BlockW blk[4]; Mlp2dW mid; Mlp2dW dec[4]; const float* out_w = nullptr; int dec_out = 0; LinW fc[3]; int cin = 0, ncls = 0;
                  const void* head_wh[4] = {}; const void* head_wl[4] = {}; };   // fp16 split of mlp_out + fc_label (head_mlp_h.hip)
@@ -87,6 +87,10 @@ struct Act {
   int rows = 0;       // rows per cloud
   GnRef gn = {nullptr, nullptr, nullptr, 0, 0.0};
   int act = 0;
+  // lse_uv.hip: the position-encoding layer of levels 0 / 1 is not in memory (p == nullptr): per-point tables instead
+  const float* uv = nullptr;      // [clouds][rows / 16][2 C]
+  const float* dist = nullptr;    // [clouds][rows]
+  const float* w8 = nullptr;
 };
 
 }  // namespace
@@ -97,6 +101,7 @@ struct dsir_ctx {
   hipStream_t stream = nullptr;        // where every launch of this context goes: own_stream, or a caller's (dsir_set_stream)
   hipStream_t own_stream = nullptr;
   std::string err;
+  const char* sched_error = nullptr;     // a launcher refused a layer (outside its envelope): reported by the schedule's caller
   std::vector<HostParam> params;
   std::unordered_map<std::string, int> index;
   float* dweights = nullptr;
@@ -333,9 +338,24 @@ size_t up_fc_p(Uploader& u, const HostParam& fc, int d) {
   return u.put(w);
 }
 
+// lse_uv.hip: lfa.mlp1 of a level with d / 2 <= 32 channels, folded for the split by linearity
+//   enc_raw[i, k][c] = a[c] dist + U[j][c] + V[i][c]:   per channel {a, ux, uy, uz, vx, vy, vz, b} with u = W[:, 1:4] + W[:, 7:10] (the
+// neighbour's coordinates enter through the offset and through their own channels), v = W[:, 4:7] - W[:, 1:4], b = bias.
+size_t up_lse_uv(Uploader& u, const HostParam& w, const HostParam& b, int kh) {
+  if (kh != 8 && kh != 32) return 0;
+  std::vector<float> f((size_t)kh * 8);
+  for (int c = 0; c < kh; ++c) {
+    const float* r = &w.data[(size_t)c * 10];
+    f[c * 8 + 0] = r[0];
+    for (int k = 0; k < 3; ++k) { f[c * 8 + 1 + k] = r[1 + k] + r[7 + k]; f[c * 8 + 4 + k] = r[4 + k] - r[1 + k]; }
+    f[c * 8 + 7] = b.data[c];
+  }
+  return u.put(f);
+}
+
 struct RandlaOff {
   Mlp2dOff pre, mid, dec[4];
-  struct { Mlp2dOff mlp1, lfa1, lfa2, mlp2, skip, a1m, a2m; size_t fc1, fc2, fc1g, fc2g, fc1p, fc2p; } blk[4];
+  struct { Mlp2dOff mlp1, lfa1, lfa2, mlp2, skip, a1m, a2m; size_t fc1, fc2, fc1g, fc2g, fc1p, fc2p, lse8; } blk[4];
   size_t out_w; int dec_out;
   LinOff fc[3];
 };
@@ -346,6 +366,7 @@ RandlaOff up_randla(dsir_ctx* c, Uploader& u, const std::string& pre) {
     const std::string p = pre + ".dilated_res_blocks." + std::to_string(i);
     r.blk[i].mlp1 = up_mlp2d(c, u, p + ".mlp1");
     r.blk[i].lfa1 = up_mlp2d(c, u, p + ".lfa.mlp1");
+    r.blk[i].lse8 = up_lse_uv(u, P(c, p + ".lfa.mlp1.conv.weight"), P(c, p + ".lfa.mlp1.conv.bias"), c->cfg.d_out[i] / 2);
     r.blk[i].fc1 = u.put(P(c, p + ".lfa.att_pooling_1.fc.weight").data);
     r.blk[i].fc1g = up_fc_g(u, P(c, p + ".lfa.att_pooling_1.fc.weight"), c->cfg.d_out[i]);
     r.blk[i].fc1p = up_fc_p(u, P(c, p + ".lfa.att_pooling_1.fc.weight"), c->cfg.d_out[i]);
@@ -380,6 +401,7 @@ RandlaW bind_randla(const float* base, const RandlaOff& o, const dsir_cfg& g) {
     b.att2.fc = base + o.blk[i].fc2; b.att2.d = g.d_out[i]; b.att2.mlp = bind_mlp2d(base, o.blk[i].a2m);
     b.att1.fc_g = g.d_out[i] >= 64 ? base + o.blk[i].fc1g : nullptr;
     b.att2.fc_g = g.d_out[i] >= 64 ? base + o.blk[i].fc2g : nullptr;
+    b.lse_w8 = (g.d_out[i] == 16 || g.d_out[i] == 64) ? base + o.blk[i].lse8 : nullptr;
     const bool pooled = g.d_out[i] == 64 || g.d_out[i] == 128;
     b.att1.fc_p = pooled ? base + o.blk[i].fc1p : nullptr;
     b.att2.fc_p = pooled ? base + o.blk[i].fc2p : nullptr;
@@ -397,6 +419,13 @@ RandlaW bind_randla(const float* base, const RandlaOff& o, const dsir_cfg& g) {
 bool att_pool_enabled() {
   static const bool off = tuning_flag("DSIR_NO_ATT_POOL");
   return !off;
+}
+
+// A/B switch: DSIR_NO_LSE_UV = lfa.mlp1 of levels 0 / 1 written to memory as up to round 3 (pw_stream.hip, loader S_LSE) instead of
+// the per-point tables of lse_uv.hip; the tables' consumers are att_pool.hip and pw_stream.hip (loader S_UV) only
+bool lse_uv_enabled() {
+  static const bool off = tuning_flag("DSIR_NO_LSE_UV");
+  return !off && att_pool_enabled();
 }
 
 // ------------------------------------------------------------------ schedule helpers
@@ -421,6 +450,7 @@ struct Sched {
     Seg s{};
     s.x = a.p; s.cloud_stride = (int64_t)a.rows * a.C; s.C = a.C; s.ld = a.C;
     s.idx = idx; s.idx_cloud_stride = idx_cs; s.gn = a.gn; s.act = a.act;
+    s.uv = a.uv; s.uv_cloud_stride = (int64_t)(a.rows / kKnn) * 2 * a.C; s.dist = a.dist; s.dist_cloud_stride = a.rows; s.w8 = a.w8;
     return s;
   }
   // MLP2D: conv1x1 + GroupNorm (lazy) [+ LeakyReLU (lazy)]
@@ -438,6 +468,25 @@ struct Sched {
     a.Y = y.p; a.y_cloud_stride = (int64_t)M * w.cout; a.ldy = w.cout; a.stats_out = st_out; a.groups_out = w.groups;
     split_of(a);
     if (!c->ws.overflow) launch_pw_gemm(a, st);   // an exhausted arena hands out its base: nothing may run on it
+    return y;
+  }
+  // lfa.mlp1 split by linearity (lse_uv.hip): per-point tables + dist + statistics, no output rows.  uv_buf / dist_buf: caller-owned
+  // storage (persistent across launches) or nullptr
+  Act lse_uv(const Mlp2dW& w, const float* w8, const float* xyz, int64_t xyz_cs, const int32_t* neigh, int64_t neigh_cs, int n,
+             float* uv_buf, float* dist_buf, double* st_buf) {
+    const int M = n * kKnn;
+    Act y;
+    y.p = nullptr; y.C = w.cout; y.rows = M; y.act = 1;
+    float* uv = uv_buf ? uv_buf : c->ws.get<float>((size_t)clouds * n * 2 * w.cout);
+    float* dist = dist_buf ? dist_buf : c->ws.get<float>((size_t)clouds * M);
+    double* st_out = st_buf ? st_buf : stats_slot(w.groups);
+    y.gn = GnRef{st_out, w.gamma, w.beta, w.groups, 1.0 / ((double)(w.cout / w.groups) * (double)M)};
+    y.uv = uv; y.dist = dist; y.w8 = w8;
+    LseUvArgs a;
+    a.xyz = xyz; a.xyz_cs = xyz_cs; a.neigh = neigh; a.neigh_cs = neigh_cs; a.w8 = w8;
+    a.uv = uv; a.uv_cs = (int64_t)n * 2 * w.cout; a.dist = dist; a.dist_cs = M;
+    a.stats_out = st_out; a.groups = w.groups; a.n = n; a.clouds = clouds; a.KH = w.cout;
+    if (!c->ws.overflow && !launch_lse_uv_stats(a, st)) { c->sched_error = "lse_uv: layer outside the kernel's envelope"; c->ws.overflow = true; }
     return y;
   }
   Act mlp2d_lse(const Mlp2dW& w, const float* xyz, int64_t xyz_cs, const int32_t* neigh, int64_t neigh_cs, int n,
@@ -477,6 +526,7 @@ struct Sched {
       if (launch_pw_stream(g, st)) {
         AttPoolArgs a;
         a.enc = enc.p; a.enc_cs = (int64_t)enc.rows * enc.C; a.enc_gn = enc.gn; a.enc_act = enc.act;
+        a.uv = enc.uv; a.uv_cs = (int64_t)n * 2 * enc.C; a.dist = enc.dist; a.dist_cs = (int64_t)n * kKnn; a.w8 = enc.w8;
         a.gp = gp; a.gp_cs = (int64_t)n * 4 * h; a.neigh = neigh; a.neigh_cs = neigh_cs;
         const size_t off = (size_t)(w.fc - c->dweights);
         a.Wh = c->dweights16 + off; a.Wl = c->dweights16 + c->nweights + off; a.ldw = w.d; a.wcol0 = h;
@@ -510,11 +560,17 @@ struct Sched {
       AttPool16Args a;
       a.f = f.p; a.f_cs = (int64_t)f.rows * f.C; a.f_ld = f.C; a.f_gn = f.gn; a.f_act = f.act;
       a.enc = enc.p; a.enc_cs = (int64_t)enc.rows * enc.C; a.enc_gn = enc.gn; a.enc_act = enc.act;
+      a.uv = enc.uv; a.uv_cs = (int64_t)n * 2 * enc.C; a.dist = enc.dist; a.dist_cs = (int64_t)n * kKnn; a.w8 = enc.w8;
       a.neigh = neigh; a.neigh_cs = neigh_cs;
       const size_t off = (size_t)(w.fc - c->dweights);
       a.Wh = c->dweights16 + off; a.Wl = c->dweights16 + c->nweights + off; a.ldw = w.d;
       a.Y = y.p; a.y_cs = (int64_t)n * w.d; a.n = n; a.clouds = clouds;
       if (!c->ws.overflow && launch_att_pool16(a, st)) return y;
+    }
+    if (!enc.p) {     // table-only rows have no other consumer (lse_uv_enabled() excludes this)
+      if (!c->ws.overflow) c->sched_error = "attentive pooling: no kernel took the table-only position encoding";
+      c->ws.overflow = true;
+      return y;
     }
     GemmArgs a;
     a.amode = A_SEGS; a.nseg = 2;
@@ -558,6 +614,8 @@ struct EncCache {
   bool valid = false;
   float* s2_buf[DSIR_MAX_LEVELS][2] = {};   // enc half of the attention scores (W2 enc / W2 enc2) of the split levels (d >= 64)
   float* enc_buf[DSIR_MAX_LEVELS] = {};
+  float* uv_buf[DSIR_MAX_LEVELS] = {};     // levels whose lfa.mlp1 rows are not stored (lse_uv.hip): tables + dist instead of enc_buf
+  float* dist_buf[DSIR_MAX_LEVELS] = {};
   float* enc2_buf[DSIR_MAX_LEVELS] = {};
   double* enc_stats[DSIR_MAX_LEVELS] = {};
   double* enc2_stats[DSIR_MAX_LEVELS] = {};
@@ -592,15 +650,18 @@ int randla_forward(dsir_ctx* c, const RandlaW& w, const Seg& in0, const Seg* in1
     const Seg xin = Sched::seg_of(x);
     Act f = s.mlp2d(b.mlp1, xin, nullptr, n, true);
     const bool reuse = cache && cache->valid;
+    const bool uvl = b.lse_w8 && lse_uv_enabled();     // this level's lfa.mlp1 rows are rebuilt from per-point tables, never stored
     Act enc = reuse ? cache->enc[l]
+              : uvl ? s.lse_uv(b.lfa1, b.lse_w8, xyz_l, xyz_cs, nb_l, neigh_cs, n, cache ? cache->uv_buf[l] : nullptr,
+                               cache ? cache->dist_buf[l] : nullptr, cache ? cache->enc_stats[l] : nullptr)
                     : s.mlp2d_lse(b.lfa1, xyz_l, xyz_cs, nb_l, neigh_cs, n, cache ? cache->enc_buf[l] : nullptr,
                                   cache ? cache->enc_stats[l] : nullptr);
     const int s2_mode = reuse ? 2 : 1;      // iteration 0 stores the pyramid-only half of the scores, later iterations load it
     Act agg = s.att(b.att1, f, enc, nb_l, neigh_cs, n, cache ? cache->s2_buf[l][0] : nullptr, s2_mode);
     Act a1 = s.mlp2d(b.att1.mlp, Sched::seg_of(agg), nullptr, n, true);
     Act enc2 = reuse ? cache->enc2[l]
-                     : s.mlp2d(b.lfa2, Sched::seg_of(enc), nullptr, n * kKnn, true, cache ? cache->enc2_buf[l] : nullptr,
-                               cache ? cache->enc2_stats[l] : nullptr);
+                     : s.mlp2d(b.lfa2, Sched::seg_of(enc, enc.uv ? nb_l : nullptr, enc.uv ? neigh_cs : 0), nullptr, n * kKnn, true,
+                               cache ? cache->enc2_buf[l] : nullptr, cache ? cache->enc2_stats[l] : nullptr);
     if (cache && !reuse) { cache->enc[l] = enc; cache->enc2[l] = enc2; }
     Act agg2 = s.att(b.att2, a1, enc2, nb_l, neigh_cs, n, cache ? cache->s2_buf[l][1] : nullptr, s2_mode);
     Act a2 = s.mlp2d(b.att2.mlp, Sched::seg_of(agg2), nullptr, n, true);
@@ -612,7 +673,10 @@ int randla_forward(dsir_ctx* c, const RandlaW& w, const Seg& in0, const Seg* in1
     samp.C = enc_out.C; samp.rows = py.nl[l + 1];
     samp.p = c->ws.get<float>((size_t)py.clouds * samp.rows * samp.C);
     if (l == 0) enc_out.p = c->ws.get<float>((size_t)py.clouds * n * enc_out.C);
-    if (c->ws.overflow) return fail(c, "workspace exhausted in randla_forward (raise max_points / max_pairs)");
+    if (c->ws.overflow) {
+      if (c->sched_error) { const char* m = c->sched_error; c->sched_error = nullptr; return fail(c, "randla_forward: %s (level %d)", m, l); }
+      return fail(c, "workspace exhausted in randla_forward (raise max_points / max_pairs)");
+    }
     if (l == 0) {
       // the level-0 block output is also the decoder's last skip connection: materialise it
       launch_residual_combine(mainb.p, mainb.gn, skipb.p, skipb.gn, enc_out.C, n, py.clouds, enc_out.p, st);
@@ -754,7 +818,7 @@ int build_pyramid(dsir_ctx* c, const float* points, int stride, int clouds, int 
 int check_ready(dsir_ctx* c) {
   if (!c) return 1;
   if (!c->finalized) return fail(c, "weights not finalized (call dsir_load_weight for every key, then dsir_finalize_weights)");
-  c->ws.top = 0; c->ws.overflow = false;
+  c->ws.top = 0; c->ws.overflow = false; c->sched_error = nullptr;
   return 0;
 }
 
@@ -962,6 +1026,7 @@ int dsir_finalize_weights(dsir_ctx* c) {
     // fp16 split (x -> fp16(x), fp16(x - fp16(x))) of the WHOLE blob (BatchNorm already folded), at the same offsets: the kernels
     // with an fp16-split contraction (agg_chain_h.hip, head_mlp_h.hip, pw_tile.hip) find the two parts of any matrix W at
     // dweights16 + (W - dweights) and dweights16 + nweights + (W - dweights).  20 MB for the align pipeline.
+    u.blob.resize((u.blob.size() + 63) & ~(size_t)63, 0.f);     // the low parts start at dweights16 + total: keep them 16-byte aligned too
     const size_t total = u.blob.size();
     std::vector<uint16_t> h16(2 * total, 0);
     split_weights_f16(u.blob.data(), total, h16.data(), h16.data() + total);
@@ -1313,7 +1378,12 @@ static int register_enqueue(dsir_ctx* c, const dsir_pair_batch* in, int n_iter, 
     size_t nstats = 0;
     for (int l = 0; l < g.num_layers; ++l) {
       const size_t rows = (size_t)P * ps.nl[l] * kKnn, ch = (size_t)g.d_out[l] / 2;
-      enc_cache.enc_buf[l] = ws.get<float>(rows * ch);
+      if (c->net.inl.blk[l].lse_w8 && lse_uv_enabled()) {
+        enc_cache.uv_buf[l] = ws.get<float>((size_t)P * ps.nl[l] * 2 * ch);
+        enc_cache.dist_buf[l] = ws.get<float>(rows);
+      } else {
+        enc_cache.enc_buf[l] = ws.get<float>(rows * ch);
+      }
       enc_cache.enc2_buf[l] = ws.get<float>(rows * ch);
       static const bool no_s2 = tuning_flag("DSIR_NO_S2");   // A/B switch: recompute the enc half of the scores every iteration
       // level 1 (d = 64: a 32-channel contraction) caches its score halves only for a few pairs in flight: with the chip full

@@ -39,6 +39,13 @@ struct Seg {
                          // source row = idx ? idx[r] : r
   GnRef gn;
   int act;               // 1 => LeakyReLU(0.2) after the normalisation
+  // lse_uv.hip: the segment is the position-encoding layer of a level whose rows are NOT in memory (x == nullptr): row r =
+  // (point i = r / 16, neighbour j = idx[r]) is rebuilt as a[c] dist[r] + U[j][c] + V[i][c] from the tables below
+  const float* uv = nullptr;        // [clouds][n][2 C] = [U | V] per point
+  int64_t uv_cloud_stride = 0;
+  const float* dist = nullptr;      // [clouds][n * 16]
+  int64_t dist_cloud_stride = 0;
+  const float* w8 = nullptr;        // [C][8] folded weights {a, ux, uy, uz, vx, vy, vz, b} (engine.hip, up_lse_uv)
 };
 
 enum AMode { A_SEGS = 0, A_LSE = 1 };
@@ -100,8 +107,13 @@ bool launch_pw_tile(const GemmArgs& a, hipStream_t st);
 // att_pool.hip - attentive pooling of the k = 16 layers of levels 1 / 2 (d = 64 / 128), score GEMM split by linearity: two points per
 // wave on v_mfma_f32_32x32x16_f16, softmax and weighted sum in registers (no cross-lane step)
 struct AttPoolArgs {
-  const float* enc = nullptr;        // E [clouds][n * 16][KH] raw conv outputs of the position-encoding branch
+  const float* enc = nullptr;        // E [clouds][n * 16][KH] raw conv outputs of the position-encoding branch, or nullptr:
   int64_t enc_cs = 0;
+  const float* uv = nullptr;         //   E rebuilt from the per-point tables of lse_uv.hip: [clouds][n][2 KH], dist [clouds][n * 16], w8 [KH][8]
+  int64_t uv_cs = 0;
+  const float* dist = nullptr;
+  int64_t dist_cs = 0;
+  const float* w8 = nullptr;
   GnRef enc_gn = {nullptr, nullptr, nullptr, 0, 0.0};   // its lazy GroupNorm
   int enc_act = 1;                   // LeakyReLU(0.2) after it
   const float* gp = nullptr;         // [clouds][n][4 KH]: per 64-column block and lane c: [G[col], G[col+1], X0, X1], col = 64 cb + 2 c (engine.hip, up_fc_p)
@@ -122,8 +134,11 @@ struct AttPool16Args {
   const float* f = nullptr;          // [clouds][n][f_ld], 8 channels used: the features that are gathered (raw conv outputs)
   int64_t f_cs = 0; int f_ld = 8;
   GnRef f_gn = {nullptr, nullptr, nullptr, 0, 0.0}; int f_act = 1;
-  const float* enc = nullptr;        // E [clouds][n * 16][8]
+  const float* enc = nullptr;        // E [clouds][n * 16][8], or nullptr: rebuilt from the tables of lse_uv.hip
   int64_t enc_cs = 0;
+  const float* uv = nullptr; int64_t uv_cs = 0;       // [clouds][n][16] = [U | V]
+  const float* dist = nullptr; int64_t dist_cs = 0;   // [clouds][n * 16]
+  const float* w8 = nullptr;                          // [8][8] folded weights
   GnRef enc_gn = {nullptr, nullptr, nullptr, 0, 0.0}; int enc_act = 1;
   const int32_t* neigh = nullptr;    // [clouds][n][16]
   int64_t neigh_cs = 0;
@@ -136,6 +151,19 @@ struct AttPool16Args {
   int grid_x = 0;                    // filled by the launcher
 };
 bool launch_att_pool16(const AttPool16Args& a, hipStream_t st);
+
+// lse_uv.hip - lfa.mlp1 of levels 0 / 1 split by linearity into per-point tables: writes U | V and dist, commits the layer's GroupNorm
+// statistics; the layer's output itself is never stored (consumers: att_pool.hip, pw_stream.hip loader S_UV)
+struct LseUvArgs {
+  const float* xyz = nullptr; int64_t xyz_cs = 0;        // [clouds][n][3]
+  const int32_t* neigh = nullptr; int64_t neigh_cs = 0;  // [clouds][n][16]
+  const float* w8 = nullptr;                             // [KH][8] folded weights
+  float* uv = nullptr; int64_t uv_cs = 0;                // [clouds][n][2 KH]
+  float* dist = nullptr; int64_t dist_cs = 0;            // [clouds][n * 16]
+  double* stats_out = nullptr; int groups = 0;           // [clouds][groups][kGnWords]
+  int n = 0, clouds = 0, KH = 0;
+};
+bool launch_lse_uv_stats(const LseUvArgs& a, hipStream_t st);   // KH = 8 or 32; false => outside the envelope
 
 // mlp_out + fc_label fused (head_mlp.hip): x[32] -> feat[64] -> 64 -> 32 -> ncls   (RandLANet.py:363-367)
 struct HeadArgs {

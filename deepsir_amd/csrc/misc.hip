@@ -27,19 +27,25 @@ __global__ __launch_bounds__(256) void residual_combine_kernel(const float* __re
                                                                float* __restrict__ y) {
   __shared__ float sa[512], ha[512], sb[512], hb[512];
   const int cloud = blockIdx.y;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    gn_scale_shift(ga, cloud, c, C, sa[c], ha[c]);
-    gn_scale_shift(gb, cloud, c, C, sb[c], hb[c]);
-  }
-  __syncthreads();
   const int C4 = C >> 2;
   const int64_t total4 = (int64_t)rows * C4;
   const float4* a4 = reinterpret_cast<const float4*>(a + (int64_t)cloud * rows * C);
   const float4* b4 = reinterpret_cast<const float4*>(b + (int64_t)cloud * rows * C);
   float4* y4 = reinterpret_cast<float4*>(y + (int64_t)cloud * rows * C);
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total4; e += (int64_t)gridDim.x * blockDim.x) {
+  // the first element's loads are issued before the statistics chain (a dependent load -> fp64 arithmetic -> barrier sequence
+  // that opens every workgroup), the next element's during the current one's arithmetic
+  const int64_t e0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, estep = (int64_t)gridDim.x * blockDim.x;
+  float4 xn = make_float4(0.f, 0.f, 0.f, 0.f), zn = xn;
+  if (e0 < total4) { xn = a4[e0]; zn = b4[e0]; }
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    gn_scale_shift(ga, cloud, c, C, sa[c], ha[c]);
+    gn_scale_shift(gb, cloud, c, C, sb[c], hb[c]);
+  }
+  __syncthreads();
+  for (int64_t e = e0; e < total4; e += estep) {
     const int c = (int)(e % C4) * 4;
-    const float4 x = a4[e], z = b4[e];
+    const float4 x = xn, z = zn;
+    if (e + estep < total4) { xn = a4[e + estep]; zn = b4[e + estep]; }
     float4 r;
     r.x = lrelu(fmaf(x.x, sa[c], ha[c]) + fmaf(z.x, sb[c], hb[c]));
     r.y = lrelu(fmaf(x.y, sa[c + 1], ha[c + 1]) + fmaf(z.y, sb[c + 1], hb[c + 1]));
@@ -83,19 +89,35 @@ __global__ __launch_bounds__(256) void gather_max_combine_kernel(const float* __
   // 1-D grid of bpc workgroups per cloud, XCD-aware: a cloud's workgroups share one L2 (every input row is gathered ~4 times)
   const int wi = xcd_contiguous(blockIdx.x, gridDim.x);
   const int cloud = wi / bpc, bx = wi % bpc;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    gn_scale_shift(ga, cloud, c, C, sa[c], ha[c]);
-    gn_scale_shift(gb, cloud, c, C, sb[c], hb[c]);
-  }
-  __syncthreads();
   const int C4 = C >> 2;
   const int64_t total4 = (int64_t)rows_out * C4;
   const float* pa = a + (int64_t)cloud * rows_in * C;
   const float* pb = b + (int64_t)cloud * rows_in * C;
   float4* o4 = reinterpret_cast<float4*>(out + (int64_t)cloud * rows_out * C);
-  for (int64_t e = (int64_t)bx * blockDim.x + threadIdx.x; e < total4; e += (int64_t)bpc * blockDim.x) {
-    const int i = (int)(e / C4), c = (int)(e % C4) * 4;
-    const int32_t* nb = idx + cloud * idx_cs + (int64_t)i * kKnn;
+  // the first element's neighbour list is fetched before the statistics chain that opens the workgroup, every next one during
+  // the current element's gathers (index -> row is a dependent pair of loads)
+  const int64_t e0 = (int64_t)bx * blockDim.x + threadIdx.x, estep = (int64_t)bpc * blockDim.x;
+  int nbn[kKnn];
+  {
+    const int4* ip = reinterpret_cast<const int4*>(idx + cloud * idx_cs + (int64_t)(int)(min(e0, total4 - 1) / C4) * kKnn);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const int4 v = ip[q]; nbn[4 * q] = v.x; nbn[4 * q + 1] = v.y; nbn[4 * q + 2] = v.z; nbn[4 * q + 3] = v.w; }
+  }
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    gn_scale_shift(ga, cloud, c, C, sa[c], ha[c]);
+    gn_scale_shift(gb, cloud, c, C, sb[c], hb[c]);
+  }
+  __syncthreads();
+  for (int64_t e = e0; e < total4; e += estep) {
+    const int c = (int)(e % C4) * 4;
+    int nb[kKnn];
+#pragma unroll
+    for (int k = 0; k < kKnn; ++k) nb[k] = nbn[k];
+    if (e + estep < total4) {
+      const int4* ip = reinterpret_cast<const int4*>(idx + cloud * idx_cs + (int64_t)(int)((e + estep) / C4) * kKnn);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { const int4 v = ip[q]; nbn[4 * q] = v.x; nbn[4 * q + 1] = v.y; nbn[4 * q + 2] = v.z; nbn[4 * q + 3] = v.w; }
+    }
     const float4 s1 = *reinterpret_cast<const float4*>(&sa[c]), h1 = *reinterpret_cast<const float4*>(&ha[c]);
     const float4 s2 = *reinterpret_cast<const float4*>(&sb[c]), h2 = *reinterpret_cast<const float4*>(&hb[c]);
     float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);

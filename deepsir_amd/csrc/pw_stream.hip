@@ -26,7 +26,7 @@ namespace dsir {
 
 namespace {
 
-enum SMode { S_VEC = 0, S_ELEM = 1, S_LSE = 2 };
+enum SMode { S_VEC = 0, S_ELEM = 1, S_LSE = 2, S_UV = 3 };   // S_UV: rows rebuilt from the per-point tables of lse_uv.hip
 
 template <int KQ>
 struct Chunk { float v[KQ]; };
@@ -66,6 +66,7 @@ __device__ __forceinline__ void split8(const float* x, h8& h, h8& l) {
 template <int KQ, int NT, int EPI, int MODE, int SC = 0>   // SC: GemmArgs::s2_mode (EPI_ATT2 only)
 __global__ __launch_bounds__(256) void pw_stream_kernel(const GemmArgs p) {
   constexpr int BN = NT * 16;
+  constexpr bool kVec = MODE == S_VEC || MODE == S_UV;   // raw rows loaded first, normalised after the loads have landed
   // Attentive pooling (round 3): the score contraction of a 16-neighbour tile runs on the fp16 matrix pipe at fp32 accuracy -
   // a lane's 8 or 16 contiguous channels ARE the A fragment of v_mfma_f32_16x16x32_f16 (k = 8 fq + j per 32-channel step, the
   // same re-ordered k index as the fp32 form), each operand split into two fp16 numbers, three MFMAs per product: 12 / 24 fp16
@@ -177,14 +178,14 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const GemmArgs p) {
       __syncthreads();
     }
   };
-  if (MODE != S_VEC) stats_to_lds();      // the element-wise and position-encoding loaders normalise while they load
+  if (!kVec) stats_to_lds();      // the element-wise and position-encoding loaders normalise while they load
   // lane-constant pieces
   float sc[KQ], sh[KQ];
   auto fill_scale_shift = [&]() {
 #pragma unroll
     for (int j = 0; j < KQ; ++j) { sc[j] = (MODE != S_LSE) ? s_sc[c_lo + j] : 1.f; sh[j] = (MODE != S_LSE) ? s_sh[c_lo + j] : 0.f; }
   };
-  if (MODE != S_VEC) fill_scale_shift();
+  if (!kVec) fill_scale_shift();
   h8 wh[kSplit ? NT : 1][NS], wl[kSplit ? NT : 1][NS];   // kSplit: the weight fragments as fp16 pairs (wf is dead after this)
   if (kSplit) {
 #pragma unroll
@@ -201,6 +202,11 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const GemmArgs p) {
   const float* mybase = myseg.x + cloud * myseg.cloud_stride + seg_c;                     // per lane (segment of its chunk)
   const int32_t* myidx = myseg.idx ? myseg.idx + cloud * myseg.idx_cloud_stride : nullptr;
   const uint32_t my_ld = (uint32_t)myseg.ld;
+  const float* uvb = MODE == S_UV ? p.seg[0].uv + cloud * p.seg[0].uv_cloud_stride : nullptr;
+  const float* distb = MODE == S_UV ? p.seg[0].dist + cloud * p.seg[0].dist_cloud_stride : nullptr;
+  float uva[KQ];
+#pragma unroll
+  for (int j = 0; j < KQ; ++j) uva[j] = MODE == S_UV ? p.seg[0].w8[(c_lo + j) * 8] : 0.f;
 
   const int ntiles = (p.M + 15) >> 4;
   const int wave0 = bx * 4 + w, nwaves = p.grid_x * 4;
@@ -209,12 +215,12 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const GemmArgs p) {
   // Rows past M (last, partial tile) are CLAMPED to row M-1 rather than predicated: their MFMA results are
   // never stored nor counted, and unconditional loads keep the exec mask (and the branch count) out of the loop.
   auto tile_srow = [&](int tile) -> int {
-    if (MODE != S_VEC) return 0;
+    if (!kVec) return 0;
     const int row = min(tile * 16 + fr, p.M - 1);
     return myidx ? myidx[row] : row;
   };
   auto finish_tile = [&](int tile, Chunk<KQ>& ch) {
-    if (MODE != S_VEC) return;
+    if (!kVec) return;
 #pragma unroll
     for (int j = 0; j < KQ; ++j) {
       const float v = fmaf(ch.v[j], sc[j], sh[j]);
@@ -227,6 +233,16 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const GemmArgs p) {
     if (MODE == S_VEC) {
       const float* src = mybase + (uint32_t)srow * my_ld;      // 32-bit row offset: per-cloud tensors are < 4 GiB
       vec_load<KQ>(src, ch.v);          // raw values; normalised by finish_tile() after the MFMA burst
+    } else if (MODE == S_UV) {
+      // lse_uv.hip: row (point i = row / 16, neighbour j = srow) of the position-encoding layer = a dist + U[j] + V[i], this
+      // lane's KQ channels; the same expression - the same bits - its GroupNorm statistics were taken of
+      const int rowc = min(row, p.M - 1);
+      float u[KQ], v[KQ];
+      vec_load<KQ>(uvb + (uint32_t)srow * (uint32_t)(2 * 4 * KQ) + c_lo, u);
+      vec_load<KQ>(uvb + (uint32_t)(rowc >> 4) * (uint32_t)(2 * 4 * KQ) + 4 * KQ + c_lo, v);
+      const float dd = distb[rowc];
+#pragma unroll
+      for (int j = 0; j < KQ; ++j) ch.v[j] = __fadd_rn(fmaf(uva[j], dd, u[j]), v[j]);
     } else if (MODE == S_ELEM) {
 #pragma unroll
       for (int j = 0; j < KQ; ++j) {
@@ -293,7 +309,7 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const GemmArgs p) {
     for (int d = 0; d < D; ++d) {
       const int tl = tile0 + d * nwaves;
       const int tlc = min(tl, ntiles - 1);
-      srow[d] = (MODE == S_VEC) ? tile_srow(tlc) : (tl < ntiles ? tile_srow(tl) : 0);
+      srow[d] = kVec ? tile_srow(tlc) : (tl < ntiles ? tile_srow(tl) : 0);
       if (EPI == EPI_ATT2) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
@@ -303,7 +319,7 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const GemmArgs p) {
 #pragma unroll
     for (int d = 0; d < D; ++d) {
       const int tl = tile0 + d * nwaves;
-      if (MODE == S_VEC) load_tile(min(tl, ntiles - 1), srow[d], buf[d]);
+      if (kVec) load_tile(min(tl, ntiles - 1), srow[d], buf[d]);
       else if (tl < ntiles) load_tile(tl, srow[d], buf[d]);
       if (EPI == EPI_ATT2) {
         // the gathered rows of G = W1 f (added to the scores; all NT tiles) and of f (pooled operand; the first
@@ -491,7 +507,7 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const GemmArgs p) {
     Group ga, gb;
     int t0 = wave0;
     if (t0 < ntiles) issue_group(ga, t0);
-    if (MODE == S_VEC) { stats_to_lds(); fill_scale_shift(); }     // the first group's loads are in flight meanwhile
+    if (kVec) { stats_to_lds(); fill_scale_shift(); }     // the first group's loads are in flight meanwhile
     while (t0 < ntiles) {
       const int t1 = t0 + gstride;
       if (t1 < ntiles) issue_group(gb, t1);
@@ -596,6 +612,13 @@ bool launch_pw_stream(const GemmArgs& a, hipStream_t st) {
     return launch_nt<3, S_LSE>(a, st);
   }
   if (a.Cin > 64) return false;
+  if (a.seg[0].uv) {     // rows rebuilt from per-point tables (lse_uv.hip): one segment of 8 or 32 channels, GroupNorm epilogue
+    if (a.nseg != 1 || a.epi != EPI_GN || !a.seg[0].idx || !a.seg[0].dist || !a.seg[0].w8 || (a.M % 16) != 0) return false;
+    if ((reinterpret_cast<uintptr_t>(a.seg[0].uv) % 16) != 0 || (a.seg[0].uv_cloud_stride % 4) != 0) return false;
+    if (a.Cin == 8) return launch_nt<2, S_UV>(a, st);
+    if (a.Cin == 32) return launch_nt<8, S_UV>(a, st);
+    return false;
+  }
   const int C0 = a.seg[0].C;
   // vector mode: Cin = 4 KQ exactly, chunks do not straddle the segment boundary, aligned rows
   for (int KQ : {2, 4, 8, 16}) {

@@ -55,10 +55,14 @@ __device__ __forceinline__ float softplus(float x) {  // F.softplus, beta = 1, t
 __global__ __launch_bounds__(256) void score_point_kernel(const float* __restrict__ feat, const float* __restrict__ xyz,
                                                           int64_t xyz_cs, const int32_t* __restrict__ neigh,
                                                           int64_t neigh_cs, int n, ScoreScratch s,
-                                                          float* __restrict__ score, int32_t* __restrict__ label_out) {
-  const int cloud = blockIdx.y;
+                                                          float* __restrict__ score, int32_t* __restrict__ label_out, int bpc) {
+  // 1-D grid of bpc workgroups per cloud, XCD-aware: every XCD takes whole clouds in turn, so the 17 feature rows a point gathers
+  // (256 B each, 1.28 MB per cloud) stay in ONE L2.  Round 3 dealt a cloud's workgroups over all eight XCDs: 2.5 GB of HBM-side
+  // fetches per 256-cloud launch for 0.33 GB of features.
+  const int wi = xcd_contiguous(blockIdx.x, gridDim.x);
+  const int cloud = wi / bpc;
   const int lane = threadIdx.x & 63;
-  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int i = (wi % bpc) * 4 + (threadIdx.x >> 6);
   if (i >= n) return;
   const float* F = feat + (int64_t)cloud * n * 64;
   const float* X = xyz + cloud * xyz_cs;
@@ -110,8 +114,9 @@ void launch_score(const float* feat, const float* logits, int ncls, const float*
   int gx = (n + 255) / 256;
   if (gx > 256) gx = 256;
   hipLaunchKernelGGL(score_reduce_kernel, dim3(gx, clouds), dim3(256), 0, st, feat, logits, ncls, n, s);
-  hipLaunchKernelGGL(score_point_kernel, dim3((n + 3) / 4, clouds), dim3(256), 0, st, feat, xyz, xyz_cs, neigh, neigh_cs,
-                     n, s, score, label_out);
+  const int bpc = (n + 3) / 4;
+  hipLaunchKernelGGL(score_point_kernel, dim3((unsigned)((int64_t)bpc * clouds)), dim3(256), 0, st, feat, xyz, xyz_cs, neigh, neigh_cs,
+                     n, s, score, label_out, bpc);
 }
 
 }  // namespace dsir

@@ -319,3 +319,43 @@ def test_groupnorm_statistics_do_not_depend_on_arrival_order():
     eng.close()
     for k in keep:
         assert torch.equal(one[k], keep[k]), k
+
+
+def test_config4_shard_walked_in_ragged_calls():
+    """BASELINE configs[3] (the 1623-pair 3DMatch test set, pair-sharded): one rank's shard of a 1623-pair set at world size 8 is
+    203 pairs; here 300 pairs of 5000 points are walked the way bench.py --total-pairs walks a shard - engine calls of at most
+    128 pairs on the 2-stream pool, the last one ragged (128 + 128 + 44), results written into one [pairs, n_iter, 3, 4] buffer
+    and gathered with the padded all_gather path - and once more in calls of 100 on a single engine: a pair's pose does not
+    depend on how the shard is cut (bitwise), every pose is a rigid transform."""
+    from deepsir_amd.arch import NetConfig
+    from deepsir_amd.dist import gather_results, shard_range, shard_sizes
+    from deepsir_amd.engine import Engine, EnginePool
+    from deepsir_amd.synth import make_batch
+    from deepsir_amd.weights import generate_state_dict
+    cfg = NetConfig(feat_len=3)
+    sd = generate_state_dict(cfg, 0)
+    T, N, n_iter = 300, 5000, 5
+    assert shard_sizes(1623, 8) == [203] * 7 + [202] and list(shard_range(T, 0, 1)) == list(range(T))
+    b = make_batch(N, [50_000 + i for i in range(T)], 3)
+    src, ref = cu(b["points_src"]), cu(b["points_ref"])
+    out = torch.empty((T, n_iter, 3, 4), dtype=torch.float32, device=src.device)
+    pool = EnginePool(cfg, 0, max_points=N, max_pairs=128, streams=2)
+    pool.load_state_dict(sd)
+    for c0 in range(0, T, 128):
+        c1 = min(c0 + 128, T)
+        pool.register(src[c0:c1], ref[c0:c1], n_iter, want_aux=False, sync=False, out={"transforms": out[c0:c1]})
+    pool.sync()
+    got = gather_results(out, None, sizes=[T])
+    pool.close()
+    assert got.shape == (T, n_iter, 3, 4) and bool(torch.isfinite(got).all())
+    R = got[:, -1, :, :3].double()
+    assert float((R @ R.transpose(1, 2) - torch.eye(3, dtype=torch.float64, device=R.device)).abs().max()) < 1e-5
+    assert float((torch.linalg.det(R) - 1).abs().max()) < 1e-5
+    eng = Engine(cfg, 0, max_points=N, max_pairs=100)
+    eng.load_state_dict(sd)
+    again = torch.empty_like(out)
+    for c0 in range(0, T, 100):
+        eng.register(src[c0:c0 + 100], ref[c0:c0 + 100], n_iter, want_aux=False, sync=False, out={"transforms": again[c0:c0 + 100]})
+    eng.sync()
+    eng.close()
+    assert torch.equal(got, again), "a pair's pose depends on how the shard is cut into engine calls"
