@@ -1,24 +1,22 @@
-// Attentive pooling (reference network/RandLANet.py:140-157) for the k = 16 layers of pyramid levels 0 - 2.  Levels 1 / 2 (d = 64 / 128):
+// Attentive pooling (reference network/RandLANet.py:140-157) of the k = 16 layers of pyramid levels 0 - 2 (d = 16 / 64 / 128):
 //   y[i][c] = sum_k softmax_k(S[k][c]) X[k][c],   X[k] = [ fN[nb(i,k)] ; E[i,k] ],   S[k] = fc X[k]
-// with the score GEMM split by linearity: S[k] = G[nb(i,k)] + W2 E[i,k], G = W1 fN a per-POINT GEMM made
-// beforehand.  Round 4: the previous kernels (pw_stream.hip EPI_ATT2) spent ~350 vector instructions per point, most of them
-// the cross-lane softmax butterflies of a 16 x 16 accumulator tile, gather address arithmetic and operand plumbing (PMC: 58 %
-// VALU + 30 % MFMA busy).  This kernel is organised around the ACCUMULATOR LAYOUT instead:
-//   * a wave owns units of TWO points = 32 rows = one row tile of v_mfma_f32_32x32x16_f16.  A-row m carries neighbour
-//     k = 4 (m >> 3) + (m & 3) of point (m >> 2) & 1: the accumulator rows a lane holds - (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5),
-//     cdna_hip_programming.md section 3 - are then exactly the 16 neighbours of ONE point (lane half = point, register =
-//     neighbour).  The softmax over the neighbours and the weighted sum run in registers: no cross-lane instruction at all;
-//   * a block owns 64 output columns; lane c = lane & 31 owns the ADJACENT pair 64 cb + 2 c + {0, 1} - tile t of the two MFMA
-//     column tiles is "column 2 c + t" (a column permutation costs nothing: it only selects the weight rows of the B fragment).
-//     Everything the epilogue gathers for one neighbour - the pair's G values and, for columns of the gathered-feature half, the
-//     pair's fN values - is then ONE 16-byte load: the per-point GEMM writes rows gp[point] = 32 lanes x [G0 G1 X0 X1] per
-//     column block (its weight matrix carries the permutation and an identity block, engine.hip::up_fc_p; fN x 1.0 is exact in
-//     the fp32 MFMA).  16 wide gathers per unit instead of 48 dword ones;
-//   * the contraction W2 E runs on the fp16 matrix pipe at fp32 accuracy (x = fp16(x) + fp16(x - fp16(x)), three MFMAs per
-//     product: agg_chain_h.hip); weights split at load, B fragments in registers (d = 64) or in LDS (d = 128);
-//   * E (normalised: the producer's GroupNorm + LeakyReLU applied while the A operand is formed) reaches the epilogue's
-//     column layout through a wave-private LDS tile [32][KH + 8];
-//   * software pipeline: the next unit's neighbour indices and E rows are in flight during the current unit's epilogue.
+// Up to round 3 these layers ran in pw_stream.hip (EPI_ATT / EPI_ATT2) on 16 x 16 MFMA tiles: the 16 neighbours of a point sat in four
+// lane groups x four registers, so every softmax was a chain of cross-lane butterflies, and the kernels were bound by vector-ALU
+// issue (~350 instructions per point at d = 64; PMC: 58 % VALU + 30 % MFMA busy; level 0: the exact-fp32 matrix pipe 79 % busy).
+// The kernels here are organised around the ACCUMULATOR LAYOUT of v_mfma_f32_32x32x16_f16 instead:
+//   * a wave owns units of TWO points = 32 rows = one row tile.  A-row m carries neighbour k = 4 (m >> 3) + (m & 3) of point
+//     (m >> 2) & 1: the accumulator rows a lane holds - (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5), cdna_hip_programming.md section 3 -
+//     are then exactly the 16 neighbours of ONE point (lane half = point, register = neighbour).  Softmax and weighted sum run in
+//     registers: no cross-lane instruction at all;
+//   * the whole score contraction fc [fN[nb] ; E] runs on the fp16 matrix pipe at fp32 accuracy (x = fp16(x) + fp16(x - fp16(x)), three
+//     MFMAs per product: agg_chain_h.hip; weights split at load): lane half h = 0 forms the gathered-feature part of an A row (one
+//     index, one row of the raw features, their GroupNorm + LeakyReLU), h = 1 the E part (from memory, or rebuilt from the per-point
+//     tables of lse_uv.hip); the normalised values double as the pooled operand through a wave-private LDS tile, so the epilogue
+//     gathers nothing.  (A first version kept round 3's split of the scores by linearity - S = G[nb] + W2 E with G = W1 fN a per-point
+//     GEMM - and gathered G and fN in the epilogue: 20 KB of L2 reads per two points at d = 64, the matrix pipe 8 % busy, no faster
+//     than the kernel it replaced; profiles/README.md, round 4);
+//   * software pipeline: the next unit's rows are in flight during the current unit's MFMAs and epilogue, its neighbour indices one
+//     unit further ahead (index -> row is a dependent pair of loads).
 #include "kernels.h"
 #include "device_utils.h"
 
@@ -37,211 +35,6 @@ __device__ __forceinline__ void split8f(const float* x, h8& h, h8& l) {
     l[k] = (_Float16)(x[k] - (float)t);
   }
 }
-
-// UV: E is not in memory - a row is rebuilt as a[c] dist + U[j][c] + V[i][c] from the per-point tables of lse_uv.hip (two gathered
-// table rows that live in L2 instead of a streamed HBM row; the neighbour index of the A row is fetched two units ahead)
-template <int KH, bool UV = false>   // enc channels per row = d / 2: 32 (level 1) or 64 (level 2)
-__global__ __launch_bounds__(256) void att_pool_kernel(const AttPoolArgs p) {
-  constexpr int KC = KH / 2;     // channels of its row a lane holds: [h KC, (h + 1) KC), 8 of them per k-step
-  constexpr int NS = KH / 16;    // k-steps
-  constexpr int LD = KH + 8;     // LDS row stride in floats
-  constexpr int NCB = KH / 32;   // column blocks of 64 = d / 64
-  constexpr bool WLDS = KH > 32; // B fragments in LDS instead of registers (64 VGPRs at d = 128)
-  constexpr uint32_t ROWB = 4u * KH * 4u;   // bytes per row of gp: d / 64 blocks x 32 lanes x 4 floats
-  __shared__ float s_sc[KH];
-  __shared__ float s_sh[KH];
-  __shared__ __attribute__((aligned(16))) float s_t[4][32 * LD];
-  __shared__ h8 s_w[WLDS ? 2 * NS * 2 * 64 : 1];   // [tile][k-step][high | low][lane]
-
-  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int m = lane & 31, h = lane >> 5;
-  const int wi = xcd_contiguous(blockIdx.x, gridDim.x);     // whole clouds per XCD: a cloud's gathered rows stay in one L2
-  const int bx = wi % p.grid_x;
-  const int cb = (wi / p.grid_x) % NCB;
-  const int cloud = wi / (p.grid_x * NCB);
-  const int d = 2 * KH;
-
-  // GroupNorm (+ LeakyReLU) of the producer of E, per channel -> LDS.  A dependent chain (statistics load, fixed-point decode, fp64
-  // arithmetic) that opens every workgroup: it runs after the weight fragments and the first unit's loads have been issued.
-  auto stats_to_lds = [&]() {
-    for (int c = tid; c < KH; c += 256) {
-      float scale = 1.f, shift = 0.f;
-      if (p.enc_gn.stats) {
-        const int g = c / (KH / p.enc_gn.groups);
-        const double* st = p.enc_gn.stats + ((int64_t)cloud * p.enc_gn.groups + g) * kGnWords;
-        const double mean = gn_stat_get(st) * p.enc_gn.inv_count;
-        double var = gn_stat_get(st + 2) * p.enc_gn.inv_count - mean * mean;
-        var = var > 0.0 ? var : 0.0;
-        const double rstd = gn_rstd(var);
-        const double scd = (double)p.enc_gn.gamma[c] * rstd;
-        scale = (float)scd;
-        shift = (float)((double)p.enc_gn.beta[c] - mean * scd);
-      }
-      s_sc[c] = scale;
-      s_sh[c] = shift;
-    }
-  };
-
-  // B fragments: tile t = output columns 64 cb + 2 m + t; the k index of step s, lane half h, element j is channel h KC + 8 s + j
-  // of E (any bijection serves as long as A and B agree: this one makes a lane's A chunk contiguous)
-  const int col0 = 64 * cb + 2 * m;
-  const _Float16* Wh = reinterpret_cast<const _Float16*>(p.Wh);
-  const _Float16* Wl = reinterpret_cast<const _Float16*>(p.Wl);
-  h8 wh[WLDS ? 1 : 2][WLDS ? 1 : NS], wl[WLDS ? 1 : 2][WLDS ? 1 : NS];
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      const int64_t o = (int64_t)(col0 + t) * p.ldw + p.wcol0 + h * KC + 8 * s;
-      if (WLDS) {
-        if (w == 0) {
-          s_w[((t * NS + s) * 2 + 0) * 64 + lane] = *reinterpret_cast<const h8*>(Wh + o);
-          s_w[((t * NS + s) * 2 + 1) * 64 + lane] = *reinterpret_cast<const h8*>(Wl + o);
-        }
-      } else {
-        wh[t][s] = *reinterpret_cast<const h8*>(Wh + o);
-        wl[t][s] = *reinterpret_cast<const h8*>(Wl + o);
-      }
-    }
-  }
-
-  const float slope = p.enc_act ? 0.2f : 1.f;
-  const int pm = (m >> 2) & 1, km = ((m >> 3) << 2) | (m & 3);      // the (point, neighbour) of this lane's A row
-  const float* encb = p.enc + cloud * p.enc_cs + h * KC;
-  const int32_t* nbb = p.neigh + cloud * p.neigh_cs;
-  const float* gpb = p.gp + cloud * p.gp_cs;
-  float* Yb = p.Y + cloud * p.y_cs;
-  float* T = &s_t[w][0];
-  const uint32_t coff = 16u * (uint32_t)(32 * cb + m);     // this lane's [G0 G1 X0 X1] inside a row of gp
-  const bool fhalf = col0 < KH;                            // its column pair lies in the gathered-feature half
-  const int tcol = fhalf ? 0 : col0 - KH;                  // ... else: the pair's columns in E
-
-  const int units = (p.n + 1) >> 1;
-  const int nw = p.grid_x * 4;
-  int u = bx * 4 + w;
-
-  float a[KC];          // this lane's raw E chunk of the CURRENT unit (UV: the U part)
-  float av[UV ? KC : 1], ad = 0.f, wa[UV ? KC : 1];     // UV: the V part, dist of the row, a[c] of this lane's channels
-  int ja = 0;                                           // UV: neighbour index of this lane's A row, one unit further ahead
-  const float* uvb = UV ? p.uv + cloud * p.uv_cs + h * KC : nullptr;
-  const float* distb = UV ? p.dist + cloud * p.dist_cs : nullptr;
-  if (UV) {
-#pragma unroll
-    for (int c = 0; c < KC; ++c) wa[c] = p.w8[(h * KC + c) * 8];
-  }
-  auto load_ja = [&](int uu) { ja = nbb[(uint32_t)min(2 * uu + pm, p.n - 1) * 16u + (uint32_t)km]; };
-  int nb[16];           // the 16 neighbours of this lane's point
-  auto load_unit = [&](int uu) {
-    const int pa = min(2 * uu + pm, p.n - 1);                       // clamped: results of a padding point are never stored
-    if (UV) {
-      const float* su = uvb + (uint32_t)ja * (uint32_t)(2 * KH);
-      const float* sv = uvb + (uint32_t)pa * (uint32_t)(2 * KH) + KH;
-#pragma unroll
-      for (int q = 0; q < KC / 4; ++q) {
-        const float4 v = *reinterpret_cast<const float4*>(su + 4 * q);
-        a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
-        const float4 z = *reinterpret_cast<const float4*>(sv + 4 * q);
-        av[UV ? 4 * q : 0] = z.x; av[UV ? 4 * q + 1 : 0] = z.y; av[UV ? 4 * q + 2 : 0] = z.z; av[UV ? 4 * q + 3 : 0] = z.w;
-      }
-      ad = distb[(uint32_t)(pa * 16 + km)];
-    } else {
-      const float* src = encb + ((uint32_t)(pa * 16 + km)) * (uint32_t)KH;
-#pragma unroll
-      for (int q = 0; q < KC / 4; ++q) {
-        const float4 v = *reinterpret_cast<const float4*>(src + 4 * q);
-        a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
-      }
-    }
-    const int pe = min(2 * uu + h, p.n - 1);
-    const int4* ip = reinterpret_cast<const int4*>(nbb + (uint32_t)pe * 16u);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int4 v = ip[q];
-      nb[4 * q] = v.x; nb[4 * q + 1] = v.y; nb[4 * q + 2] = v.z; nb[4 * q + 3] = v.w;
-    }
-  };
-  if (u < units) {
-    if (UV) load_ja(u);
-    load_unit(u);
-    if (UV && u + nw < units) load_ja(u + nw);
-  }
-  stats_to_lds();
-  __syncthreads();
-  while (u < units) {
-    // ---- the epilogue's gathers, one 16-byte load per neighbour: issued first, consumed last
-    float4 g4[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i)
-      g4[i] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(gpb) + (__umul24((uint32_t)nb[i], ROWB) + coff));
-    // ---- A operand: normalise (GroupNorm + LeakyReLU of the producer), keep fp32 for the pooled operand, split for the MFMAs
-    h8 ah[NS], al[NS];
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int c = 8 * s + j;
-        if (UV) a[c] = __fadd_rn(fmaf(wa[UV ? c : 0], ad, a[c]), av[UV ? c : 0]);     // the row of lfa.mlp1, as lse_uv.hip formed it
-        const float v = fmaf(a[c], s_sc[h * KC + c], s_sh[h * KC + c]);
-        a[c] = fmaxf(v, slope * v);
-      }
-      split8f(&a[8 * s], ah[s], al[s]);
-    }
-#pragma unroll
-    for (int q = 0; q < KC / 4; ++q)
-      *reinterpret_cast<float4*>(&T[m * LD + h * KC + 4 * q]) = make_float4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
-    // ---- next unit's rows and indices: in flight during the MFMAs and the epilogue
-    const int pt = 2 * u + h;
-    const int un = u + nw;
-    if (un < units) {
-      load_unit(un);
-      if (UV && un + nw < units) load_ja(un + nw);
-    }
-    // ---- scores of the enc half: 3 fp16 MFMAs per (tile, k-step)
-    f32x16 acc[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-#pragma unroll
-      for (int s = 0; s < NS; ++s) {
-        const h8 bh = WLDS ? s_w[((t * NS + s) * 2 + 0) * 64 + lane] : wh[WLDS ? 0 : t][WLDS ? 0 : s];
-        const h8 bl = WLDS ? s_w[((t * NS + s) * 2 + 1) * 64 + lane] : wl[WLDS ? 0 : t][WLDS ? 0 : s];
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], bh, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bl, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bh, acc[t], 0, 0, 0);
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-    // ---- epilogue: register i of the accumulator = neighbour i of point (lane >> 5), columns col0 + {0, 1}
-    constexpr float L2E = 1.44269504088896340736f;
-    float y[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      float sc[16];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) sc[i] = acc[t][i] + (t == 0 ? g4[i].x : g4[i].y);
-      float mx = fmaxf(sc[0], sc[1]);
-#pragma unroll
-      for (int i = 2; i < 16; i += 2) mx = fmaxf(mx, fmaxf(sc[i], sc[i + 1]));     // v_max3_f32
-      const float ml = -mx * L2E;
-      float se = 0.f, o = 0.f;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        // softmax numerator e^(s - max) = 2^(s log2e - max log2e): one fma + v_exp_f32 (1 ulp), arguments <= 0 up to rounding
-        const float e = __builtin_amdgcn_exp2f(fmaf(sc[i], L2E, ml));
-        const float xe = T[(8 * (i >> 2) + 4 * h + (i & 3)) * LD + tcol + t];
-        const float x = fhalf ? (t == 0 ? g4[i].z : g4[i].w) : xe;
-        se += e;
-        o = fmaf(x, e, o);
-      }
-      y[t] = o * __builtin_amdgcn_rcpf(se);      // se >= ~1: the max term contributes 2^0
-    }
-    if (pt < p.n) *reinterpret_cast<float2*>(Yb + (uint32_t)pt * (uint32_t)d + (uint32_t)col0) = make_float2(y[0], y[1]);
-    __builtin_amdgcn_wave_barrier();
-    u = un;
-  }
-}
-
 
 // ---------------------------------------------------------------- level 0 (d = 16): the unsplit form, fc [gather(f) ; enc]
 // The score GEMM contracts all 16 channels [fN[nb] (8) ; E (8)] (splitting it by linearity would gather 64 more bytes per row
@@ -415,45 +208,182 @@ __global__ __launch_bounds__(256) void att_pool16_kernel(const AttPool16Args p) 
   }
 }
 
-template <int KH>
-void launch_k(const AttPoolArgs& a, hipStream_t st) {
-  const int units = (a.n + 1) / 2;
-  // ~8 units per wave; no cross-workgroup reduction in this kernel, so the grid may follow the launch size (same bits under
-  // any unit -> wave assignment): a single cloud still spreads over the chip
-  int blocks = (units + 31) / 32;
-  const int ncb = KH / 32;
-  const int64_t total = (int64_t)blocks * ncb * a.clouds;
-  if (total < 512) {
-    const int want = (int)((512 + (int64_t)ncb * a.clouds - 1) / ((int64_t)ncb * a.clouds)), most = (units + 3) / 4;
-    const int nb = want < most ? want : most;
-    if (nb > blocks) blocks = nb;
+// ---------------------------------------------------------------- levels 1 / 2 (d = 64 / 128): the UNSPLIT form on the same organisation
+// All d channels [fN[nb] (d/2) ; E (d/2)] are contracted, like level 0 does: lane half h = 0 forms the gathered-feature part of an A row (one index,
+// one row of the raw features, their GroupNorm + LeakyReLU), h = 1 the E part (from memory or from the tables of
+// lse_uv.hip); the pooled operand comes back from the wave's LDS tile: 8 KB of global reads per two points at d = 64.  d = 128: two workgroups per row range, one per 64 output columns
+// (the first owns columns of the feature half, the second of the E half: each keeps only that half of the A rows in its LDS tile).
+template <int KH, bool UV>
+__global__ __launch_bounds__(256) void att_full_kernel(const AttPool16Args p) {
+  constexpr int KC = KH;          // channels of its row a lane holds (h = 0: features, h = 1: E)
+  constexpr int NS = KH / 8;      // k-steps of 16 over the 2 KH channels
+  constexpr int NCB = KH / 32;    // workgroups per row range: 64 output columns each
+  constexpr int LD = 72;          // LDS row stride (floats): rows 4 apart land 32 banks apart
+  __shared__ float s_sc[2 * KH];
+  __shared__ float s_sh[2 * KH];
+  __shared__ __attribute__((aligned(16))) float s_t[4][32 * LD];
+  __shared__ h8 s_w[2 * NS * 2 * 64];          // [tile][k-step][high | low][lane]
+
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 31, h = lane >> 5;
+  const int wi = xcd_contiguous(blockIdx.x, gridDim.x);
+  const int bx = wi % p.grid_x;
+  const int cb = (wi / p.grid_x) % NCB;
+  const int cloud = wi / (p.grid_x * NCB);
+  const int col0 = 64 * cb;
+
+  // B fragments -> LDS: tile t = columns 64 cb + 32 t + m; the k index of step s, lane half h, element j is channel KH h + 8 s + j
+  if (w == 0) {
+    const _Float16* Wh = reinterpret_cast<const _Float16*>(p.Wh);
+    const _Float16* Wl = reinterpret_cast<const _Float16*>(p.Wl);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const int o = (col0 + 32 * t + m) * p.ldw + KH * h + 8 * s;
+        s_w[((t * NS + s) * 2 + 0) * 64 + lane] = *reinterpret_cast<const h8*>(Wh + o);
+        s_w[((t * NS + s) * 2 + 1) * 64 + lane] = *reinterpret_cast<const h8*>(Wl + o);
+      }
   }
-  if (blocks < 1) blocks = 1;
-  AttPoolArgs b = a;
-  b.grid_x = blocks;
-  const dim3 grid((unsigned)((int64_t)blocks * ncb * a.clouds));
-  if (a.enc) hipLaunchKernelGGL((att_pool_kernel<KH, false>), grid, dim3(256), 0, st, b);
-  else if (KH == 32) hipLaunchKernelGGL((att_pool_kernel<KH == 32 ? 32 : 64, KH == 32>), grid, dim3(256), 0, st, b);
+  const float slope = (h ? p.enc_act : p.f_act) ? 0.2f : 1.f;
+  const int pm = (m >> 2) & 1, km = ((m >> 3) << 2) | (m & 3);      // the (point, neighbour) of this lane's A row
+  const float* fb = p.f + cloud * p.f_cs;
+  const float* eb = p.enc + cloud * p.enc_cs;
+  const int32_t* nbb = p.neigh + cloud * p.neigh_cs;
+  const float* uvb = UV ? p.uv + cloud * p.uv_cs : nullptr;
+  const float* distb = UV ? p.dist + cloud * p.dist_cs : nullptr;
+  float* Yb = p.Y + cloud * p.y_cs;
+  float* T = &s_t[w][0];
+  float wa[UV ? KC : 1];
+  if (UV) {
+#pragma unroll
+    for (int c = 0; c < KC; ++c) wa[c] = p.w8[c * 8];
+  }
+
+  const int units = (p.n + 1) >> 1;
+  const int nw = p.grid_x * 4;
+  int u = bx * 4 + w;
+
+  float a[KC], av[UV ? KC : 1], ad = 0.f;
+  int jn = 0;                                   // neighbour index of this lane's A row, one unit further ahead than the rows
+  auto point_of = [&](int uu) { return min(2 * uu + pm, p.n - 1); };
+  auto load_idx = [&](int uu) { jn = nbb[(uint32_t)point_of(uu) * 16u + (uint32_t)km]; };
+  auto load_rows = [&](int uu) {
+    const int pt = point_of(uu);
+    // one instruction stream serves both lane halves through per-lane addresses: h = 0 the gathered feature row, h = 1 the E row
+    // (UV: the neighbour's U row; its V row and dist follow in loads only the h = 1 lanes use)
+    const float* src = h ? (UV ? uvb + (uint32_t)jn * (uint32_t)(2 * KH) : eb + ((uint32_t)(pt * 16 + km)) * (uint32_t)KH) : fb + (uint32_t)jn * (uint32_t)p.f_ld;
+#pragma unroll
+    for (int q = 0; q < KC / 4; ++q) {
+      const float4 v = *reinterpret_cast<const float4*>(src + 4 * q);
+      a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
+    }
+    if (UV) {
+      const float* sv = uvb + (uint32_t)pt * (uint32_t)(2 * KH) + (uint32_t)KH;
+#pragma unroll
+      for (int q = 0; q < KC / 4; ++q) {
+        const float4 z = *reinterpret_cast<const float4*>(sv + 4 * q);
+        av[UV ? 4 * q : 0] = z.x; av[UV ? 4 * q + 1 : 0] = z.y; av[UV ? 4 * q + 2 : 0] = z.z; av[UV ? 4 * q + 3 : 0] = z.w;
+      }
+      ad = distb[(uint32_t)(pt * 16 + km)];
+    }
+  };
+  if (u < units) {
+    load_idx(u);
+    load_rows(u);
+    if (u + nw < units) load_idx(u + nw);
+  }
+  // GroupNorm scale / shift of both operand halves (channels 0 .. KH - 1 the features, then E): decoded while the first loads fly
+  if (tid < 2 * KH) {
+    const GnRef& g = tid < KH ? p.f_gn : p.enc_gn;
+    const int c = tid < KH ? tid : tid - KH;
+    float scale = 1.f, shift = 0.f;
+    if (g.stats) {
+      const int grp = c / (KH / g.groups);
+      const double* st = g.stats + ((int64_t)cloud * g.groups + grp) * kGnWords;
+      const double mean = gn_stat_get(st) * g.inv_count;
+      double var = gn_stat_get(st + 2) * g.inv_count - mean * mean;
+      var = var > 0.0 ? var : 0.0;
+      const double rstd = gn_rstd(var);
+      const double scd = (double)g.gamma[c] * rstd;
+      scale = (float)scd;
+      shift = (float)((double)g.beta[c] - mean * scd);
+    }
+    s_sc[tid] = scale;
+    s_sh[tid] = shift;
+  }
+  __syncthreads();
+  while (u < units) {
+    // ---- A operand: normalise, keep fp32 in LDS for the pooled operand, split for the MFMAs
+    h8 ah[NS], al[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = 8 * s + j;
+        if (UV) {        // the row of lfa.mlp1, as lse_uv.hip formed it (lanes of the E half)
+          const float e = __fadd_rn(fmaf(wa[UV ? c : 0], ad, a[c]), av[UV ? c : 0]);
+          a[c] = h ? e : a[c];
+        }
+        const float v = fmaf(a[c], s_sc[KH * h + c], s_sh[KH * h + c]);
+        a[c] = fmaxf(v, slope * v);
+      }
+      split8f(&a[8 * s], ah[s], al[s]);
+    }
+    // the pooled operand of this workgroup's 64 columns: d = 64 both halves (32 + 32), d = 128 the half the columns belong to
+    if (KH == 32 || h == cb) {
+#pragma unroll
+      for (int q = 0; q < KC / 4; ++q)
+        *reinterpret_cast<float4*>(&T[m * LD + (KH == 32 ? 32 * h : 0) + 4 * q]) = make_float4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
+    }
+    // ---- next unit's rows (and the index one unit further): in flight during the MFMAs and the epilogue
+    const int pt = 2 * u + h;
+    const int un = u + nw;
+    if (un < units) {
+      load_rows(un);
+      if (un + nw < units) load_idx(un + nw);
+    }
+    // ---- scores: 3 fp16 MFMAs per (tile, k-step)
+    f32x16 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const h8 bh = s_w[((t * NS + s) * 2 + 0) * 64 + lane];
+        const h8 bl = s_w[((t * NS + s) * 2 + 1) * 64 + lane];
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], bh, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bl, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bh, acc[t], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- epilogue: register i of the accumulator = neighbour i of point (lane >> 5), column 64 cb + 32 t + m
+    constexpr float L2E = 1.44269504088896340736f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      float mx = fmaxf(acc[t][0], acc[t][1]);
+#pragma unroll
+      for (int i = 2; i < 16; i += 2) mx = fmaxf(mx, fmaxf(acc[t][i], acc[t][i + 1]));
+      const float ml = -mx * L2E;
+      float se = 0.f, o = 0.f;
+      const float* Tc = &T[4 * h * LD + 32 * t + m];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float e = __builtin_amdgcn_exp2f(fmaf(acc[t][i], L2E, ml));
+        const float x = Tc[(8 * (i >> 2) + (i & 3)) * LD];
+        se += e;
+        o = fmaf(x, e, o);
+      }
+      if (pt < p.n) Yb[(uint32_t)pt * (uint32_t)(2 * KH) + (uint32_t)(col0 + 32 * t + m)] = o * __builtin_amdgcn_rcpf(se);
+    }
+    __builtin_amdgcn_wave_barrier();
+    u = un;
+  }
 }
 
 }  // namespace
-
-bool launch_att_pool(const AttPoolArgs& a, hipStream_t st) {
-  if (a.n <= 0 || a.clouds <= 0) return true;
-  if (!a.Wh || !a.Wl || !a.gp || !a.neigh || !a.Y) return false;
-  if (!a.enc && (a.KH != 32 || !a.uv || !a.dist || !a.w8 || (reinterpret_cast<uintptr_t>(a.uv) % 16) != 0 || (a.uv_cs % 4) != 0)) return false;
-  if ((a.ldw % 8) != 0 || (a.wcol0 % 8) != 0 || (reinterpret_cast<uintptr_t>(a.Wh) % 16) != 0 || (reinterpret_cast<uintptr_t>(a.Wl) % 16) != 0) return false;
-  if ((a.enc && ((reinterpret_cast<uintptr_t>(a.enc) % 16) != 0 || (a.enc_cs % 4) != 0)) || (reinterpret_cast<uintptr_t>(a.neigh) % 16) != 0 || (a.neigh_cs % 4) != 0) return false;
-  if ((reinterpret_cast<uintptr_t>(a.gp) % 16) != 0 || (a.gp_cs % 4) != 0 || (reinterpret_cast<uintptr_t>(a.Y) % 8) != 0 || (a.y_cs % 2) != 0) return false;
-  if (a.enc_gn.stats && (a.KH % a.enc_gn.groups) != 0) return false;
-  // 24-bit neighbour indices and 32-bit byte offsets inside a cloud
-  if (a.n >= (1 << 24) || (int64_t)a.n * 16 * a.KH * 4 >= ((int64_t)1 << 32) || (int64_t)a.n * 4 * a.KH * 4 >= ((int64_t)1 << 32)) return false;
-  switch (a.KH) {
-    case 32: launch_k<32>(a, st); return true;
-    case 64: launch_k<64>(a, st); return true;
-    default: return false;
-  }
-}
 
 bool launch_att_pool16(const AttPool16Args& a, hipStream_t st) {
   if (a.n <= 0 || a.clouds <= 0) return true;
@@ -476,6 +406,34 @@ bool launch_att_pool16(const AttPool16Args& a, hipStream_t st) {
   b.grid_x = blocks;
   if (a.enc) hipLaunchKernelGGL(att_pool16_kernel<false>, dim3((unsigned)((int64_t)blocks * a.clouds)), dim3(256), 0, st, b);
   else hipLaunchKernelGGL(att_pool16_kernel<true>, dim3((unsigned)((int64_t)blocks * a.clouds)), dim3(256), 0, st, b);
+  return true;
+}
+
+// levels 1 / 2 (d = 64 / 128), unsplit: the arguments of level 0 with KH-channel halves (f [n][f_ld >= KH], E [n * 16][KH] or - KH = 32 -
+// tables [n][64]), fc [2 KH][ldw], Y [n][2 KH]
+bool launch_att_full(const AttPool16Args& a, int KH, hipStream_t st) {
+  if (a.n <= 0 || a.clouds <= 0) return true;
+  if ((KH != 32 && KH != 64) || !a.Wh || !a.Wl || !a.f || !a.neigh || !a.Y) return false;
+  if (!a.enc && (KH != 32 || !a.uv || !a.dist || !a.w8 || (reinterpret_cast<uintptr_t>(a.uv) % 16) != 0 || (a.uv_cs % 4) != 0)) return false;
+  if ((a.ldw % 8) != 0 || (reinterpret_cast<uintptr_t>(a.Wh) % 16) != 0 || (reinterpret_cast<uintptr_t>(a.Wl) % 16) != 0) return false;
+  if ((reinterpret_cast<uintptr_t>(a.f) % 16) != 0 || (a.f_cs % 4) != 0 || (a.f_ld % 4) != 0 || (a.enc && ((reinterpret_cast<uintptr_t>(a.enc) % 16) != 0 || (a.enc_cs % 4) != 0))) return false;
+  if ((a.f_gn.stats && (KH % a.f_gn.groups) != 0) || (a.enc_gn.stats && (KH % a.enc_gn.groups) != 0)) return false;
+  if ((int64_t)a.n * 16 * KH * 4 >= ((int64_t)1 << 32)) return false;
+  const int units = (a.n + 1) / 2, ncb = KH / 32;
+  int blocks = (units + 31) / 32;       // ~8 units per wave; no cross-workgroup reduction: the grid may follow the launch size
+  const int64_t total = (int64_t)blocks * ncb * a.clouds;
+  if (total < 512) {
+    const int want = (int)((512 + (int64_t)ncb * a.clouds - 1) / ((int64_t)ncb * a.clouds)), most = (units + 3) / 4;
+    const int nb = want < most ? want : most;
+    if (nb > blocks) blocks = nb;
+  }
+  if (blocks < 1) blocks = 1;
+  AttPool16Args b = a;
+  b.grid_x = blocks;
+  const dim3 grid((unsigned)((int64_t)blocks * ncb * a.clouds));
+  if (KH == 64) hipLaunchKernelGGL((att_full_kernel<64, false>), grid, dim3(256), 0, st, b);
+  else if (a.enc) hipLaunchKernelGGL((att_full_kernel<32, false>), grid, dim3(256), 0, st, b);
+  else hipLaunchKernelGGL((att_full_kernel<32, true>), grid, dim3(256), 0, st, b);
   return true;
 }
 

@@ -45,7 +45,7 @@ struct HostParam {
 };
 
 struct Mlp2dW { const float *W = nullptr, *b = nullptr, *gamma = nullptr, *beta = nullptr; int cin = 0, cout = 0, groups = 0; };
-struct AttW { const float* fc = nullptr; const float* fc_g = nullptr; const float* fc_p = nullptr; int d = 0; Mlp2dW mlp; };   // fc_g: up_fc_g, fc_p: up_fc_p
+struct AttW { const float* fc = nullptr; const float* fc_g = nullptr; int d = 0; Mlp2dW mlp; };   // fc_g: see up_fc_g
 struct BlockW { Mlp2dW mlp1, lfa1, lfa2, mlp2, skip; AttW att1, att2; int d_in = 0, d = 0; const float* lse_w8 = nullptr; };   // lse_w8: up_lse_uv
 struct LinW { const float *W = nullptr, *b = nullptr; int cin = 0, cout = 0; };
 struct RandlaW { Mlp2dW pre; BlockW blk[4]; Mlp2dW mid; Mlp2dW dec[4]; const float* out_w = nullptr; int dec_out = 0; LinW fc[3]; int cin = 0, ncls = 0;
@@ -317,27 +317,6 @@ size_t up_fc_g(Uploader& u, const HostParam& fc, int d) {
   return u.put(w);
 }
 
-// att_pool.hip (d = 64, 128): the per-point GEMM in front of the pooling writes ONE row per point in the pooling kernel's gather
-// order: per 64-column block cb and lane c (0 .. 31) the four floats [G[col], G[col + 1], X0, X1], col = 64 cb + 2 c, G = W1 fN
-// (W1 = fc[:, :d/2]) and X = fN[col], fN[col + 1] where the column pair lies in the gathered-feature half (col < d/2), else 0.
-// Its weight matrix is therefore W1's rows in that order with identity / zero rows in between: fN x 1.0 + zeros is exact in
-// the fp32 MFMA, so X is the normalised feature itself - everything the pooling gathers of a neighbour is one 16-byte load.
-size_t up_fc_p(Uploader& u, const HostParam& fc, int d) {
-  if (d != 64 && d != 128) return 0;
-  const int h = d / 2;
-  std::vector<float> w((size_t)(2 * d) * h, 0.f);
-  for (int cb = 0; cb < d / 64; ++cb)
-    for (int c = 0; c < 32; ++c) {
-      const int col = 64 * cb + 2 * c;
-      const size_t r0 = (size_t)(128 * cb + 4 * c);
-      for (int t = 0; t < 2; ++t) {
-        for (int k = 0; k < h; ++k) w[(r0 + t) * h + k] = fc.data[(size_t)(col + t) * d + k];
-        if (col + t < h) w[(r0 + 2 + t) * h + (col + t)] = 1.f;
-      }
-    }
-  return u.put(w);
-}
-
 // lse_uv.hip: lfa.mlp1 of a level with d / 2 <= 32 channels, folded for the split by linearity
 //   enc_raw[i, k][c] = a[c] dist + U[j][c] + V[i][c]:   per channel {a, ux, uy, uz, vx, vy, vz, b} with u = W[:, 1:4] + W[:, 7:10] (the
 // neighbour's coordinates enter through the offset and through their own channels), v = W[:, 4:7] - W[:, 1:4], b = bias.
@@ -355,7 +334,7 @@ size_t up_lse_uv(Uploader& u, const HostParam& w, const HostParam& b, int kh) {
 
 struct RandlaOff {
   Mlp2dOff pre, mid, dec[4];
-  struct { Mlp2dOff mlp1, lfa1, lfa2, mlp2, skip, a1m, a2m; size_t fc1, fc2, fc1g, fc2g, fc1p, fc2p, lse8; } blk[4];
+  struct { Mlp2dOff mlp1, lfa1, lfa2, mlp2, skip, a1m, a2m; size_t fc1, fc2, fc1g, fc2g, lse8; } blk[4];
   size_t out_w; int dec_out;
   LinOff fc[3];
 };
@@ -369,12 +348,10 @@ RandlaOff up_randla(dsir_ctx* c, Uploader& u, const std::string& pre) {
     r.blk[i].lse8 = up_lse_uv(u, P(c, p + ".lfa.mlp1.conv.weight"), P(c, p + ".lfa.mlp1.conv.bias"), c->cfg.d_out[i] / 2);
     r.blk[i].fc1 = u.put(P(c, p + ".lfa.att_pooling_1.fc.weight").data);
     r.blk[i].fc1g = up_fc_g(u, P(c, p + ".lfa.att_pooling_1.fc.weight"), c->cfg.d_out[i]);
-    r.blk[i].fc1p = up_fc_p(u, P(c, p + ".lfa.att_pooling_1.fc.weight"), c->cfg.d_out[i]);
     r.blk[i].a1m = up_mlp2d(c, u, p + ".lfa.att_pooling_1.mlp");
     r.blk[i].lfa2 = up_mlp2d(c, u, p + ".lfa.mlp2");
     r.blk[i].fc2 = u.put(P(c, p + ".lfa.att_pooling_2.fc.weight").data);
     r.blk[i].fc2g = up_fc_g(u, P(c, p + ".lfa.att_pooling_2.fc.weight"), c->cfg.d_out[i]);
-    r.blk[i].fc2p = up_fc_p(u, P(c, p + ".lfa.att_pooling_2.fc.weight"), c->cfg.d_out[i]);
     r.blk[i].a2m = up_mlp2d(c, u, p + ".lfa.att_pooling_2.mlp");
     r.blk[i].mlp2 = up_mlp2d(c, u, p + ".mlp2");
     r.blk[i].skip = up_mlp2d(c, u, p + ".mlp_skip");
@@ -402,9 +379,6 @@ RandlaW bind_randla(const float* base, const RandlaOff& o, const dsir_cfg& g) {
     b.att1.fc_g = g.d_out[i] >= 64 ? base + o.blk[i].fc1g : nullptr;
     b.att2.fc_g = g.d_out[i] >= 64 ? base + o.blk[i].fc2g : nullptr;
     b.lse_w8 = (g.d_out[i] == 16 || g.d_out[i] == 64) ? base + o.blk[i].lse8 : nullptr;
-    const bool pooled = g.d_out[i] == 64 || g.d_out[i] == 128;
-    b.att1.fc_p = pooled ? base + o.blk[i].fc1p : nullptr;
-    b.att2.fc_p = pooled ? base + o.blk[i].fc2p : nullptr;
     b.d = g.d_out[i]; b.d_in = b.mlp1.cin;
   }
   r.mid = bind_mlp2d(base, o.mid);
@@ -415,7 +389,7 @@ RandlaW bind_randla(const float* base, const RandlaOff& o, const dsir_cfg& g) {
   return r;
 }
 
-// A/B switch: DSIR_NO_ATT_POOL = the round-3 EPI_ATT2 kernels (pw_stream.hip) for d = 64 / 128 instead of att_pool.hip
+// A/B switch: DSIR_NO_ATT_POOL = the round-3 EPI_ATT / EPI_ATT2 kernels (pw_stream.hip) for d = 16 / 64 / 128 instead of att_pool.hip
 bool att_pool_enabled() {
   static const bool off = tuning_flag("DSIR_NO_ATT_POOL");
   return !off;
@@ -513,26 +487,23 @@ struct Sched {
     y.p = c->ws.get<float>((size_t)clouds * n * w.d);
     y.C = w.d; y.rows = n;
     static const bool no_att2 = tuning_flag("DSIR_NO_ATT2");   // A/B switch
-    if (!no_att2 && att_pool_enabled() && w.fc_p && c->dweights16 && f.C * 2 == w.d && enc.C * 2 == w.d && !(s2 && s2_mode)) {
-      // att_pool.hip: gp = the scores' G half and the features in the pooling's gather order (exact-fp32 MFMA GEMM, up_fc_p), then
-      // two points per wave with the softmax in registers
-      const int h = w.d / 2;
-      float* gp = c->ws.get<float>((size_t)clouds * n * 4 * h);
-      if (c->ws.overflow) return y;
-      GemmArgs g;
-      g.amode = A_SEGS; g.nseg = 1; g.seg[0] = seg_of(f);
-      g.W = w.fc_p; g.ldw = h; g.bias = nullptr; g.Cin = h; g.Cout = 4 * h; g.M = n; g.clouds = clouds;
-      g.epi = EPI_LINEAR; g.Y = gp; g.y_cloud_stride = (int64_t)n * 4 * h; g.ldy = 4 * h;
-      if (launch_pw_stream(g, st)) {
-        AttPoolArgs a;
-        a.enc = enc.p; a.enc_cs = (int64_t)enc.rows * enc.C; a.enc_gn = enc.gn; a.enc_act = enc.act;
-        a.uv = enc.uv; a.uv_cs = (int64_t)n * 2 * enc.C; a.dist = enc.dist; a.dist_cs = (int64_t)n * kKnn; a.w8 = enc.w8;
-        a.gp = gp; a.gp_cs = (int64_t)n * 4 * h; a.neigh = neigh; a.neigh_cs = neigh_cs;
-        const size_t off = (size_t)(w.fc - c->dweights);
-        a.Wh = c->dweights16 + off; a.Wl = c->dweights16 + c->nweights + off; a.ldw = w.d; a.wcol0 = h;
-        a.Y = y.p; a.y_cs = (int64_t)n * w.d; a.n = n; a.clouds = clouds; a.KH = h;
-        if (launch_att_pool(a, st)) return y;
-      }
+    if (att_pool_enabled() && (w.d == 64 || w.d == 128) && f.C * 2 == w.d && enc.C * 2 == w.d && (enc.p || w.d == 64) && c->dweights16 && w.fc >= c->dweights && w.fc < c->dweights + c->nweights &&
+        !(s2 && s2_mode)) {
+      // att_pool.hip, levels 1 / 2 unsplit: the whole score contraction on the matrix pipe, nothing gathered in the epilogue
+      AttPool16Args a;
+      a.f = f.p; a.f_cs = (int64_t)f.rows * f.C; a.f_ld = f.C; a.f_gn = f.gn; a.f_act = f.act;
+      a.enc = enc.p; a.enc_cs = (int64_t)enc.rows * enc.C; a.enc_gn = enc.gn; a.enc_act = enc.act;
+      a.uv = enc.uv; a.uv_cs = (int64_t)n * 2 * enc.C; a.dist = enc.dist; a.dist_cs = (int64_t)n * kKnn; a.w8 = enc.w8;
+      a.neigh = neigh; a.neigh_cs = neigh_cs;
+      const size_t off = (size_t)(w.fc - c->dweights);
+      a.Wh = c->dweights16 + off; a.Wl = c->dweights16 + c->nweights + off; a.ldw = w.d;
+      a.Y = y.p; a.y_cs = (int64_t)n * w.d; a.n = n; a.clouds = clouds;
+      if (!c->ws.overflow && launch_att_full(a, w.d / 2, st)) return y;
+    }
+    if (!enc.p && w.d >= 64) {     // table-only rows have no other consumer (lse_uv_enabled() excludes this)
+      if (!c->ws.overflow) c->sched_error = "attentive pooling: no kernel took the table-only position encoding";
+      c->ws.overflow = true;
+      return y;
     }
     if (!no_att2 && w.d >= 64 && w.fc_g && f.C * 2 == w.d && enc.C * 2 == w.d) {   // d = 16: the extra gathers cost more than the MFMAs saved
       // score GEMM split by linearity: fc [gather(f); enc] = gather(W1 f) + W2 enc  (kernels.h, EPI_ATT2).

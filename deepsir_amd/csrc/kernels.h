@@ -104,31 +104,7 @@ bool launch_pw_stream(const GemmArgs& a, hipStream_t st);
 // wide-layer path, LDS-tiled 128/64 x 64 x 32 (pw_tile.hip): Cin a multiple of 32 in [64,768], Cout >= 64
 bool launch_pw_tile(const GemmArgs& a, hipStream_t st);
 
-// att_pool.hip - attentive pooling of the k = 16 layers of levels 1 / 2 (d = 64 / 128), score GEMM split by linearity: two points per
-// wave on v_mfma_f32_32x32x16_f16, softmax and weighted sum in registers (no cross-lane step)
-struct AttPoolArgs {
-  const float* enc = nullptr;        // E [clouds][n * 16][KH] raw conv outputs of the position-encoding branch, or nullptr:
-  int64_t enc_cs = 0;
-  const float* uv = nullptr;         //   E rebuilt from the per-point tables of lse_uv.hip: [clouds][n][2 KH], dist [clouds][n * 16], w8 [KH][8]
-  int64_t uv_cs = 0;
-  const float* dist = nullptr;
-  int64_t dist_cs = 0;
-  const float* w8 = nullptr;
-  GnRef enc_gn = {nullptr, nullptr, nullptr, 0, 0.0};   // its lazy GroupNorm
-  int enc_act = 1;                   // LeakyReLU(0.2) after it
-  const float* gp = nullptr;         // [clouds][n][4 KH]: per 64-column block and lane c: [G[col], G[col+1], X0, X1], col = 64 cb + 2 c (engine.hip, up_fc_p)
-  int64_t gp_cs = 0;
-  const int32_t* neigh = nullptr;    // [clouds][n][16]
-  int64_t neigh_cs = 0;
-  const void* Wh = nullptr;          // fp16 split of fc [2 KH][ldw]; the contraction reads columns [wcol0, wcol0 + KH) (= W2)
-  const void* Wl = nullptr;
-  int ldw = 0, wcol0 = 0;
-  float* Y = nullptr;                // [clouds][n][2 KH]
-  int64_t y_cs = 0;
-  int n = 0, clouds = 0, KH = 0;
-  int grid_x = 0;                    // filled by the launcher
-};
-bool launch_att_pool(const AttPoolArgs& a, hipStream_t st);   // false => outside the envelope (caller takes the EPI_ATT2 kernels)
+// att_pool.hip - attentive pooling of the k = 16 layers of levels 0 - 2 on v_mfma_f32_32x32x16_f16: softmax and weighted sum in registers
 // level 0 (d = 16), unsplit: scores = fc [gather(f) ; E] with both halves 8 channels wide; four points per wave
 struct AttPool16Args {
   const float* f = nullptr;          // [clouds][n][f_ld], 8 channels used: the features that are gathered (raw conv outputs)
@@ -151,6 +127,9 @@ struct AttPool16Args {
   int grid_x = 0;                    // filled by the launcher
 };
 bool launch_att_pool16(const AttPool16Args& a, hipStream_t st);
+// levels 1 / 2 (d = 64 / 128) in the same unsplit form: KH-channel halves (f [n][f_ld], E [n * 16][KH] or - KH = 32 - tables [n][64]),
+// fc [2 KH][ldw], Y [n][2 KH]
+bool launch_att_full(const AttPool16Args& a, int KH, hipStream_t st);
 
 // lse_uv.hip - lfa.mlp1 of levels 0 / 1 split by linearity into per-point tables: writes U | V and dist, commits the layer's GroupNorm
 // statistics; the layer's output itself is never stored (consumers: att_pool.hip, pw_stream.hip loader S_UV)
