@@ -34,7 +34,7 @@ sys.path.insert(0, ROOT)
 PEAK_F16_MFMA_TFLOPS = 2500.0   # dense fp16/bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_F32_MFMA_TFLOPS = 157.3    # same guide: v_mfma_f32_16x16x4_f32 dense peak (= the fp32 vector peak)
 PEAK_HBM_GBPS = 8000.0          # HBM3E spec (6.3 TB/s measured achievable)
-SCREEN_MIN_WORK = 200_000_000   # csrc/engine.hip: P*J*K from which dsir_register screens the arg-min
+SCREEN_MIN_WORK = 100_000_000   # csrc/engine.hip: P*J*K from which dsir_register screens the arg-min
 
 
 def match_flops(P, J, K):
@@ -519,13 +519,13 @@ def main():
                        "note": "the reference's own evaluation mode (test.py:56 BATCH_SIZE = 1, BASELINE configs[1] 'batch=1')"}
 
         # K single-pair registrations in flight (deepsir_amd/serve.py): what a test.py-style caller that feeds one pair per call
-        # AHEAD of the results gets - requests coalesced into hipGraph-replayed batches of K / 2 on two engines in turn
+        # AHEAD of the results gets - requests coalesced into hipGraph-replayed batches of K / engines on the engines in turn
         if not a.no_latency and N <= 16384:
             from deepsir_amd.serve import PairServer
             serving = {}
-            for K_, E_ in ((2, 2), (4, 2), (8, 2), (8, 4)):
+            for K_, E_ in ((2, 1), (4, 1), (8, 1), (8, 2), (16, 2)):
                 srv = PairServer(cfg, sd, dev_index, max_points=N, max_in_flight=K_, engines=E_, n_iter=n_iter, want_aux=False)
-                nreq = min(L, 64)
+                nreq = 128
                 reqs = [(src[i % L], ref[i % L]) for i in range(nreq)]
                 srv.run_closed_loop(reqs[: 2 * K_], K_)               # captures the graphs
                 torch.cuda.synchronize()

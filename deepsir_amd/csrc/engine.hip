@@ -1322,7 +1322,7 @@ static int register_enqueue(dsir_ctx* c, const dsir_pair_batch* in, int n_iter, 
   // both paths return the same bits, so the choice is free: small problems (latency-bound, e.g. one pair in flight) take
   // the single exhaustive kernel, large ones the three-kernel screened path.  dsir_enable_screen / DSIR_NO_SCREEN: A/B
   // switch to the exhaustive fp32 kernel throughout
-  static const long long screen_min = tuning_int("DSIR_SCREEN_MIN_WORK", 200000000ll);   // A/B hook
+  static const long long screen_min = tuning_int("DSIR_SCREEN_MIN_WORK", 100000000ll);   // A/B hook
   const bool screen = c->screen_mode && !in->forced_idx && (int64_t)P * J * K >= screen_min;
   void *sc_ah = nullptr, *sc_al = nullptr, *sc_bh = nullptr, *sc_bl = nullptr, *sc_scratch = nullptr;
   float *sc_sa = nullptr, *sc_sb = nullptr;

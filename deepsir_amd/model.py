@@ -188,7 +188,7 @@ class Network(nn.Module):
             self._server_dirty = False
         return srv
 
-    def serve(self, max_points: int = 5000, max_in_flight: int = 8, engines: int = 2, n_iter: Optional[int] = None, want_aux: bool = True):
+    def serve(self, max_points: int = 5000, max_in_flight: int = 8, engines: Optional[int] = None, n_iter: Optional[int] = None, want_aux: bool = True):
         """A ``deepsir_amd.serve.PairServer`` on this network's weights: K single-pair registrations in flight
         (the reference's batch-1 evaluation mode, test.py:56, fed ahead)."""
         from .serve import PairServer

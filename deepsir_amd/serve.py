@@ -9,7 +9,9 @@ small scheduler instead:
 * requests of the same shape are coalesced, up to ``max_batch = K / engines`` of them, into one ``dsir_register`` call that
   is replayed from a captured hipGraph (one graph per batch size, ``include/dsir.h`` ``dsir_enable_graph``);
 * ``engines`` contexts on their own HIP streams take the batches in turn, so the launch chain of one batch fills the gaps of
-  the other's;
+  the other's.  Measured (tools/serve_bench.py, 5000-point pairs): up to 8 requests in flight ONE engine with the whole window in
+  its batch is fastest (K = 8: 1620 pairs/s against 1575 as 2 x 4 - a batch of 8 costs little more than a batch of 4), from 16 on
+  two engines win (K = 16: 2500 against 2310, K = 32: 3300 against 3135); four never do.  ``engines=None`` picks by that rule;
 * ``future.result()`` waits for that request's batch only.
 
 A pair's result does not depend on what shares its batch (every kernel's tiling is a function of the per-cloud shape alone,
@@ -91,11 +93,13 @@ class _Slot:
 
 
 class PairServer:
-    def __init__(self, cfg: NetConfig, state_dict, device: int = 0, max_points: int = 5000, max_in_flight: int = 8, engines: int = 2,
-                 n_iter: int = 5, want_aux: bool = True):
+    def __init__(self, cfg: NetConfig, state_dict, device: int = 0, max_points: int = 5000, max_in_flight: int = 8,
+                 engines: Optional[int] = None, n_iter: int = 5, want_aux: bool = True):
         if cfg.pipeline != "align":
             raise EngineError("PairServer serves the align pipeline (dsir_register)")
         self.cfg, self.n_iter, self.want_aux = cfg, int(n_iter), bool(want_aux)
+        if engines is None:
+            engines = 1 if int(max_in_flight) <= 8 else 2
         self.engines = max(1, min(int(engines), int(max_in_flight)))
         self.max_batch = max(1, int(max_in_flight) // self.engines)
         self.max_in_flight = self.max_batch * self.engines
