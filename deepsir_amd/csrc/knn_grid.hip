@@ -170,6 +170,31 @@ struct TopLex {
     const int i = (int)(unsigned)(k[t] & 0xffffffffull);
     return i == 0x7fffffff ? self : i;
   }
+  static __device__ __forceinline__ void ce(unsigned long long& a, unsigned long long& b) {
+    const bool sw = b < a;
+    const unsigned long long lo = sw ? b : a, hi = sw ? a : b;
+    a = lo; b = hi;
+  }
+  // The 16 smallest of (this list) U (16 more keys in any order; unused slots hold the sentinel): Batcher's odd-even merge sort of
+  // the newcomers (63 compare-exchanges, checked over all 2^16 0/1 inputs when the list was generated), then min(k[i], q[15 - i]) -
+  // the lower half of the union as a bitonic sequence - and a bitonic merge (32 compare-exchanges).  ~500 VALU instructions whatever
+  // the number of live newcomers, against ~130 per newcomer for insert(): the burst form of 16 insertions.  Keys are unique (the
+  // sentinel aside), so the result is the insertions', bit for bit.
+  __device__ __forceinline__ void merge16(unsigned long long (&q)[kKnn]) {
+#define CE(a, b) ce(q[a], q[b]);
+    CE(0,1) CE(2,3) CE(4,5) CE(6,7) CE(8,9) CE(10,11) CE(12,13) CE(14,15) CE(0,2) CE(1,3) CE(4,6) CE(5,7) CE(8,10) CE(9,11) CE(12,14) CE(13,15)
+    CE(1,2) CE(5,6) CE(9,10) CE(13,14) CE(0,4) CE(1,5) CE(2,6) CE(3,7) CE(8,12) CE(9,13) CE(10,14) CE(11,15) CE(2,4) CE(3,5) CE(10,12) CE(11,13)
+    CE(1,2) CE(3,4) CE(5,6) CE(9,10) CE(11,12) CE(13,14) CE(0,8) CE(1,9) CE(2,10) CE(3,11) CE(4,12) CE(5,13) CE(6,14) CE(7,15) CE(4,8) CE(5,9)
+    CE(6,10) CE(7,11) CE(2,4) CE(3,5) CE(6,8) CE(7,9) CE(10,12) CE(11,13) CE(1,2) CE(3,4) CE(5,6) CE(7,8) CE(9,10) CE(11,12) CE(13,14)
+#undef CE
+#pragma unroll
+    for (int t = 0; t < kKnn; ++t) k[t] = q[kKnn - 1 - t] < k[t] ? q[kKnn - 1 - t] : k[t];
+#pragma unroll
+    for (int j = kKnn / 2; j > 0; j >>= 1)
+#pragma unroll
+      for (int t = 0; t < kKnn; ++t)
+        if ((t ^ j) > t) ce(k[t], k[t ^ j]);
+  }
   __device__ __forceinline__ void insert(float dist, int idx) {
     const unsigned long long x = ((unsigned long long)__float_as_uint(dist) << 32) | (unsigned)idx;
     if (x < k[kKnn - 1]) {
@@ -184,7 +209,7 @@ struct TopLex {
   }
 };
 
-constexpr int QCAP = 16;   // per-lane candidate queue depth
+constexpr int QCAP = 16;   // per-lane candidate queue depth (= kKnn: a full queue is one TopLex::merge16)
 constexpr int KB = 64;     // threads per query block (queue = QCAP * KB * 8 bytes of LDS)
 
 // One lane per query (queries taken in cell order, so a wave's lanes walk neighbouring cells).  The sorted
@@ -216,9 +241,17 @@ __global__ __launch_bounds__(KB) void grid_knn_kernel(const float4* __restrict__
   float thr = INFINITY;
   int nq = 0;
   auto flush = [&]() {
+    if (__any(nq > 3)) {                                  // a burst: all 16 queue slots at once (TopLex::merge16)
+      unsigned long long x[QCAP];
+#pragma unroll
+      for (int c = 0; c < QCAP; ++c)
+        x[c] = c < nq ? (((unsigned long long)__float_as_uint(qd[c][tid]) << 32) | (unsigned)qi[c][tid]) : 0x7f8000007fffffffull;
+      top.merge16(x);
+    } else {
 #pragma unroll 1
-    for (int c = 0; c < QCAP; ++c)
-      if (c < nq) top.insert(qd[c][tid], qi[c][tid]);
+      for (int c = 0; c < 3; ++c)
+        if (c < nq) top.insert(qd[c][tid], qi[c][tid]);
+    }
     nq = 0;
     thr = top.worst();
   };
@@ -318,9 +351,17 @@ __global__ __launch_bounds__(KB4) void grid_knn4_kernel(const float4* __restrict
   int nq = 0;
   auto quad_min = [&](float v) { v = fminf(v, __shfl_xor(v, 1)); return fminf(v, __shfl_xor(v, 2)); };
   auto flush = [&]() {
+    if (__any(nq > 3)) {                                  // a burst: all 16 queue slots at once (TopLex::merge16)
+      unsigned long long x[QCAP];
+#pragma unroll
+      for (int c = 0; c < QCAP; ++c)
+        x[c] = c < nq ? (((unsigned long long)__float_as_uint(qd[c][tid]) << 32) | (unsigned)qi[c][tid]) : 0x7f8000007fffffffull;
+      top.merge16(x);
+    } else {
 #pragma unroll 1
-    for (int c = 0; c < QCAP; ++c)
-      if (c < nq) top.insert(qd[c][tid], qi[c][tid]);
+      for (int c = 0; c < 3; ++c)
+        if (c < nq) top.insert(qd[c][tid], qi[c][tid]);
+    }
     nq = 0;
     thr = quad_min(top.worst());
   };
