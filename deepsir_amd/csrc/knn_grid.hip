@@ -23,7 +23,7 @@ struct GridParams {
   int gx, gy, gz;
 };
 
-constexpr int kPointsPerCell = 8;
+constexpr int kPointsPerCell = 6;
 
 __device__ __forceinline__ float sqdist3(float qx, float qy, float qz, float sx, float sy, float sz) {
   const float dx = __fsub_rn(sx, qx), dy = __fsub_rn(sy, qy), dz = __fsub_rn(sz, qz);
@@ -209,6 +209,10 @@ struct TopLex {
   }
 };
 
+// Shell 1 (the 26 cells around the query's own) is walked NEAR FIRST: its nine (z, y) rows in the order centre, the four rows that
+// share a face with it, the four diagonal ones - (dz + 1, dy + 1) of row j in two bits each.  Far-first orders fill the top 16 with
+// candidates that are evicted again: every eviction is a queue slot, and queue slots are what the merge network is paid for.
+constexpr unsigned kNearDz = 0x28215u, kNearDy = 0x22161u;
 constexpr int QCAP = 16;   // per-lane candidate queue depth (= kKnn: a full queue is one TopLex::merge16)
 constexpr int KB = 64;     // threads per query block (queue = QCAP * KB * 8 bytes of LDS)
 
@@ -219,7 +223,7 @@ constexpr int KB = 64;     // threads per query block (queue = QCAP * KB * 8 byt
 // threshold (its 16th best distance at the last flush) are therefore parked in a per-lane LDS queue and inserted in
 // bursts — all lanes together — when some lane's queue is full and at the end of every shell.  insert() re-checks
 // exactly, and TopLex is order independent, so the result is unchanged.
-__global__ __launch_bounds__(KB) void grid_knn_kernel(const float4* __restrict__ sorted, const int* __restrict__ starts,
+__global__ __launch_bounds__(KB) __attribute__((amdgpu_waves_per_eu(3, 3))) void grid_knn_kernel(const float4* __restrict__ sorted, const int* __restrict__ starts,
                                                        const GridParams* __restrict__ gp, int max_cells, int n,
                                                        int32_t* __restrict__ out, int64_t ocs) {
   __shared__ float qd[QCAP][KB];
@@ -258,10 +262,12 @@ __global__ __launch_bounds__(KB) void grid_knn_kernel(const float4* __restrict__
   // Four candidates per step: their (clamped) loads are independent, so their latencies overlap instead of adding up.
   auto scan = [&](int b, int e) {
     for (int k = b; k < e; k += 4) {
+      if (__any(nq > QCAP - 4)) flush();                  // before the loads: nothing of this step is live across the merge network
+      // 32-bit byte offsets on the cloud's (wave-uniform) base: one add + one min per address (n * 16 < 2^32, launch_knn16_grid)
+      const uint32_t kb = (uint32_t)k * 16u, eb = (uint32_t)(e - 1) * 16u;
       float4 sv[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) sv[u] = S[min(k + u, e - 1)];
-      if (__any(nq > QCAP - 4)) flush();
+      for (int u = 0; u < 4; ++u) sv[u] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S) + min(kb + 16u * u, eb));
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const float d = sqdist3(q.x, q.y, q.z, sv[u].x, sv[u].y, sv[u].z);
@@ -270,7 +276,9 @@ __global__ __launch_bounds__(KB) void grid_knn_kernel(const float4* __restrict__
     }
   };
   const int rmax = live ? max(max(max(cx, g.gx - 1 - cx), max(cy, g.gy - 1 - cy)), max(cz, g.gz - 1 - cz)) : -1;
-  for (int r = 0; r <= rmax; ++r) {
+  // the walk starts with the whole 3 x 3 x 3 cube around the query's cell (r = 1: a cell holds ~6 points, the own cell alone never
+  // ends a 16-NN search), then Chebyshev shells r = 2, 3, ...
+  for (int r = 1; r <= max(rmax, 1) && live; ++r) {
     const int z0 = max(cz - r, 0), z1 = min(cz + r, g.gz - 1);
     const int y0 = max(cy - r, 0), y1 = min(cy + r, g.gy - 1);
     const int x0 = max(cx - r, 0), x1 = min(cx + r, g.gx - 1);
@@ -279,21 +287,24 @@ __global__ __launch_bounds__(KB) void grid_knn_kernel(const float4* __restrict__
     // row -> up to two candidate ranges [b0,e0), [b1,e1): the whole x-run when the row lies on a face of the shell,
     // else its two end cells
     auto bounds = [&](int j, int& b0, int& e0, int& b1, int& e1) {
-      const int z = z0 + j / ny, y = y0 + j % ny;
-      const bool face = (z == cz - r) || (z == cz + r) || (y == cy - r) || (y == cy + r);
+      int z = z0 + j / ny, y = y0 + j % ny;
+      if (r == 1) { z = cz + (int)((kNearDz >> (2 * j)) & 3u) - 1; y = cy + (int)((kNearDy >> (2 * j)) & 3u) - 1; }
+      const bool face = r == 1 || (z == cz - r) || (z == cz + r) || (y == cy - r) || (y == cy + r);   // r = 1: the full 3 x 3 x 3 cube
       const int rowbase = (z * g.gy + y) * g.gx;
       b0 = e0 = b1 = e1 = 0;
+      if (r == 1 && ((unsigned)z >= (unsigned)g.gz || (unsigned)y >= (unsigned)g.gy)) return;      // row outside the grid
       if (face) { b0 = ST[rowbase + x0]; e0 = ST[rowbase + x1 + 1]; }
       else {
         if (cx - r >= 0) { b0 = ST[rowbase + cx - r]; e0 = ST[rowbase + cx - r + 1]; }
         if (cx + r <= g.gx - 1) { b1 = ST[rowbase + cx + r]; e1 = ST[rowbase + cx + r + 1]; }
       }
     };
-    int b0, e0, b1, e1;
-    if (nrows > 0) bounds(0, b0, e0, b1, e1);
-    for (int j = 0; j < nrows; ++j) {
+    const int nr = r == 1 ? 9 : nrows;             // shell 1: all nine rows in near-first order, those outside the grid empty
+    int b0 = 0, e0 = 0, b1 = 0, e1 = 0;
+    if (nr > 0) bounds(0, b0, e0, b1, e1);
+    for (int j = 0; j < nr; ++j) {
       int nb0 = 0, ne0 = 0, nb1 = 0, ne1 = 0;
-      if (j + 1 < nrows) bounds(j + 1, nb0, ne0, nb1, ne1);
+      if (j + 1 < nr) bounds(j + 1, nb0, ne0, nb1, ne1);
       scan(b0, e0);
       scan(b1, e1);
       b0 = nb0; e0 = ne0; b1 = nb1; e1 = ne1;
@@ -368,10 +379,10 @@ __global__ __launch_bounds__(KB4) void grid_knn4_kernel(const float4* __restrict
   auto scan = [&](int b, int e) {
     for (int kb = b; kb < e; kb += 16) {                  // trip count uniform over the quad (its lanes shuffle in flush())
       const int k = kb + sub;
+      if (__any(nq > QCAP - 4)) flush();
       float4 sv[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) sv[u] = S[min(k + 4 * u, n - 1)];
-      if (__any(nq > QCAP - 4)) flush();
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const float d = sqdist3(q.x, q.y, q.z, sv[u].x, sv[u].y, sv[u].z);
@@ -380,27 +391,30 @@ __global__ __launch_bounds__(KB4) void grid_knn4_kernel(const float4* __restrict
     }
   };
   const int rmax = live ? max(max(max(cx, g.gx - 1 - cx), max(cy, g.gy - 1 - cy)), max(cz, g.gz - 1 - cz)) : -1;
-  for (int r = 0; r <= rmax; ++r) {
+  for (int r = 1; r <= max(rmax, 1) && live; ++r) {       // from the full 3 x 3 x 3 cube, as grid_knn_kernel
     const int z0 = max(cz - r, 0), z1 = min(cz + r, g.gz - 1);
     const int y0 = max(cy - r, 0), y1 = min(cy + r, g.gy - 1);
     const int x0 = max(cx - r, 0), x1 = min(cx + r, g.gx - 1);
     const int ny = y1 - y0 + 1, nrows = (z1 - z0 + 1) * ny;
     auto bounds = [&](int j, int& b0, int& e0, int& b1, int& e1) {
-      const int z = z0 + j / ny, y = y0 + j % ny;
-      const bool face = (z == cz - r) || (z == cz + r) || (y == cy - r) || (y == cy + r);
+      int z = z0 + j / ny, y = y0 + j % ny;
+      if (r == 1) { z = cz + (int)((kNearDz >> (2 * j)) & 3u) - 1; y = cy + (int)((kNearDy >> (2 * j)) & 3u) - 1; }
+      const bool face = r == 1 || (z == cz - r) || (z == cz + r) || (y == cy - r) || (y == cy + r);   // r = 1: the full 3 x 3 x 3 cube
       const int rowbase = (z * g.gy + y) * g.gx;
       b0 = e0 = b1 = e1 = 0;
+      if (r == 1 && ((unsigned)z >= (unsigned)g.gz || (unsigned)y >= (unsigned)g.gy)) return;      // row outside the grid
       if (face) { b0 = ST[rowbase + x0]; e0 = ST[rowbase + x1 + 1]; }
       else {
         if (cx - r >= 0) { b0 = ST[rowbase + cx - r]; e0 = ST[rowbase + cx - r + 1]; }
         if (cx + r <= g.gx - 1) { b1 = ST[rowbase + cx + r]; e1 = ST[rowbase + cx + r + 1]; }
       }
     };
-    int b0, e0, b1, e1;
-    if (nrows > 0) bounds(0, b0, e0, b1, e1);
-    for (int j = 0; j < nrows; ++j) {
+    const int nr = r == 1 ? 9 : nrows;             // shell 1: all nine rows in near-first order, those outside the grid empty
+    int b0 = 0, e0 = 0, b1 = 0, e1 = 0;
+    if (nr > 0) bounds(0, b0, e0, b1, e1);
+    for (int j = 0; j < nr; ++j) {
       int nb0 = 0, ne0 = 0, nb1 = 0, ne1 = 0;
-      if (j + 1 < nrows) bounds(j + 1, nb0, ne0, nb1, ne1);
+      if (j + 1 < nr) bounds(j + 1, nb0, ne0, nb1, ne1);
       scan(b0, e0);
       scan(b1, e1);
       b0 = nb0; e0 = ne0; b1 = nb1; e1 = ne1;
