@@ -125,6 +125,11 @@ __global__ __launch_bounds__(256) void tile_stats_kernel(const float* __restrict
   }
 }
 
+// DOMAIN of the margins below (2e-5 (1 + |a|^2 + |b_prev|^2) on T, 1e-5 (1 + |a|^2 + |c|^2) on L): they cover the fp32 evaluation error
+// of a SKIPPED column only while that column's own |b|^2 is of the order of the norms they are built from.  The pruned search is
+// reachable from dsir_register alone (engine.hip: `prune` requires the registration's own descriptors), and those are L2-normalised by
+// the aggregation chain (model.py:232-233: |a| = |b| = 1 up to rounding); it is not offered to caller-supplied descriptors
+// (dsir_nn_match searches exhaustively or through the unpruned screening, whose bound carries every column's own norm).
 // per src row: the sort key of the row order (its nearest-centroid tile) and the upper bound from the previous iteration's match,
 // T = D(a, b_prev) + margin, D evaluated as nn_match.hip evaluates it (fmaf chain over the channels, the reference's roundings);
 // iteration 0 (idx_prev == nullptr): +inf (tile_T_kernel supplies the bound)
@@ -220,13 +225,26 @@ Layout carve(void* scratch, int pairs, int J, int K) {
   L.pbh = take((size_t)pairs * K * 64 * 2);
   L.pbl = take((size_t)pairs * K * 64 * 2);
   L.psb = reinterpret_cast<float*>(take((size_t)pairs * K * 4));
+  // temporary storage of the two radix sorts: sized for the largest sort over all 32 key bits; every sort asks again for its own
+  // size and bit range and refuses to run if the answer exceeds this (sort_pairs)
   size_t tmp = 0;
-  hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr,
-                                     (int)nmax, 0, 32);
+  if (hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr,
+                                         (int)nmax, 0, 32) != hipSuccess)
+    tmp = 0;                       // no storage: sort_pairs fails, the caller reports the error
   L.cub = take(tmp);
   L.cub_bytes = tmp;
   L.total = (size_t)(p - reinterpret_cast<char*>(scratch));
   return L;
+}
+
+// (key, value) radix sort k0 / v0 -> k1 / v1 over key bits [0, end_bit): the library is asked for the temporary size of THIS sort first
+int sort_pairs(const Layout& L, int64_t total, int end_bit, hipStream_t st) {
+  size_t need = 0;
+  if (hipcub::DeviceRadixSort::SortPairs(nullptr, need, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr,
+                                         (int)total, 0, end_bit, st) != hipSuccess || need > L.cub_bytes || L.cub_bytes == 0)
+    return 1;
+  size_t tmp = L.cub_bytes;
+  return hipcub::DeviceRadixSort::SortPairs(L.cub, tmp, L.k0, L.k1, L.v0, L.v1, (int)total, 0, end_bit, st) != hipSuccess;
 }
 
 inline int bits_for(int n) { int b = 0; while ((1ll << b) < n) ++b; return b; }   // smallest b with 2^b >= n
@@ -250,8 +268,7 @@ int launch_prune_ref(const float* ref_xyz, int64_t xyz_cs, const float* desc_r, 
   const int mbits = 32 - pbits < 30 ? 32 - pbits : 30;
   hipLaunchKernelGGL(bbox_kernel, dim3(pairs), dim3(1024), 0, st, ref_xyz, xyz_cs, K, L.box);
   hipLaunchKernelGGL(morton_kernel, dim3(grid_for(total)), dim3(256), 0, st, ref_xyz, xyz_cs, K, L.box, total, mbits, L.k0, L.v0);
-  size_t tmp = L.cub_bytes;
-  if (hipcub::DeviceRadixSort::SortPairs(L.cub, tmp, L.k0, L.k1, L.v0, L.v1, (int)total, 0, mbits + pbits, st) != hipSuccess) return 1;
+  if (sort_pairs(L, total, mbits + pbits, st)) return 1;
   hipLaunchKernelGGL(order_kernel, dim3(grid_for(total)), dim3(256), 0, st, L.v1, K, total, false, L.cols, (int32_t*)nullptr);
   const int64_t tiles_total = (int64_t)pairs * nt;
   hipLaunchKernelGGL(tile_stats_kernel, dim3((unsigned)((tiles_total + 3) / 4)), dim3(256), 0, st, desc_r, L.cols, K, nt, tiles_total, L.cen, L.cn2,
@@ -279,8 +296,7 @@ int launch_prune_rows(const float* desc_s, const float* desc_r, const void* ah, 
   launch_centroid_argmin(ah, al, L.ch, L.cl, L.cn2, pairs, J, nt, L.tstar, st);
   hipLaunchKernelGGL(row_prep_kernel, dim3(grid_for(total)), dim3(256), 0, st, desc_s, desc_r, sa, sb, idx_prev, L.tstar, J, K, tbits, total,
                      keep_all, L.k0, L.v0, L.T);
-  size_t tmp = L.cub_bytes;
-  if (hipcub::DeviceRadixSort::SortPairs(L.cub, tmp, L.k0, L.k1, L.v0, L.v1, (int)total, 0, tbits + bits_for(pairs), st) != hipSuccess) return 1;
+  if (sort_pairs(L, total, tbits + bits_for(pairs), st)) return 1;
   hipLaunchKernelGGL(order_kernel, dim3(grid_for(total)), dim3(256), 0, st, L.v1, J, total, id_rows, L.rows, (int32_t*)nullptr);
   if (!keep_all && !no_tile_T) launch_tile_T(ah, al, sa, L.rows, L.tstar, L.pbh, L.pbl, L.psb, pairs, J, K, nt, L.T, st);
   launch_tile_bound(ah, al, sa, L.rows, L.T, L.ch, L.cl, L.cn2, L.rad, pairs, J, nt, L.tlist, L.tcount, nt, no_lpt ? nullptr : L.rborder, st);

@@ -72,7 +72,8 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const GemmArgs p) {
   // same re-ordered k index as the fp32 form), each operand split into two fp16 numbers, three MFMAs per product: 12 / 24 fp16
   // MFMAs (192 / 384 matrix-pipe cycles) per tile instead of 32 / 64 fp32 ones (1024 / 2048), which two waves per SIMD
   // contend for.  Scores differ from the fp32 form's by ~1e-7 of their scale; the cached enc halves (SC 1 / 2) come from
-  // this same arithmetic, so hoisted and recomputed iterations still agree bit for bit.
+  // this same arithmetic, so hoisted and recomputed iterations still agree bit for bit.  Compile-time and unconditional: dsir_enable_agg_split(0) /
+  // DSIR_AGG_F32 do NOT bring the fp32 form back (include/dsir.h says so); its reference is the oracle.
   constexpr bool kSplit = (EPI == EPI_ATT || EPI == EPI_ATT2) && (KQ == 8 || KQ == 16) && MODE == S_VEC;
   constexpr int NS = kSplit ? KQ / 8 : 1;
   constexpr int CP = KQ * 4;  // padded Cin

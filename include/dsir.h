@@ -309,7 +309,11 @@ int dsir_enable_screen(dsir_ctx* ctx, int enable);
  * 64, mlp_proj; network/model.py:223-233) run as fp16-split products on the fp16 matrix pipe (csrc/agg_chain_h.hip: each fp32
  * operand = two fp16 numbers, three MFMAs per product, fp32 accumulation - fp32 accuracy, descriptors within ~1e-7 of the
  * fp32 kernel's); 0 = the exact-fp32 chain (csrc/agg_chain.hip), bit-identical to the unfused layer-by-layer launches.
- * Initialised from DSIR_AGG_F32 (set => 0). */
+ * Initialised from DSIR_AGG_F32 (set => 0).
+ * What the switch covers: the aggregation chain, the per-point head (csrc/head_mlp_h.hip) and the LDS-tiled GEMMs (csrc/pw_tile.hip,
+ * through GemmArgs::Wh staying unset).  What it does NOT cover: the attentive-pooling score contraction, which is an fp16-split
+ * product unconditionally - csrc/att_pool.hip (levels 0 - 2) and the kSplit epilogues of csrc/pw_stream.hip (level 3 and the
+ * DSIR_NO_ATT_POOL reference) have no exact-fp32 twin at run time; their fp32 reference is the oracle (tests/test_gpu_parity.py). */
 int dsir_enable_agg_split(dsir_ctx* ctx, int enable);
 /* The operand split those layers rest on, HOST buffers, no context, no GPU: hi[i] = fp16(x[i]) and lo[i] = fp16(x[i] - hi[i])
  * as IEEE binary16 bit patterns, both rounded to nearest even - what dsir_finalize_weights applies to every weight matrix (the

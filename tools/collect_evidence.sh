@@ -8,7 +8,7 @@ mkdir -p $out
 export TMPDIR=/tmp
 echo "== default bench"; python3 bench.py > $out/${tag}_bench_default.json 2> $out/${tag}_bench_default.err || { tail -5 $out/${tag}_bench_default.err; exit 1; }
 echo "== kernel trace + PMC passes of the bench command"; bash tools/profile_bench.sh $tag || exit 1
-python3 tools/step_hbm.py $out/${tag}_pmc_fetch.csv $out/${tag}_pmc_write.csv 5 256 5000 2 5 $out/${tag}_step_hbm.json > /dev/null || exit 1
+python3 tools/step_hbm.py $out/${tag}_pmc_fetch.csv $out/${tag}_pmc_write.csv 4 256 5000 2 5 $out/${tag}_step_hbm.json > /dev/null || exit 1
 python3 tools/trace_gaps.py /tmp/prof_trace $out/${tag}_trace_gaps.json > /dev/null || echo "(trace_gaps skipped)"
 echo "== one engine (the launches of the roofline pass): kernel trace, its own PMC passes, the per-kernel roofline table"
 bash tools/kstat_single.sh $tag > $out/${tag}_single_top.txt 2>&1 || { tail -5 $out/${tag}_single_top.txt; exit 1; }

@@ -5,7 +5,7 @@
 # gpurun_out/<tag>_*; copy what is to be judged into profiles/.
 set -o pipefail
 tag=$1; shift
-args="--timed-only --steps 3 --warmup 1 $*"   # 5 identical register calls: allocation, warm-up, 3 timed steps
+args="--timed-only --steps 3 --warmup 1 $*"   # 4 identical steps (1 warm-up + 3 timed): tools/step_hbm.py counts them from the table
 out=gpurun_out
 mkdir -p $out
 export TMPDIR=/tmp
