@@ -48,7 +48,7 @@ __device__ __forceinline__ void split8f(const float* x, h8& h, h8& l) {
 // EPI_ATT, exact-fp32 16 x 16 x 4 MFMAs) ran the matrix pipe 79 % and the vector ALU 57 % busy; this one issues 6 fp16 MFMAs
 // (192 cycles) and ~250 vector instructions per four points.
 template <bool UV>   // UV: the E half of an A row rebuilt from the per-point tables of lse_uv.hip (see att_pool_kernel)
-__global__ __launch_bounds__(256) void att_pool16_kernel(const AttPool16Args p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(UV ? 4 : 5, UV ? 4 : 5))) void att_pool16_kernel(const AttPool16Args p) {
   constexpr int LD = 20;                  // LDS row stride (floats): rows 4 apart land 16 banks apart
   constexpr int TB = 32 * LD + 32;        // tile B's offset: 32 banks away from tile A
   __shared__ float s_sc[16];
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void att_pool16_kernel(const AttPool16Args p) 
 // lse_uv.hip); the pooled operand comes back from the wave's LDS tile: 8 KB of global reads per two points at d = 64.  d = 128: two workgroups per row range, one per 64 output columns
 // (the first owns columns of the feature half, the second of the E half: each keeps only that half of the A rows in its LDS tile).
 template <int KH, bool UV>
-__global__ __launch_bounds__(256) void att_full_kernel(const AttPool16Args p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KH == 32 ? 3 : 2, KH == 32 ? 3 : 2))) void att_full_kernel(const AttPool16Args p) {
   constexpr int KC = KH;          // channels of its row a lane holds (h = 0: features, h = 1: E)
   constexpr int NS = KH / 8;      // k-steps of 16 over the 2 KH channels
   constexpr int NCB = KH / 32;    // workgroups per row range: 64 output columns each
@@ -346,17 +346,24 @@ __global__ __launch_bounds__(256) void att_full_kernel(const AttPool16Args p) {
     // ---- scores: 3 fp16 MFMAs per (tile, k-step)
     f32x16 acc[2];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+    // the two tiles' chains are independent: issued alternately they interleave on the pipe (per accumulator the order is unchanged)
 #pragma unroll
-      for (int s = 0; s < NS; ++s) {
-        const h8 bh = s_w[((t * NS + s) * 2 + 0) * 64 + lane];
-        const h8 bl = s_w[((t * NS + s) * 2 + 1) * 64 + lane];
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], bh, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bl, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bh, acc[t], 0, 0, 0);
+    for (int s = 0; s < NS; ++s) {
+      h8 bh[2], bl[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        bh[t] = s_w[((t * NS + s) * 2 + 0) * 64 + lane];
+        bl[t] = s_w[((t * NS + s) * 2 + 1) * 64 + lane];
       }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], bh[t], acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bl[t], acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bh[t], acc[t], 0, 0, 0);
     }
     __builtin_amdgcn_wave_barrier();
     // ---- epilogue: register i of the accumulator = neighbour i of point (lane >> 5), column 64 cb + 32 t + m
@@ -379,6 +386,164 @@ __global__ __launch_bounds__(256) void att_full_kernel(const AttPool16Args p) {
       if (pt < p.n) Yb[(uint32_t)pt * (uint32_t)(2 * KH) + (uint32_t)(col0 + 32 * t + m)] = o * __builtin_amdgcn_rcpf(se);
     }
     __builtin_amdgcn_wave_barrier();
+    u = un;
+  }
+}
+
+// ---------------------------------------------------------------- level 2 (d = 128): all 128 output columns in ONE workgroup
+// att_full_kernel<64> gave each 64-column half of a row range its own workgroup, and each of the two gathered, normalised and split the
+// whole 128-channel A row again (~450 of ~680 vector instructions per unit, and every row read twice).  Here a wave forms the A
+// fragments of a unit ONCE and walks the four 32-column tiles two at a time (two independent accumulator chains interleave on the
+// pipe): per tile 24 MFMAs from the weight fragments in LDS (64 KB for the 128 x 128 fc matrix as fp16 pairs, shared by EIGHT waves -
+// 512 threads, so that two waves per SIMD still fit the CU's LDS), the pair's half of the pooled operand goes through the wave's LDS
+// tile (32 rows x 64 channels: tiles 0 / 1 are the feature channels, held by lane half 0; tiles 2 / 3 the E channels, lane half 1)
+// and the epilogue runs as before.  Every (row, column)
+// sees the same MFMA sequence as in att_full_kernel<64>: same bits.
+__global__ __launch_bounds__(512) void att_full128_kernel(const AttPool16Args p) {
+  constexpr int KH = 64, KC = 64, NS = 8, NT = 4;
+  constexpr int LD = 72;          // LDS row stride (floats): rows 4 apart land 32 banks apart
+  __shared__ float s_sc[2 * KH];
+  __shared__ float s_sh[2 * KH];
+  __shared__ __attribute__((aligned(16))) float s_t[8][32 * LD];
+  __shared__ h8 s_w[NT * NS * 2 * 64];          // [tile][k-step][high | low][lane]
+
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 31, h = lane >> 5;
+  const int wi = xcd_contiguous(blockIdx.x, gridDim.x);
+  const int bx = wi % p.grid_x;
+  const int cloud = wi / p.grid_x;
+
+  // B fragments -> LDS: tile t = columns 32 t + m; the k index of step s, lane half h, element j is channel KH h + 8 s + j
+  {
+    const _Float16* Wh = reinterpret_cast<const _Float16*>(p.Wh);
+    const _Float16* Wl = reinterpret_cast<const _Float16*>(p.Wl);
+#pragma unroll
+    for (int q = 0; q < NT * NS / 8; ++q) {      // 32 (tile, step) pairs over the 8 waves
+      const int ts = q * 8 + w, t = ts / NS, st = ts % NS;
+      const int o = (32 * t + m) * p.ldw + KH * h + 8 * st;
+      s_w[(ts * 2 + 0) * 64 + lane] = *reinterpret_cast<const h8*>(Wh + o);
+      s_w[(ts * 2 + 1) * 64 + lane] = *reinterpret_cast<const h8*>(Wl + o);
+    }
+  }
+  const float slope = (h ? p.enc_act : p.f_act) ? 0.2f : 1.f;
+  const int pm = (m >> 2) & 1, km = ((m >> 3) << 2) | (m & 3);      // the (point, neighbour) of this lane's A row
+  const float* fb = p.f + cloud * p.f_cs;
+  const float* eb = p.enc + cloud * p.enc_cs;
+  const int32_t* nbb = p.neigh + cloud * p.neigh_cs;
+  float* Yb = p.Y + cloud * p.y_cs;
+  float* T = &s_t[w][0];
+
+  const int units = (p.n + 1) >> 1;
+  const int nw = p.grid_x * 8;
+  int u = bx * 8 + w;
+
+  float a[KC];
+  int jn = 0;                                   // neighbour index of this lane's A row, one unit further ahead than the rows
+  auto point_of = [&](int uu) { return min(2 * uu + pm, p.n - 1); };
+  auto load_idx = [&](int uu) { jn = nbb[(uint32_t)point_of(uu) * 16u + (uint32_t)km]; };
+  auto load_rows = [&](int uu) {
+    const int pt = point_of(uu);
+    const float* src = h ? eb + ((uint32_t)(pt * 16 + km)) * (uint32_t)KH : fb + (uint32_t)jn * (uint32_t)p.f_ld;
+#pragma unroll
+    for (int q = 0; q < KC / 4; ++q) {
+      const float4 v = *reinterpret_cast<const float4*>(src + 4 * q);
+      a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
+    }
+  };
+  if (u < units) {
+    load_idx(u);
+    load_rows(u);
+    if (u + nw < units) load_idx(u + nw);
+  }
+  if (tid < 2 * KH) {
+    const GnRef& g = tid < KH ? p.f_gn : p.enc_gn;
+    const int c = tid < KH ? tid : tid - KH;
+    float scale = 1.f, shift = 0.f;
+    if (g.stats) {
+      const int grp = c / (KH / g.groups);
+      const double* st = g.stats + ((int64_t)cloud * g.groups + grp) * kGnWords;
+      const double mean = gn_stat_get(st) * g.inv_count;
+      double var = gn_stat_get(st + 2) * g.inv_count - mean * mean;
+      var = var > 0.0 ? var : 0.0;
+      const double rstd = gn_rstd(var);
+      const double scd = (double)g.gamma[c] * rstd;
+      scale = (float)scd;
+      shift = (float)((double)g.beta[c] - mean * scd);
+    }
+    s_sc[tid] = scale;
+    s_sh[tid] = shift;
+  }
+  __syncthreads();
+  while (u < units) {
+    // ---- A operand: normalise (fp32 values stay in registers for the pooled operand), split for the MFMAs
+    h8 ah[NS], al[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = 8 * s + j;
+        const float v = fmaf(a[c], s_sc[KH * h + c], s_sh[KH * h + c]);
+        a[c] = fmaxf(v, slope * v);
+      }
+      split8f(&a[8 * s], ah[s], al[s]);
+    }
+    const int pt = 2 * u + h;
+    const int un = u + nw;
+    constexpr float L2E = 1.44269504088896340736f;
+#pragma unroll
+    for (int tp = 0; tp < 2; ++tp) {
+      // the pooled operand of this tile pair's 64 columns: the feature half (tp = 0, lane half 0 holds it) or the E half (tp = 1)
+      if (h == tp) {
+#pragma unroll
+        for (int q = 0; q < KC / 4; ++q)
+          *reinterpret_cast<float4*>(&T[m * LD + 4 * q]) = make_float4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
+        // this lane half's fp32 values are in LDS now (their split copies in ah / al): its rows of the NEXT unit go out here - the
+        // feature gathers (index -> row, the latency-critical pair) fly during both tile pairs, the E rows during the second
+        if (un < units) load_rows(un);
+      }
+      // two tiles at a time: their MFMA chains are independent and interleave on the pipe
+      f32x16 acc[2];
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[tt][i] = 0.f;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        h8 bh[2], bl[2];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+          bh[tt] = s_w[(((2 * tp + tt) * NS + s) * 2 + 0) * 64 + lane];
+          bl[tt] = s_w[(((2 * tp + tt) * NS + s) * 2 + 1) * 64 + lane];
+        }
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], bh[tt], acc[tt], 0, 0, 0);
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bl[tt], acc[tt], 0, 0, 0);
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bh[tt], acc[tt], 0, 0, 0);
+      }
+      if (tp == 1 && un + nw < units) load_idx(un + nw);      // the index one unit further ahead (its own jn was consumed above)
+      __builtin_amdgcn_wave_barrier();
+      // ---- epilogue: register i of the accumulator = neighbour i of point (lane >> 5), column 64 tp + 32 tt + m
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        float mx = fmaxf(acc[tt][0], acc[tt][1]);
+#pragma unroll
+        for (int i = 2; i < 16; i += 2) mx = fmaxf(mx, fmaxf(acc[tt][i], acc[tt][i + 1]));
+        const float ml = -mx * L2E;
+        float se = 0.f, o = 0.f;
+        const float* Tc = &T[4 * h * LD + 32 * tt + m];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float e = __builtin_amdgcn_exp2f(fmaf(acc[tt][i], L2E, ml));
+          const float x = Tc[(8 * (i >> 2) + (i & 3)) * LD];
+          se += e;
+          o = fmaf(x, e, o);
+        }
+        if (pt < p.n) Yb[(uint32_t)pt * (uint32_t)(2 * KH) + (uint32_t)(64 * tp + 32 * tt + m)] = o * __builtin_amdgcn_rcpf(se);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
     u = un;
   }
 }
@@ -419,7 +584,23 @@ bool launch_att_full(const AttPool16Args& a, int KH, hipStream_t st) {
   if ((reinterpret_cast<uintptr_t>(a.f) % 16) != 0 || (a.f_cs % 4) != 0 || (a.f_ld % 4) != 0 || (a.enc && ((reinterpret_cast<uintptr_t>(a.enc) % 16) != 0 || (a.enc_cs % 4) != 0))) return false;
   if ((a.f_gn.stats && (KH % a.f_gn.groups) != 0) || (a.enc_gn.stats && (KH % a.enc_gn.groups) != 0)) return false;
   if ((int64_t)a.n * 16 * KH * 4 >= ((int64_t)1 << 32)) return false;
-  const int units = (a.n + 1) / 2, ncb = KH / 32;
+  const int units = (a.n + 1) / 2;
+  // d = 128: one 8-wave workgroup per row range (att_full128_kernel) once the launch fills the chip with them; small launches keep the
+  // two 4-wave workgroups per row range (a 64 KB weight prologue per workgroup is what a one-unit wave cannot amortise).  Same bits.
+  if (KH == 64 && (int64_t)units * a.clouds >= 8192) {
+    int blocks = (units + 63) / 64;     // ~8 units per wave
+    if ((int64_t)blocks * a.clouds < 256) {
+      const int want = (int)((256 + (int64_t)a.clouds - 1) / (int64_t)a.clouds), most = (units + 7) / 8;
+      const int nb = want < most ? want : most;
+      if (nb > blocks) blocks = nb;
+    }
+    if (blocks < 1) blocks = 1;
+    AttPool16Args b = a;
+    b.grid_x = blocks;
+    hipLaunchKernelGGL(att_full128_kernel, dim3((unsigned)((int64_t)blocks * a.clouds)), dim3(512), 0, st, b);
+    return true;
+  }
+  const int ncb = KH / 32;
   int blocks = (units + 31) / 32;       // ~8 units per wave; no cross-workgroup reduction: the grid may follow the launch size
   const int64_t total = (int64_t)blocks * ncb * a.clouds;
   if (total < 512) {

@@ -63,8 +63,15 @@ __device__ __forceinline__ void split8(const float* x, h8& h, h8& l) {
   }
 }
 
+// Occupancy floor: the level-1 lfa.mlp2 with the table loader (32 channels in) runs at the latency of its gather -> MFMA -> store
+// chain, which a third resident wave per SIMD hides better than 12 bytes of spill cost (244 -> 217 us per launch).  The 64-channel
+// streams lose under the same floor (52 bytes of spill: 71 -> 85 us) and keep the allocator's choice.
+constexpr int pw_stream_min_waves(int KQ, int NT, int EPI, int MODE) {
+  return (EPI != EPI_ATT && EPI != EPI_ATT2 && KQ == 8 && MODE == S_UV) ? 3 : 1;
+}
+
 template <int KQ, int NT, int EPI, int MODE, int SC = 0>   // SC: GemmArgs::s2_mode (EPI_ATT2 only)
-__global__ __launch_bounds__(256) void pw_stream_kernel(const GemmArgs p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(pw_stream_min_waves(KQ, NT, EPI, MODE)))) void pw_stream_kernel(const GemmArgs p) {
   constexpr int BN = NT * 16;
   constexpr bool kVec = MODE == S_VEC || MODE == S_UV;   // raw rows loaded first, normalised after the loads have landed
   // Attentive pooling (round 3): the score contraction of a 16-neighbour tile runs on the fp16 matrix pipe at fp32 accuracy -

@@ -64,7 +64,7 @@ __device__ __forceinline__ float group16_max(float v) {
   return v;
 }
 
-__global__ __launch_bounds__(256) void score_point_kernel(const float* __restrict__ feat, const float* __restrict__ xyz,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void score_point_kernel(const float* __restrict__ feat, const float* __restrict__ xyz,
                                                           int64_t xyz_cs, const int32_t* __restrict__ neigh,
                                                           int64_t neigh_cs, int n, ScoreScratch s,
                                                           float* __restrict__ score, int32_t* __restrict__ label_out, int bpc) {
