@@ -47,7 +47,7 @@ __device__ __forceinline__ void split8f(const float* x, h8& h, h8& l) {
 // the E part; the normalised values double as the pooled operand through the LDS tile.  Round 3's kernel (pw_stream.hip
 // EPI_ATT, exact-fp32 16 x 16 x 4 MFMAs) ran the matrix pipe 79 % and the vector ALU 57 % busy; this one issues 6 fp16 MFMAs
 // (192 cycles) and ~250 vector instructions per four points.
-template <bool UV>   // UV: the E half of an A row rebuilt from the per-point tables of lse_uv.hip (see att_pool_kernel)
+template <bool UV>   // UV: the E half of an A row rebuilt from the per-point tables of lse_uv.hip; occupancy floor: five (tables: four) waves per SIMD - the next step down spills 64 - 116 bytes and doubles the kernel time
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(UV ? 4 : 5, UV ? 4 : 5))) void att_pool16_kernel(const AttPool16Args p) {
   constexpr int LD = 20;                  // LDS row stride (floats): rows 4 apart land 16 banks apart
   constexpr int TB = 32 * LD + 32;        // tile B's offset: 32 banks away from tile A
