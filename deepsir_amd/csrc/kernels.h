@@ -96,6 +96,8 @@ struct GemmArgs {
   int64_t res_cloud_stride = 0;
   int ldres = 0;
   int grid_x = 0, grid_y = 0;   // filled by the launchers that flatten their grid (XCD-aware work mapping)
+  int vgrid_x = 0;              // pw_stream_kernel, EPI_GN: row-block UNITS per cloud (a function of M alone: they fix the summation order of the
+                                // statistics); a workgroup walks the units bx, bx + grid_x, ... (filled by the launcher)
 };
 
 void launch_pw_gemm(const GemmArgs& a, hipStream_t st);

@@ -217,7 +217,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(pw_stream_m
   for (int j = 0; j < KQ; ++j) uva[j] = MODE == S_UV ? p.seg[0].w8[(c_lo + j) * 8] : 0.f;
 
   const int ntiles = (p.M + 15) >> 4;
-  const int wave0 = bx * 4 + w, nwaves = p.grid_x * 4;
+  // EPI_GN: the tile -> wave assignment is that of a VIRTUAL grid of vgrid_x workgroups per cloud (a function of M alone, so a cloud's
+  // statistics are summed in the same order alone or in a batch); the physical workgroup bx plays the virtual ones bx, bx + grid_x, ...
+  // one after the other - same sums, same commits, but weights, scale / shift and the launch of the workgroup are paid once
+  const int vgx = EPI == EPI_GN ? p.vgrid_x : p.grid_x;
+  const int nwaves = vgx * 4;
 
   // source row of this lane's A row in tile `tile` (gathered segments: one index load, issued a tile ahead)
   // Rows past M (last, partial tile) are CLAMPED to row M-1 rather than predicated: their MFMA results are
@@ -285,9 +289,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(pw_stream_m
     }
   };
 
-  float g1[NT], g2[NT];   // GroupNorm partial sums of this lane's columns
-#pragma unroll
-  for (int t = 0; t < NT; ++t) { g1[t] = 0.f; g2[t] = 0.f; }
+  float g1[NT], g2[NT];   // GroupNorm partial sums of this lane's columns (reset per virtual workgroup)
 
   // Memory-level parallelism: a narrow tile is only 16 rows x 8..64 bytes, far too little to cover the
   // HBM/L2 latency with the few waves a CU holds.  Tiles are therefore processed in GROUPS of D: first the
@@ -510,12 +512,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(pw_stream_m
     }  // tile < ntiles
     }  // d
   };
+  bool first = true;
+  for (int vb = bx; vb < vgx; vb += p.grid_x) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t) { g1[t] = 0.f; g2[t] = 0.f; }
   {
     const int gstride = D * nwaves;
     Group ga, gb;
-    int t0 = wave0;
+    int t0 = vb * 4 + w;
     if (t0 < ntiles) issue_group(ga, t0);
-    if (kVec) { stats_to_lds(); fill_scale_shift(); }     // the first group's loads are in flight meanwhile
+    if (kVec && first) { stats_to_lds(); fill_scale_shift(); }     // the first group's loads are in flight meanwhile
+    first = false;
     while (t0 < ntiles) {
       const int t1 = t0 + gstride;
       if (t1 < ntiles) issue_group(gb, t1);
@@ -551,7 +558,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(pw_stream_m
     __syncthreads();
     // ONE atomic instruction per workgroup for all its groups (device_utils.h, gn_block_commit)
     gn_block_commit(s_red, n0, min(BN, p.Cout - n0), gw, p.stats_out + (int64_t)cloud * p.groups_out * kGnWords);
+    if (vb + p.grid_x < vgx) __syncthreads();      // s_red is free again before the next virtual workgroup's sums land in it
   }
+  }  // vb
 }
 
 template <int KQ, int NT, int EPI, int MODE, int SC = 0>
@@ -583,6 +592,20 @@ void launch_s(const GemmArgs& a, hipStream_t st) {
     }
   }
   GemmArgs b = a;
+  b.vgrid_x = blocks;
+  // EPI_GN: `blocks` fixes the summation order (above); how many physical workgroups play them follows the launch size - about one
+  // residency round of the chip, never fewer than one per cloud and column block.  Only the wide instantiations (64 / 32 weight
+  // registers per lane, two or three workgroups per CU): the narrow ones hold six workgroups per CU, want many more of them in
+  // flight than 512, and lose under the same rule (level-0 lfa.mlp2: 346 -> 384 us).
+  if (EPI == EPI_GN && KQ * NT >= 32) {
+    static const int phys_target = (int)tuning_int("DSIR_STREAM_PHYS_BLOCKS", 512);   // tuning hook; 0 = one workgroup per unit
+    const int64_t total = (int64_t)blocks * gy * a.clouds;
+    if (phys_target > 0 && total > phys_target) {
+      int f = (int)(total / phys_target);                  // units per workgroup
+      if (f > blocks) f = blocks;
+      if (f > 1) blocks = (blocks + f - 1) / f;
+    }
+  }
   b.grid_x = blocks; b.grid_y = gy;
   dim3 grid((unsigned)((int64_t)blocks * gy * a.clouds));
   hipLaunchKernelGGL((pw_stream_kernel<KQ, NT, EPI, MODE, SC>), grid, dim3(256), 0, st, b);
