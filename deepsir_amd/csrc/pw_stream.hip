@@ -575,7 +575,8 @@ void launch_s(const GemmArgs& a, hipStream_t st) {
   // chip; DSIR_STREAM_MIN_BLOCKS trades batch-1 latency (more, shorter waves) against throughput at large
   // batches (fewer waves, per-wave setup amortised over more tiles)
   static const int floor_blocks = (int)tuning_int("DSIR_STREAM_MIN_BLOCKS", 16);
-  if (blocks * gy < floor_blocks) {
+  const bool big = EPI != EPI_GN && (int64_t)blocks * gy * a.clouds >= 512;   // no statistics, chip already full: ~8 tiles per wave stand
+  if (!big && blocks * gy < floor_blocks) {
     const int want = (floor_blocks + gy - 1) / gy, most = (ntiles + 3) / 4;
     blocks = want < most ? want : most;
   }
