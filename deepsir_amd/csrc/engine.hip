@@ -827,6 +827,9 @@ int dsir_create(int device, const dsir_cfg* cfg, dsir_ctx** out) {
   }
   if (cfg->feat_len < 3 || cfg->feat_len > 16) return fail(nullptr, "feat_len must be in [3,16]");
   if (cfg->max_points < kKnn * 64 || cfg->max_pairs < 1) return fail(nullptr, "max_points must be >= %d and max_pairs >= 1", kKnn * 64);
+  // several kernels address a cloud's rows with 32-bit byte offsets from a per-cloud base (n * 16 * d * 4 < 2^32 at d = 64: knn_grid.hip,
+  // att_pool.hip, lse_uv.hip check their own products); 2^20 points per cloud is far beyond what the 2.5 kB-per-point workspace admits
+  if (cfg->max_points > (1 << 20)) return fail(nullptr, "max_points must be <= %d", 1 << 20);
   if (cfg->pipeline < DSIR_PIPELINE_ALIGN || cfg->pipeline > DSIR_PIPELINE_LABEL) return fail(nullptr, "unknown pipeline %d", cfg->pipeline);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, "no HIP device available");
