@@ -287,6 +287,7 @@ struct ScreenOrder {
   int tl_stride = 0;
   const int32_t* rborder = nullptr;  // [pairs][row blocks]: the row blocks by descending tile count (the order items are taken in)
   int32_t* queue = nullptr;          // [8], zeroed before every launch: the XCDs' item counters (with tlist)
+  long long cand_rs = 0;             // filled by launch_nn_screen: rows of the launch (pairs x J) = the stride between the slots of the entry lists
 };
 int nn_screen_rows_per_block(int J);   // rows a workgroup of the screening owns for this J (what tile lists are built for)
 int nn_screen_max_bound_tiles();

@@ -446,7 +446,7 @@ __device__ __forceinline__ void screen_item(const int wi, const _Float16* __rest
       const int row = rowv[rt][r];
       int slot = base[rt][r];
       auto emit = [&](int code, float lower) {
-        if (slot < CAP) cand[(arow + row) * CAP + slot] = make_int2(code, __float_as_int(lower));
+        if (slot < CAP) cand[(int64_t)slot * ord.cand_rs + arow + row] = make_int2(code, __float_as_int(lower));   // [slot][row]: see exact_pick_kernel
         else if (slot == CAP) rowlist[arow + atomicAdd(ovf + pair, 1)] = row;   // this row just overflowed (once per row)
         ++slot;
       };
@@ -525,11 +525,15 @@ __global__ __launch_bounds__(256) void exact_pick_kernel(const float* __restrict
   const int n = cnt[row];
   if (n > CAP || ovf[pair] >= ovf_min) return;
   const float T = unorder_bits(umin[row]);
-  const int2* ce = cand + row * CAP;
+  // entry lists slot-major, [slot][row] (round 4; [row][CAP] before): a row holds two to four entries (one per ref split and more), and
+  // with one thread per row the slot-s entries of neighbouring rows are neighbours in memory - 8 bytes per entry read instead of the
+  // 128-byte line of a row's list (the lists were ~80 of the 569 MB a 128-pair search moved)
+  const int64_t crs = (int64_t)gridDim.y * J;
+  const int2* ce = cand + row;
   int kept = 0, first = 0;
   bool cls = false;
   for (int e = 0; e < n; ++e) {
-    const int2 c = ce[e];
+    const int2 c = ce[e * crs];
     if (__int_as_float(c.y) <= T) {
       if (c.x < 0) cls = true;
       else if (kept++ == 0) first = c.x;
@@ -551,7 +555,7 @@ __global__ __launch_bounds__(256) void exact_pick_kernel(const float* __restrict
   const float* sbp = sb + (int64_t)pair * K;
   unsigned long long best = ~0ull;
   for (int e = 0; e < n; ++e) {
-    const int2 c = ce[e];
+    const int2 c = ce[e * crs];
     if (c.x >= 0 && __int_as_float(c.y) <= T) {
       const unsigned long long key =
           ((unsigned long long)order_bits(exact_dist(a, Bp + (int64_t)c.x * 64, san, sbp[c.x])) << 32) | (unsigned int)c.x;
@@ -565,7 +569,7 @@ __global__ __launch_bounds__(256) void exact_pick_kernel(const float* __restrict
     const float dbest = unorder_bits((unsigned int)(best >> 32));
     bool open = !(dbest == dbest);
     for (int e = 0; e < n && !open; ++e) {
-      const int2 c = ce[e];
+      const int2 c = ce[e * crs];
       open = c.x < 0 && __int_as_float(c.y) <= T && !(__int_as_float(c.y) > dbest);
     }
     if (open) {
@@ -701,8 +705,8 @@ __global__ void screen_export_kernel(const unsigned int* __restrict__ umin, cons
   count[j] = n;
   for (int e = 0; e < CAP; ++e) {
     const bool live = e < n;
-    code[j * CAP + e] = live ? cand[j * CAP + e].x : 0;
-    lower[j * CAP + e] = live ? __int_as_float(cand[j * CAP + e].y) : 0.f;
+    code[j * CAP + e] = live ? cand[(int64_t)e * J + j].x : 0;             // one pair: the launch had J rows
+    lower[j * CAP + e] = live ? __int_as_float(cand[(int64_t)e * J + j].y) : 0.f;
   }
 }
 
@@ -1076,6 +1080,7 @@ void launch_nn_screen(const float* a, const float* b, const void* ah, const void
                       hipEvent_t ev0, hipEvent_t ev1, unsigned long long* stats, bool keep_gate, const int32_t* bad,
                       unsigned long long* acc, hipEvent_t evk0, hipEvent_t evk1, const ScreenOrder& ord_in) {
   ScreenOrder ord = ord_in;
+  ord.cand_rs = (long long)pairs * J;
   const size_t rows = (size_t)pairs * J;
   char* p = reinterpret_cast<char*>(scratch);
   auto take = [&](size_t bytes) { char* r = p; p += (bytes + 255) & ~(size_t)255; return r; };
