@@ -764,23 +764,29 @@ int build_pyramid(dsir_ctx* c, const float* points, int stride, int clouds, int 
   auto nn1_by_grid = [&](int l) {
     return !no_grid && !no_nn1_grid && l + 1 < g.num_layers && p.nl[l + 1] >= grid_min && (int64_t)clouds * p.nl[l] >= nn1_grid_min;
   };
+  // the grid scratch of every level stays until the pyramid is done: the level above's sorted points are the QUERIES of this level's
+  // interpolation search (in cell order: a wave's lanes walk neighbouring cells)
+  const size_t mark = c->ws.mark();
+  const void* prev_scratch = nullptr;
   for (int l = 0; l < g.num_layers; ++l) {
     if (p.nl[l] >= grid_min && !no_grid) {
       // large levels: exact grid-pruned search (knn_grid.hip); same bits as the brute force
-      const size_t mark = c->ws.mark();
       void* scratch = c->ws.raw(knn_grid_scratch_bytes(clouds, p.nl[l]));
       if (c->ws.overflow) return fail(c, "workspace exhausted in the KNN pyramid");
       launch_knn16_grid(points, (int64_t)n * stride, stride, p.nl[l], clouds, neigh + (int64_t)p.off[l] * kKnn, neigh_cs,
                         scratch, st);
       // this level's points are the support of the level above's interpolation search: it walks the grid just built
       if (l > 0 && nn1_by_grid(l - 1))
-        launch_nn1_grid(points, (int64_t)n * stride, stride, p.nl[l - 1], p.nl[l], clouds, interp + p.off[l - 1], p.S, scratch, st);
-      c->ws.release(mark);   // stream-ordered: later users of this memory run after the query kernels
+        launch_nn1_grid(points, (int64_t)n * stride, stride, p.nl[l - 1], p.nl[l], clouds, interp + p.off[l - 1], p.S, scratch, st,
+                        prev_scratch);
+      prev_scratch = scratch;
     } else {
+      prev_scratch = nullptr;
       launch_knn16(points, (int64_t)n * stride, stride, p.nl[l], clouds, neigh + (int64_t)p.off[l] * kKnn, neigh_cs, st);
     }
     if (!nn1_by_grid(l)) launch_nn1(points, (int64_t)n * stride, stride, p.nl[l], p.nl[l + 1], clouds, interp + p.off[l], p.S, st);
   }
+  c->ws.release(mark);   // stream-ordered: later users of this memory run after the query kernels
   // sub_idx of level l = the neighbour lists of its first n_{l+1} points: all levels in one launch
   launch_copy_sub_levels(neigh, neigh_cs, lv, clouds, sub, sub_cs, st);
   return 0;

@@ -233,8 +233,10 @@ void launch_knn16_grid(const float* pts, int64_t cloud_stride, int stride, int n
 void launch_nn1(const float* pts, int64_t cloud_stride, int stride, int n_query, int n_support, int clouds,
                 int32_t* out, int64_t out_cloud_stride, hipStream_t st);
 // the same search through the grid launch_knn16_grid has just built over the first n_support points (its scratch); same bits
+// query_scratch (optional): the scratch launch_knn16_grid(.., n = n_query, ..) left for the QUERY level - its points in cell order are
+// then taken as the queries (neighbouring lanes walk neighbouring cells), each result written at the query's original index
 void launch_nn1_grid(const float* pts, int64_t cloud_stride, int stride, int n_query, int n_support, int clouds, int32_t* out,
-                     int64_t out_cloud_stride, const void* grid_scratch, hipStream_t st);
+                     int64_t out_cloud_stride, const void* grid_scratch, hipStream_t st, const void* query_scratch = nullptr);
 void launch_copy_xyz(const float* pts, int64_t cloud_stride, int stride, int n, int clouds, float* out,
                      int64_t out_cloud_stride, hipStream_t st);
 // all levels of a pyramid in one launch each (every level is a prefix of the level above, data_base.py:166-172):

@@ -461,12 +461,18 @@ __global__ __launch_bounds__(KB4) void grid_knn4_kernel(const float4* __restrict
 __global__ __launch_bounds__(256) void grid_nn1_kernel(const float* __restrict__ pts, int64_t cs, int stride, int n_query,
                                                        const float4* __restrict__ sorted, const int* __restrict__ starts,
                                                        const GridParams* __restrict__ gp, int max_cells, int n_support,
-                                                       int32_t* __restrict__ out, int64_t ocs) {
+                                                       int32_t* __restrict__ out, int64_t ocs, const float4* __restrict__ qsorted) {
   const int cloud = blockIdx.y;
-  const int qi = blockIdx.x * 256 + threadIdx.x;
+  int qi = blockIdx.x * 256 + threadIdx.x;
   if (qi >= n_query) return;
   const float* P = pts + cloud * cs;
-  const float qx = P[(int64_t)qi * stride], qy = P[(int64_t)qi * stride + 1], qz = P[(int64_t)qi * stride + 2];
+  float qx, qy, qz;
+  if (qsorted) {           // the query level's points in ITS cell order (round 4): a wave's lanes are neighbours in space
+    const float4 q4 = qsorted[(int64_t)cloud * n_query + qi];
+    qx = q4.x; qy = q4.y; qz = q4.z; qi = __float_as_int(q4.w);
+  } else {
+    qx = P[(int64_t)qi * stride]; qy = P[(int64_t)qi * stride + 1]; qz = P[(int64_t)qi * stride + 2];
+  }
   const GridParams g = gp[cloud];
   const float4* S = sorted + (int64_t)cloud * n_support;
   const int* ST = starts + (int64_t)cloud * (max_cells + 1);
@@ -555,8 +561,21 @@ void launch_knn16_grid(const float* pts, int64_t cs, int stride, int n, int clou
 }
 
 // nn1 through the grid launch_knn16_grid(.., n = n_support, .., scratch) has left in `scratch` (same carving)
+// the `sorted` array inside a scratch of launch_knn16_grid(.., n, ..) (same carving as below)
+static const float4* sorted_of(const void* scratch, int clouds, int n) {
+  const int max_cells = n / 2 + 64;
+  const char* p = reinterpret_cast<const char*>(scratch);
+  auto take = [&](size_t bytes) { const char* r = p; p += (bytes + 255) & ~(size_t)255; return r; };
+  take((size_t)clouds * sizeof(GridParams));
+  take((size_t)clouds * n * sizeof(int));
+  take((size_t)clouds * max_cells * sizeof(int));
+  take((size_t)clouds * (max_cells + 1) * sizeof(int));
+  take((size_t)clouds * max_cells * sizeof(int));
+  return reinterpret_cast<const float4*>(take((size_t)clouds * n * sizeof(float4)));
+}
+
 void launch_nn1_grid(const float* pts, int64_t cs, int stride, int n_query, int n_support, int clouds, int32_t* out, int64_t ocs,
-                     const void* scratch, hipStream_t st) {
+                     const void* scratch, hipStream_t st, const void* query_scratch) {
   const int n = n_support;
   const int max_cells = n / 2 + 64;
   const char* p = reinterpret_cast<const char*>(scratch);
@@ -568,7 +587,7 @@ void launch_nn1_grid(const float* pts, int64_t cs, int stride, int n_query, int 
   take((size_t)clouds * max_cells * sizeof(int));            // cursor
   const float4* sorted = reinterpret_cast<const float4*>(take((size_t)clouds * n * sizeof(float4)));
   hipLaunchKernelGGL(grid_nn1_kernel, dim3((n_query + 255) / 256, clouds), dim3(256), 0, st, pts, cs, stride, n_query, sorted, starts, gp,
-                     max_cells, n_support, out, ocs);
+                     max_cells, n_support, out, ocs, query_scratch ? sorted_of(query_scratch, clouds, n_query) : nullptr);
 }
 
 }  // namespace dsir
