@@ -44,6 +44,30 @@ struct Top16 {
       }
     }
   }
+  // The 16 smallest of this list and another SORTED list under the order (distance, then index) - what inserting the other list's
+  // entries one by one gives when its indices all exceed this list's at equal distance (the slices of the support set are merged in
+  // ascending order).  min(k[t], q[15 - t]) is a bitonic sequence holding the lower half of the union; a bitonic merge (32
+  // compare-exchanges) sorts it: ~350 instructions instead of 16 x 75.
+  __device__ __forceinline__ void merge_sorted(const float (&qd)[kKnn], const int (&qi)[kKnn]) {
+#pragma unroll
+    for (int t = 0; t < kKnn; ++t) {
+      const float e = qd[kKnn - 1 - t];
+      const int ei = qi[kKnn - 1 - t];
+      const bool sw = e < d[t] || (e == d[t] && ei < i[t]);
+      d[t] = sw ? e : d[t]; i[t] = sw ? ei : i[t];
+    }
+#pragma unroll
+    for (int j = kKnn / 2; j > 0; j >>= 1)
+#pragma unroll
+      for (int t = 0; t < kKnn; ++t)
+        if ((t ^ j) > t) {
+          const int u = t ^ j;
+          const bool sw = d[u] < d[t] || (d[u] == d[t] && i[u] < i[t]);
+          const float dl = sw ? d[u] : d[t], dh = sw ? d[t] : d[u];
+          const int il = sw ? i[u] : i[t], ih = sw ? i[t] : i[u];
+          d[t] = dl; d[u] = dh; i[t] = il; i[u] = ih;
+        }
+  }
 };
 
 __global__ __launch_bounds__(QB * NW) void knn16_kernel(const float* __restrict__ pts, int64_t cs, int stride, int n,
@@ -113,8 +137,11 @@ __global__ __launch_bounds__(QB * NW) void knn16_kernel(const float* __restrict_
   if (w == 0 && q < n) {
 #pragma unroll
     for (int s = 0; s < NW - 1; ++s) {
+      float ld[kKnn];
+      int li[kKnn];
 #pragma unroll
-      for (int t = 0; t < kKnn; ++t) top.insert(md[s][t][lane], mi[s][t][lane]);
+      for (int t = 0; t < kKnn; ++t) { ld[t] = md[s][t][lane]; li[t] = mi[s][t][lane]; }
+      top.merge_sorted(ld, li);
     }
     int32_t* o = out + cloud * ocs + (int64_t)q * kKnn;
     // fewer than 16 finite distances (non-finite coordinates): the empty slots point at the query itself, never out of range
