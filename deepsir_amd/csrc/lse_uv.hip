@@ -13,7 +13,7 @@
 //   * writes U | V per point and dist per row,
 //   * accumulates the GroupNorm statistics of enc_raw (the same expression, the same bits the consumers form) and commits them
 //     in the order-independent form of device_utils.h (gn_block_commit).
-// Four lanes per row, a quarter of the channels each (4 points x 16 neighbours per workgroup step); U[j] is evaluated from the neighbour's coordinates by the
+// Four lanes per row, a quarter of the channels each (KH = 32) or one lane per row (KH = 8); U[j] is evaluated from the neighbour's coordinates by the
 // very function that fills the table, so table and on-the-fly values agree bit for bit.
 #include "kernels.h"
 #include "device_utils.h"
@@ -27,13 +27,17 @@ __device__ __forceinline__ float dot3(float wx, float wy, float wz, float x, flo
   return fmaf(wz, z, fmaf(wy, y, __fmul_rn(wx, x)));
 }
 
-template <int KH>
+// LPR lanes share a row, KH / LPR channels each: 4 at KH = 32; ONE at KH = 8 (round 4: with four lanes per row every lane repeated
+// the row's distance and coordinate loads for two channels' worth of work - 120 vector instructions per row against 66)
+template <int KH, int LPR>
 __global__ __launch_bounds__(256) void lse_uv_stats_kernel(const LseUvArgs p) {
-  constexpr int KQ = KH / 4;               // channels per lane: four lanes share a row (64 rows = 4 points per workgroup step)
+  constexpr int KQ = KH / LPR;             // channels per lane
+  constexpr int PP = 16 / LPR;             // points per workgroup step (256 threads = 256 / LPR rows)
+  static_assert(KQ <= 16, "a point's table rows are written by the lanes of its first KQ neighbour slots");
   __shared__ float s_red[4 * KH * 2];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int cloud = blockIdx.y;
-  const int q = tid & 3, r = tid >> 2, pl = r >> 4, k = r & 15;
+  const int q = tid % LPR, r = tid / LPR, pl = r >> 4, k = r & 15;
   // this lane's folded weights {a, ux, uy, uz, vx, vy, vz, b} of its KQ channels: registers for the whole kernel
   float wq[KQ][8];
 #pragma unroll
@@ -48,16 +52,16 @@ __global__ __launch_bounds__(256) void lse_uv_stats_kernel(const LseUvArgs p) {
   float s1[KQ], s2[KQ];
 #pragma unroll
   for (int c = 0; c < KQ; ++c) { s1[c] = 0.f; s2[c] = 0.f; }
-  const int ntile = (p.n + 3) >> 2;
+  const int ntile = (p.n + PP - 1) / PP;
   // the next step's index is fetched while the current one is computed (index -> coordinates is a dependent pair of loads)
   int tile = blockIdx.x;
-  int jn = tile < ntile ? NB[(uint32_t)min(tile * 4 + pl, p.n - 1) * 16u + (uint32_t)k] : 0;
+  int jn = tile < ntile ? NB[(uint32_t)min(tile * PP + pl, p.n - 1) * 16u + (uint32_t)k] : 0;
   for (; tile < ntile; tile += gridDim.x) {
-    const int i = tile * 4 + pl;
+    const int i = tile * PP + pl;
     const bool ok = i < p.n;
     const int ic = ok ? i : p.n - 1;
     const int j = jn;
-    if (tile + (int)gridDim.x < ntile) jn = NB[(uint32_t)min((tile + (int)gridDim.x) * 4 + pl, p.n - 1) * 16u + (uint32_t)k];
+    if (tile + (int)gridDim.x < ntile) jn = NB[(uint32_t)min((tile + (int)gridDim.x) * PP + pl, p.n - 1) * 16u + (uint32_t)k];
     const float ix = X[(uint32_t)ic * 3u], iy = X[(uint32_t)ic * 3u + 1], iz = X[(uint32_t)ic * 3u + 2];
     const float jx = X[(uint32_t)j * 3u], jy = X[(uint32_t)j * 3u + 1], jz = X[(uint32_t)j * 3u + 2];
     const float dx = __fsub_rn(jx, ix), dy = __fsub_rn(jy, iy), dz = __fsub_rn(jz, iz);
@@ -76,13 +80,13 @@ __global__ __launch_bounds__(256) void lse_uv_stats_kernel(const LseUvArgs p) {
       }
     }
   }
-  // per-channel sums over the workgroup's rows: a fixed butterfly over the 16 lanes of a wave that share a chunk, the four waves in order
+  // per-channel sums over the workgroup's rows: a fixed butterfly over the lanes of a wave that share a chunk, the four waves in order
 #pragma unroll
   for (int c = 0; c < KQ; ++c) {
     float a = s1[c], b = s2[c];
 #pragma unroll
-    for (int o = 32; o >= 4; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
-    if (lane < 4) { s_red[(w * KH + q * KQ + c) * 2] = a; s_red[(w * KH + q * KQ + c) * 2 + 1] = b; }
+    for (int o = 32; o >= LPR; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+    if (lane < LPR) { s_red[(w * KH + q * KQ + c) * 2] = a; s_red[(w * KH + q * KQ + c) * 2 + 1] = b; }
   }
   __syncthreads();
   if (tid < 2 * KH) {
@@ -100,13 +104,14 @@ bool launch_lse_uv_stats(const LseUvArgs& a, hipStream_t st) {
   if (a.n <= 0 || a.clouds <= 0) return true;
   if (!a.xyz || !a.neigh || !a.w8 || !a.uv || !a.dist || !a.stats_out || a.groups < 1 || (a.KH % a.groups) != 0) return false;
   if ((int64_t)a.n * 16 * 4 >= ((int64_t)1 << 32) || (int64_t)a.n * 2 * a.KH * 4 >= ((int64_t)1 << 32)) return false;
-  const int ntile = (a.n + 3) / 4;
-  int blocks = (ntile + 15) / 16;          // ~16 steps of four points per workgroup
+  const int pp = a.KH == 8 ? 16 : 4;       // points per workgroup step
+  const int ntile = (a.n + pp - 1) / pp;
+  int blocks = (ntile + 15) / 16;          // ~16 steps per workgroup
   if (blocks < 1) blocks = 1;
   const dim3 grid(blocks, a.clouds);
   switch (a.KH) {
-    case 8: hipLaunchKernelGGL(lse_uv_stats_kernel<8>, grid, dim3(256), 0, st, a); return true;
-    case 32: hipLaunchKernelGGL(lse_uv_stats_kernel<32>, grid, dim3(256), 0, st, a); return true;
+    case 8: hipLaunchKernelGGL((lse_uv_stats_kernel<8, 1>), grid, dim3(256), 0, st, a); return true;
+    case 32: hipLaunchKernelGGL((lse_uv_stats_kernel<32, 4>), grid, dim3(256), 0, st, a); return true;
     default: return false;
   }
 }
