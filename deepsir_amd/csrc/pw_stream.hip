@@ -570,10 +570,11 @@ void launch_s(const GemmArgs& a, hipStream_t st) {
   // ~8 tiles per wave.  The grid depends on (M, Cout) only — never on the number of clouds — so the
   // tile->wave assignment, hence the summation order of the GroupNorm statistics, is the same for a
   // cloud whether it is registered alone or inside a batch (bitwise batch invariance).
-  int blocks = (ntiles + 31) / 32;
-  // small layers: at least `floor_blocks` workgroups per cloud so that a single pair still spreads over the
-  // chip; DSIR_STREAM_MIN_BLOCKS trades batch-1 latency (more, shorter waves) against throughput at large
-  // batches (fewer waves, per-wave setup amortised over more tiles)
+  const int natural = (ntiles + 31) / 32;
+  int blocks = natural;
+  // small layers: at least `floor_blocks` workgroups per cloud so that a single pair still spreads over the chip (batch-1 latency:
+  // more, shorter waves).  For the GroupNorm layers this count is the VIRTUAL grid - it fixes which wave sums which tiles - and may be
+  // generous, because chip-filling launches fold it back (below).  DSIR_STREAM_MIN_BLOCKS: tuning hook.
   static const int floor_blocks = (int)tuning_int("DSIR_STREAM_MIN_BLOCKS", 16);
   const bool big = EPI != EPI_GN && (int64_t)blocks * gy * a.clouds >= 512;   // no statistics, chip already full: ~8 tiles per wave stand
   if (!big && blocks * gy < floor_blocks) {
@@ -594,17 +595,17 @@ void launch_s(const GemmArgs& a, hipStream_t st) {
   }
   GemmArgs b = a;
   b.vgrid_x = blocks;
-  // EPI_GN: `blocks` fixes the summation order (above); how many physical workgroups play them follows the launch size - about one
-  // residency round of the chip, never fewer than one per cloud and column block.  Only the wide instantiations (64 / 32 weight
-  // registers per lane, two or three workgroups per CU): the narrow ones hold six workgroups per CU, want many more of them in
-  // flight than 512, and lose under the same rule (level-0 lfa.mlp2: 346 -> 384 us).
-  if (EPI == EPI_GN && KQ * NT >= 32) {
-    static const int phys_target = (int)tuning_int("DSIR_STREAM_PHYS_BLOCKS", 512);   // tuning hook; 0 = one workgroup per unit
-    const int64_t total = (int64_t)blocks * gy * a.clouds;
-    if (phys_target > 0 && total > phys_target) {
-      int f = (int)(total / phys_target);                  // units per workgroup
-      if (f > blocks) f = blocks;
-      if (f > 1) blocks = (blocks + f - 1) / f;
+  // EPI_GN: `blocks` fixes the summation order (above); how many PHYSICAL workgroups play them follows the launch size: the natural
+  // grid (~8 tiles per wave) once that alone fills the chip, else about one residency round (512 workgroups), never more than the
+  // virtual grid.  A physical workgroup walks the virtual ones bx, bx + grid_x, ...: weights, scale / shift and its own launch are
+  // paid once, sums and commits are those of the virtual grid - same bits at every launch size.
+  if (EPI == EPI_GN) {
+    static const int phys_target = (int)tuning_int("DSIR_STREAM_PHYS_BLOCKS", 512);   // tuning hook; 0 = one workgroup per virtual one
+    if (phys_target > 0) {
+      const int64_t per = (int64_t)gy * a.clouds;
+      int64_t want = (int64_t)natural * per >= phys_target ? natural : (phys_target + per - 1) / per;
+      if (want < 1) want = 1;
+      if (want < blocks) blocks = (int)want;
     }
   }
   b.grid_x = blocks; b.grid_y = gy;
