@@ -321,6 +321,33 @@ def test_groupnorm_statistics_do_not_depend_on_arrival_order():
         assert torch.equal(one[k], keep[k]), k
 
 
+def test_a_pairs_bits_do_not_depend_on_the_launch_size():
+    """Several kernels are chosen, and several grids sized, by how much work a launch holds (round 4: one 8-wave workgroup per row range
+    of the d = 128 attentive pooling from 8192 units on, GroupNorm layers of pw_stream.hip folded onto the natural grid in chip-filling
+    launches, four lanes per query in the grid 16-NN of small launches, one- or eight-tile waves in the epilogues without a reduction,
+    the screened arg-min from four pairs on).  None of that may change a pair's result: 64 pairs registered in ONE call - every
+    large-launch choice active - equal the same pairs registered two at a time, bit for bit."""
+    from deepsir_amd.arch import NetConfig
+    from deepsir_amd.engine import Engine
+    from deepsir_amd.synth import make_batch
+    from deepsir_amd.weights import generate_state_dict
+    cfg = NetConfig(feat_len=3)
+    sd = generate_state_dict(cfg, 3)
+    P, N, n_iter = 64, 5000, 3
+    b = make_batch(N, [30_000 + i for i in range(P)], 3)
+    src, ref = cu(b["points_src"]), cu(b["points_ref"])
+    eng = Engine(cfg, 0, max_points=N, max_pairs=P)
+    eng.load_state_dict(sd)
+    big = eng.register(src, ref, n_iter)
+    big = {k: big[k].clone() for k in ("transforms", "idx", "logits")}
+    for a in range(0, P, 2):
+        small = eng.register(src[a:a + 2], ref[a:a + 2], n_iter)
+        assert torch.equal(small["transforms"], big["transforms"][a:a + 2]), a
+        assert torch.equal(small["idx"], big["idx"][:, a:a + 2]), a
+        assert torch.equal(small["logits"], big["logits"][:, a:a + 2]), a
+    eng.close()
+
+
 def test_config4_shard_walked_in_ragged_calls():
     """BASELINE configs[3] (the 1623-pair 3DMatch test set, pair-sharded): one rank's shard of a 1623-pair set at world size 8 is
     203 pairs; here 300 pairs of 5000 points are walked the way bench.py --total-pairs walks a shard - engine calls of at most
