@@ -46,7 +46,8 @@ struct HostParam {
 
 struct Mlp2dW { const float *W = nullptr, *b = nullptr, *gamma = nullptr, *beta = nullptr; int cin = 0, cout = 0, groups = 0; };
 struct AttW { const float* fc = nullptr; const float* fc_g = nullptr; int d = 0; Mlp2dW mlp; };   // fc_g: see up_fc_g
-struct BlockW { Mlp2dW mlp1, lfa1, lfa2, mlp2, skip; AttW att1, att2; int d_in = 0, d = 0; const float* lse_w8 = nullptr; };   // lse_w8: up_lse_uv
+struct BlockW { Mlp2dW mlp1, lfa1, lfa2, mlp2, skip; AttW att1, att2; int d_in = 0, d = 0; const float* lse_w8 = nullptr;   // lse_w8: up_lse_uv
+                const float *pair_W = nullptr, *pair_b = nullptr; };   // mlp1's rows followed by mlp_skip's (and the biases likewise): up_pair
 struct LinW { const float *W = nullptr, *b = nullptr; int cin = 0, cout = 0; };
 struct RandlaW { Mlp2dW pre; BlockW blk[4]; Mlp2dW mid; Mlp2dW dec[4]; const float* out_w = nullptr; int dec_out = 0; LinW fc[3]; int cin = 0, ncls = 0;
                  const void* head_wh[4] = {}; const void* head_wl[4] = {}; };   // fp16 split of mlp_out + fc_label (head_mlp_h.hip)
@@ -334,7 +335,7 @@ size_t up_lse_uv(Uploader& u, const HostParam& w, const HostParam& b, int kh) {
 
 struct RandlaOff {
   Mlp2dOff pre, mid, dec[4];
-  struct { Mlp2dOff mlp1, lfa1, lfa2, mlp2, skip, a1m, a2m; size_t fc1, fc2, fc1g, fc2g, lse8; } blk[4];
+  struct { Mlp2dOff mlp1, lfa1, lfa2, mlp2, skip, a1m, a2m; size_t fc1, fc2, fc1g, fc2g, lse8, pair_w, pair_b; bool pair; } blk[4];
   size_t out_w; int dec_out;
   LinOff fc[3];
 };
@@ -355,6 +356,20 @@ RandlaOff up_randla(dsir_ctx* c, Uploader& u, const std::string& pre) {
     r.blk[i].a2m = up_mlp2d(c, u, p + ".lfa.att_pooling_2.mlp");
     r.blk[i].mlp2 = up_mlp2d(c, u, p + ".mlp2");
     r.blk[i].skip = up_mlp2d(c, u, p + ".mlp_skip");
+    // mlp1 and mlp_skip read the same input (RandLANet.py:226 / :229): where mlp1's width is a whole number of 64-column tiles the two
+    // weight matrices are uploaded once more, one after the other, for a launch that computes both (GemmArgs::c_split)
+    r.blk[i].pair = false; r.blk[i].pair_w = r.blk[i].pair_b = 0;
+    {
+      const HostParam& w1 = P(c, p + ".mlp1.conv.weight");
+      const HostParam& w2 = P(c, p + ".mlp_skip.conv.weight");
+      if (w1.shape[0] % 64 == 0 && w1.shape[1] == w2.shape[1]) {
+        std::vector<float> w(w1.data), b(P(c, p + ".mlp1.conv.bias").data);
+        w.insert(w.end(), w2.data.begin(), w2.data.end());
+        const auto& b2 = P(c, p + ".mlp_skip.conv.bias").data;
+        b.insert(b.end(), b2.begin(), b2.end());
+        r.blk[i].pair_w = u.put(w); r.blk[i].pair_b = u.put(b); r.blk[i].pair = true;
+      }
+    }
   }
   r.mid = up_mlp2d(c, u, pre + ".mlp_mid");
   for (int j = 0; j < 4; ++j) r.dec[j] = up_mlp2d(c, u, pre + ".decoder_blocks." + std::to_string(j));
@@ -380,6 +395,7 @@ RandlaW bind_randla(const float* base, const RandlaOff& o, const dsir_cfg& g) {
     b.att2.fc_g = g.d_out[i] >= 64 ? base + o.blk[i].fc2g : nullptr;
     b.lse_w8 = (g.d_out[i] == 16 || g.d_out[i] == 64) ? base + o.blk[i].lse8 : nullptr;
     b.d = g.d_out[i]; b.d_in = b.mlp1.cin;
+    if (o.blk[i].pair) { b.pair_W = base + o.blk[i].pair_w; b.pair_b = base + o.blk[i].pair_b; }
   }
   r.mid = bind_mlp2d(base, o.mid);
   for (int j = 0; j < 4; ++j) r.dec[j] = bind_mlp2d(base, o.dec[j]);
@@ -443,6 +459,31 @@ struct Sched {
     split_of(a);
     if (!c->ws.overflow) launch_pw_gemm(a, st);   // an exhausted arena hands out its base: nothing may run on it
     return y;
+  }
+  // mlp1 and mlp_skip of a block in ONE launch (same input; the weights one after the other, BlockW::pair_W): two outputs, two
+  // sets of statistics - each element the chain the separate launch gives it.  False: not served (the caller launches them apart).
+  bool mlp2d_pair(const BlockW& b, const Seg& s0, int M, Act& y1, Act& y2) {
+    if (!b.pair_W) return false;
+    const Mlp2dW &w1 = b.mlp1, &w2 = b.skip;
+    GemmArgs a;
+    a.amode = A_SEGS; a.nseg = 1; a.seg[0] = s0;
+    a.W = b.pair_W; a.bias = b.pair_b; a.Cin = w1.cin; a.Cout = w1.cout + w2.cout; a.M = M; a.clouds = clouds; a.epi = EPI_GN;
+    a.c_split = w1.cout;
+    split_of(a);
+    a.groups_out = w1.groups; a.groups_out2 = w2.groups;
+    a.Y = reinterpret_cast<float*>(1); a.Y2 = a.Y; a.stats_out = reinterpret_cast<double*>(1); a.stats_out2 = a.stats_out;   // placeholders for the predicate
+    a.ldy = w1.cout; a.ldy2 = w2.cout;
+    if (!pw_gemm_serves_pair(a)) return false;
+    y1.p = c->ws.get<float>((size_t)clouds * M * w1.cout); y1.C = w1.cout; y1.rows = M; y1.act = 1;
+    y2.p = c->ws.get<float>((size_t)clouds * M * w2.cout); y2.C = w2.cout; y2.rows = M; y2.act = 0;
+    double* st1 = stats_slot(w1.groups);
+    double* st2 = stats_slot(w2.groups);
+    y1.gn = GnRef{st1, w1.gamma, w1.beta, w1.groups, 1.0 / ((double)(w1.cout / w1.groups) * (double)M)};
+    y2.gn = GnRef{st2, w2.gamma, w2.beta, w2.groups, 1.0 / ((double)(w2.cout / w2.groups) * (double)M)};
+    a.Y = y1.p; a.y_cloud_stride = (int64_t)M * w1.cout; a.stats_out = st1;
+    a.Y2 = y2.p; a.y2_cloud_stride = (int64_t)M * w2.cout; a.stats_out2 = st2;
+    if (!c->ws.overflow) launch_pw_gemm(a, st);
+    return true;
   }
   // lfa.mlp1 split by linearity (lse_uv.hip): per-point tables + dist + statistics, no output rows.  uv_buf / dist_buf: caller-owned
   // storage (persistent across launches) or nullptr
@@ -619,7 +660,9 @@ int randla_forward(dsir_ctx* c, const RandlaW& w, const Seg& in0, const Seg* in1
     const float* xyz_l = py.xyz + (int64_t)py.off[l] * 3;
     const int32_t* nb_l = py.neigh + (int64_t)py.off[l] * kKnn;
     const Seg xin = Sched::seg_of(x);
-    Act f = s.mlp2d(b.mlp1, xin, nullptr, n, true);
+    Act f, skipb;
+    const bool paired = s.mlp2d_pair(b, xin, n, f, skipb);
+    if (!paired) f = s.mlp2d(b.mlp1, xin, nullptr, n, true);
     const bool reuse = cache && cache->valid;
     const bool uvl = b.lse_w8 && lse_uv_enabled();     // this level's lfa.mlp1 rows are rebuilt from per-point tables, never stored
     Act enc = reuse ? cache->enc[l]
@@ -637,7 +680,7 @@ int randla_forward(dsir_ctx* c, const RandlaW& w, const Seg& in0, const Seg* in1
     Act agg2 = s.att(b.att2, a1, enc2, nb_l, neigh_cs, n, cache ? cache->s2_buf[l][1] : nullptr, s2_mode);
     Act a2 = s.mlp2d(b.att2.mlp, Sched::seg_of(agg2), nullptr, n, true);
     Act mainb = s.mlp2d(b.mlp2, Sched::seg_of(a2), nullptr, n, false);
-    Act skipb = s.mlp2d(b.skip, xin, nullptr, n, false);
+    if (!paired) skipb = s.mlp2d(b.skip, xin, nullptr, n, false);
     Act enc_out;
     enc_out.C = 2 * b.d; enc_out.rows = n;
     Act samp;

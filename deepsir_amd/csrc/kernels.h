@@ -96,15 +96,24 @@ struct GemmArgs {
   int64_t res_cloud_stride = 0;
   int ldres = 0;
   int grid_x = 0, grid_y = 0;   // filled by the launchers that flatten their grid (XCD-aware work mapping)
+  // pw_tile_small_kernel, EPI_GN: TWO convolutions of the same input in one launch (mlp1 + mlp_skip of a dilated residual block,
+  // RandLANet.py:226 / :229): W / bias are the two layers' rows one after the other, columns [0, c_split) are the first layer's
+  // (Y, ldy, stats_out, groups_out as usual), columns [c_split, Cout) the second's (below).  c_split is a multiple of 64 or 0 (off).
+  int c_split = 0;
+  float* Y2 = nullptr; int64_t y2_cloud_stride = 0; int ldy2 = 0;
+  double* stats_out2 = nullptr; int groups_out2 = 0;
   int vgrid_x = 0;              // pw_stream_kernel, EPI_GN: row-block UNITS per cloud (a function of M alone: they fix the summation order of the
                                 // statistics); a workgroup walks the units bx, bx + grid_x, ... (filled by the launcher)
 };
 
 void launch_pw_gemm(const GemmArgs& a, hipStream_t st);
+bool pw_gemm_serves_pair(const GemmArgs& a);   // would launch_pw_gemm serve this launch with GemmArgs::c_split set? (ask before fusing two layers)
 // narrow-layer fast path (pw_stream.hip); false => not applicable
 bool launch_pw_stream(const GemmArgs& a, hipStream_t st);
 // wide-layer path, LDS-tiled 128/64 x 64 x 32 (pw_tile.hip): Cin a multiple of 32 in [64,768], Cout >= 64
 bool launch_pw_tile(const GemmArgs& a, hipStream_t st);
+// does launch_pw_tile serve this layer with pw_tile_small_kernel (the one kernel that takes GemmArgs::c_split)?
+bool pw_tile_small_serves(const GemmArgs& a);
 
 // att_pool.hip - attentive pooling of the k = 16 layers of levels 0 - 2 on v_mfma_f32_32x32x16_f16: softmax and weighted sum in registers
 // level 0 (d = 16), unsplit: scores = fc [gather(f) ; E] with both halves 8 channels wide; four points per wave

@@ -297,6 +297,13 @@ void launch_bn(const GemmArgs& a, hipStream_t st) {
 
 }  // namespace
 
+// may the caller hand this (two-layer, GemmArgs::c_split) launch to launch_pw_gemm?  Only pw_tile_small_kernel writes two outputs.
+bool pw_gemm_serves_pair(const GemmArgs& a) {
+  static const bool no_tile = tuning_flag("DSIR_NO_TILE");
+  static const bool no_pair = tuning_flag("DSIR_NO_PAIR");      // A/B switch: mlp1 and mlp_skip as two launches throughout
+  return !no_tile && !no_pair && pw_tile_small_serves(a);
+}
+
 void launch_pw_gemm(const GemmArgs& a, hipStream_t st) {
   if (a.M <= 0 || a.clouds <= 0) return;
   static const bool no_stream = tuning_flag("DSIR_NO_STREAM");   // A/B switch for tests and profiling

@@ -640,6 +640,7 @@ bool seg_vec_ok(const Seg& s, int KQ) {
 // Returns false when the layer is outside this kernel's envelope (caller falls back to pw_gemm.hip).
 bool launch_pw_stream(const GemmArgs& a, hipStream_t st) {
   if (a.M <= 0 || a.clouds <= 0) return true;
+  if (a.c_split > 0) return false;             // two-layer launches: pw_tile_small_kernel only
   if (a.amode == A_LSE) {
     if (a.epi != EPI_GN) return false;
     return launch_nt<3, S_LSE>(a, st);

@@ -608,7 +608,12 @@ __global__ __launch_bounds__(256) void pw_tile_small_kernel(const GemmArgs p) {
     if (kc + 1 < nchunks) chunk(kc + 1, 1, preB);
   }
   // ---- epilogue.  C layout: col = lane & 15, row = 4 * (lane >> 4) + reg.
-  float* Y = p.Y + cloud * p.y_cloud_stride;
+  // two layers in one launch (GemmArgs::c_split): this workgroup's 64 columns belong to ONE of them (c_split is a multiple of 64)
+  const bool sec = EPI == EPI_GN && p.c_split > 0 && n0 >= p.c_split;
+  const int cb0 = sec ? p.c_split : 0;                          // first column of the layer
+  const int cw = sec ? p.Cout - p.c_split : (p.c_split > 0 && EPI == EPI_GN ? p.c_split : p.Cout);   // its width
+  const int ldy = sec ? p.ldy2 : p.ldy;
+  float* Y = sec ? p.Y2 + cloud * p.y2_cloud_stride : p.Y + cloud * p.y_cloud_stride;
 #pragma unroll
   for (int t = 0; t < NTW; ++t) {
     const int col = n0 + 16 * (NTW * wc + t) + fr;
@@ -624,7 +629,7 @@ __global__ __launch_bounds__(256) void pw_tile_small_kernel(const GemmArgs p) {
           float v = acc[rt][t][r] + bv;
           if (EPI == EPI_LINEAR && p.residual) v += p.residual[cloud * p.res_cloud_stride + (int64_t)row * p.ldres + col];
           if (EPI == EPI_ACT && v < 0.f) v *= 0.2f;
-          Y[(int64_t)row * p.ldy + col] = v;
+          Y[(int64_t)row * ldy + (col - cb0)] = v;
           s1 += v;
           s2 += v * v;
         }
@@ -647,7 +652,9 @@ __global__ __launch_bounds__(256) void pw_tile_small_kernel(const GemmArgs p) {
       s_gn[tid] = v;
     }
     __syncthreads();
-    gn_block_commit(s_gn, n0, min(BN, p.Cout - n0), p.Cout / p.groups_out, p.stats_out + (int64_t)cloud * p.groups_out * kGnWords);
+    const int groups = sec ? p.groups_out2 : p.groups_out;
+    double* stats = sec ? p.stats_out2 : p.stats_out;
+    gn_block_commit(s_gn, n0 - cb0, min(BN, cw - (n0 - cb0)), cw / groups, stats + (int64_t)cloud * groups * kGnWords);
   }
 }
 
@@ -703,15 +710,29 @@ bool seg_ok(const Seg& s) {
 
 }  // namespace
 
+// does launch_pw_tile hand this layer to pw_tile_small_kernel?  (engine.hip asks before it fuses two layers into one launch)
+bool pw_tile_small_serves(const GemmArgs& a) {
+  static const int min_cout_h = (int)tuning_int("DSIR_TILE_MIN_COUT", 32);
+  static const int small_m = (int)tuning_int("DSIR_TILE_SMALL_M", 320);
+  if (a.amode != A_SEGS || a.Cin < 64 || a.Cin > MAXC || (a.Cin % BK) != 0 || a.Cout < (use_split(a) ? min_cout_h : 64)) return false;
+  if (!seg_ok(a.seg[0]) || (a.nseg > 1 && (!seg_ok(a.seg[1]) || (a.seg[0].C % 4) != 0))) return false;
+  if ((reinterpret_cast<uintptr_t>(a.W) % 16) != 0) return false;
+  return a.M <= small_m && a.epi == EPI_GN;
+}
+
 // Returns false when the layer is outside this kernel's envelope (caller falls back to pw_gemm.hip).
 bool launch_pw_tile(const GemmArgs& a, hipStream_t st) {
+  if (a.c_split > 0 && !pw_tile_small_serves(a)) return false;      // two-layer launches exist for the small-M kernel only
   // Cout >= 64 - or >= 32 with the fp16-split contraction, where the unused half of the 64-column tile costs next to nothing
   // (the level-0 decoder layer 160 -> 32, otherwise left to the generic pw_gemm.hip kernel)
   static const int min_cout_h = (int)tuning_int("DSIR_TILE_MIN_COUT", 32);   // A/B hook
   if (a.amode != A_SEGS || a.Cin < 64 || a.Cin > MAXC || (a.Cin % BK) != 0 || a.Cout < (use_split(a) ? min_cout_h : 64)) return false;
   if (!seg_ok(a.seg[0]) || (a.nseg > 1 && (!seg_ok(a.seg[1]) || (a.seg[0].C % 4) != 0))) return false;
   if ((reinterpret_cast<uintptr_t>(a.W) % 16) != 0) return false;
-  if (a.epi == EPI_GN && ((a.Cout / a.groups_out) % 8) != 0) return false;
+  if (a.epi == EPI_GN && a.c_split == 0 && ((a.Cout / a.groups_out) % 8) != 0) return false;
+  if (a.c_split > 0 && ((a.c_split % BN) != 0 || a.c_split >= a.Cout || !a.Y2 || !a.stats_out2 || a.groups_out2 < 1 ||
+                        ((a.c_split / a.groups_out) % 8) != 0 || (((a.Cout - a.c_split) / a.groups_out2) % 8) != 0))
+    return false;
   // rows per block: a function of M only (batch-invariant tiling)
   static const int small_m = (int)tuning_int("DSIR_TILE_SMALL_M", 320);   // tuning hook; 0 = off
   if (a.M <= small_m && (a.epi == EPI_GN || a.epi == EPI_ACT || a.epi == EPI_LINEAR)) {
