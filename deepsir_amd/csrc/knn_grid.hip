@@ -6,9 +6,9 @@
 // strictly (with a safety margin against fp32 rounding) inside the cube already
 // visited, so every point that could enter or tie the top 16 has been seen.
 //
-// Per level and cloud batch: bounding box + cell size (one block per cloud),
-// cell histogram, exclusive scan (one block per cloud), scatter into cell order
-// (xyz + original index packed in a float4), query (one lane per point, points
+// Per level and cloud batch: bounding box + cell size, cell histogram, exclusive scan, scatter into cell order
+// (xyz + original index packed in a float4) - one launch with the cell table in LDS (grid_build_kernel) up to 16384
+// points, five launches beyond -, query (one lane per point, points
 // taken in cell order so that a wave's lanes walk neighbouring cells).
 // Candidates arrive in arbitrary index order, hence the lexicographic insertion.
 #include "kernels.h"
@@ -152,6 +152,112 @@ __global__ __launch_bounds__(256) void grid_scatter_kernel(const float* __restri
     const int pos = atomicAdd(&cursor[(int64_t)cloud * max_cells + c], 1);
     sorted[(int64_t)cloud * n + pos] =
         make_float4(P[(int64_t)i * stride], P[(int64_t)i * stride + 1], P[(int64_t)i * stride + 2], __int_as_float(i));
+  }
+}
+
+// One launch instead of five (memset, setup, count, scan, scatter) for clouds whose cell table fits LDS: one 1024-thread workgroup per
+// cloud computes the bounding box and the grid, counts the points per cell in LDS, scans the counts, and scatters the points into cell
+// order through LDS cursors.  The order of the points inside a cell follows the arrival of the atomics - as in the five-launch form;
+// the searches do not depend on it (lexicographic top-16 / top-1).  kBuildMaxCells ints of LDS twice.
+constexpr int kBuildMaxCells = 8256;      // n <= 16384
+__global__ __launch_bounds__(1024) void grid_build_kernel(const float* __restrict__ pts, int64_t cs, int stride, int n, int max_cells,
+                                                          GridParams* __restrict__ gp, int* __restrict__ starts,
+                                                          float4* __restrict__ sorted) {
+  __shared__ float red[6][16];
+  __shared__ GridParams s_g;
+  __shared__ int s_cnt[kBuildMaxCells];
+  __shared__ int s_cur[kBuildMaxCells];
+  __shared__ int wsum[16];
+  __shared__ int carry_s;
+  const int cloud = blockIdx.x;
+  const float* P = pts + cloud * cs;
+  // ---- bounding box and grid (grid_setup_kernel, verbatim)
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int i = threadIdx.x; i < n; i += blockDim.x)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float v = P[(int64_t)i * stride + k];
+      lo[k] = fminf(lo[k], v);
+      hi[k] = fmaxf(hi[k], v);
+    }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    float a = lo[k], b = hi[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a = fminf(a, __shfl_xor(a, o)); b = fmaxf(b, __shfl_xor(b, o)); }
+    if (lane == 0) { red[k][w] = a; red[3 + k][w] = b; }
+  }
+  for (int c = threadIdx.x; c < max_cells; c += blockDim.x) s_cnt[c] = 0;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float mn[3], mx[3];
+    for (int k = 0; k < 3; ++k) {
+      mn[k] = red[k][0]; mx[k] = red[3 + k][0];
+      for (int ww = 1; ww < (int)(blockDim.x >> 6); ++ww) { mn[k] = fminf(mn[k], red[k][ww]); mx[k] = fmaxf(mx[k], red[3 + k][ww]); }
+    }
+    float ext[3], emax = 0.f;
+    for (int k = 0; k < 3; ++k) { ext[k] = mx[k] - mn[k]; emax = fmaxf(emax, ext[k]); }
+    if (!(emax > 0.f) || !isfinite(emax)) emax = 1.f;
+    float vol = 1.f;
+    for (int k = 0; k < 3; ++k) vol *= fmaxf(ext[k], emax * 1e-3f);
+    const float target = fmaxf((float)n / (float)kPointsPerCell, 1.f);
+    float h = cbrtf(vol / target);
+    if (!(h > 0.f) || !isfinite(h)) h = emax;
+    int g[3];
+    for (int it = 0; it < 64; ++it) {
+      long long prod = 1;
+      for (int k = 0; k < 3; ++k) {
+        g[k] = (int)fminf(floorf(ext[k] / h) + 1.f, 1.0e6f);
+        if (g[k] < 1) g[k] = 1;
+        prod *= g[k];
+      }
+      if (prod <= max_cells) break;
+      h *= 1.26f;
+      if (it == 63) g[0] = g[1] = g[2] = 1;
+    }
+    GridParams q;
+    q.ox = mn[0]; q.oy = mn[1]; q.oz = mn[2]; q.h = h; q.inv_h = 1.f / h; q.gx = g[0]; q.gy = g[1]; q.gz = g[2];
+    s_g = q;
+    gp[cloud] = q;
+    carry_s = 0;
+  }
+  __syncthreads();
+  const GridParams g = s_g;
+  const int ncell = g.gx * g.gy * g.gz;
+  auto cell_of_pt = [&](int i) {
+    const int cx = cell_coord(P[(int64_t)i * stride], g.ox, g.inv_h, g.gx);
+    const int cy = cell_coord(P[(int64_t)i * stride + 1], g.oy, g.inv_h, g.gy);
+    const int cz = cell_coord(P[(int64_t)i * stride + 2], g.oz, g.inv_h, g.gz);
+    return (cz * g.gy + cy) * g.gx + cx;
+  };
+  // ---- count
+  for (int i = threadIdx.x; i < n; i += blockDim.x) atomicAdd(&s_cnt[cell_of_pt(i)], 1);
+  __syncthreads();
+  // ---- exclusive scan (grid_scan_kernel): starts -> global, cursors -> LDS
+  int* S = starts + (int64_t)cloud * (max_cells + 1);
+  for (int base = 0; base < ncell; base += 1024) {
+    const int i = base + threadIdx.x;
+    const int v = i < ncell ? s_cnt[i] : 0;
+    int x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o); if (lane >= o) x += y; }
+    if (lane == 63) wsum[w] = x;
+    __syncthreads();
+    int woff = 0;
+    for (int ww = 0; ww < w; ++ww) woff += wsum[ww];
+    const int excl = carry_s + woff + x - v;
+    if (i < ncell) { S[i] = excl; s_cur[i] = excl; }
+    __syncthreads();
+    if (threadIdx.x == 1023) carry_s = excl + v;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) S[ncell] = carry_s;
+  // ---- scatter into cell order
+  float4* SO = sorted + (int64_t)cloud * n;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int pos = atomicAdd(&s_cur[cell_of_pt(i)], 1);
+    SO[pos] = make_float4(P[(int64_t)i * stride], P[(int64_t)i * stride + 1], P[(int64_t)i * stride + 2], __int_as_float(i));
   }
 }
 
@@ -547,12 +653,18 @@ void launch_knn16_grid(const float* pts, int64_t cs, int stride, int n, int clou
   int* starts = reinterpret_cast<int*>(take((size_t)clouds * (max_cells + 1) * sizeof(int)));
   int* cursor = reinterpret_cast<int*>(take((size_t)clouds * max_cells * sizeof(int)));
   float4* sorted = reinterpret_cast<float4*>(take((size_t)clouds * n * sizeof(float4)));
-  hipMemsetAsync(counts, 0, (size_t)clouds * max_cells * sizeof(int), st);
-  hipLaunchKernelGGL(grid_setup_kernel, dim3(clouds), dim3(1024), 0, st, pts, cs, stride, n, max_cells, gp);
-  const int gx = (n + 255) / 256;
-  hipLaunchKernelGGL(grid_count_kernel, dim3(gx, clouds), dim3(256), 0, st, pts, cs, stride, n, gp, max_cells, cell_of, counts);
-  hipLaunchKernelGGL(grid_scan_kernel, dim3(clouds), dim3(1024), 0, st, counts, max_cells, gp, starts, cursor);
-  hipLaunchKernelGGL(grid_scatter_kernel, dim3(gx, clouds), dim3(256), 0, st, pts, cs, stride, n, cell_of, max_cells, cursor, sorted);
+  static const bool no_build = tuning_flag("DSIR_GRID_NO_BUILD");     // A/B switch: the five-launch construction throughout
+  if (!no_build && max_cells <= kBuildMaxCells) {
+    // cell table in LDS: bounding box, grid, count, scan and scatter in ONE launch, one workgroup per cloud
+    hipLaunchKernelGGL(grid_build_kernel, dim3(clouds), dim3(1024), 0, st, pts, cs, stride, n, max_cells, gp, starts, sorted);
+  } else {
+    hipMemsetAsync(counts, 0, (size_t)clouds * max_cells * sizeof(int), st);
+    hipLaunchKernelGGL(grid_setup_kernel, dim3(clouds), dim3(1024), 0, st, pts, cs, stride, n, max_cells, gp);
+    const int gx = (n + 255) / 256;
+    hipLaunchKernelGGL(grid_count_kernel, dim3(gx, clouds), dim3(256), 0, st, pts, cs, stride, n, gp, max_cells, cell_of, counts);
+    hipLaunchKernelGGL(grid_scan_kernel, dim3(clouds), dim3(1024), 0, st, counts, max_cells, gp, starts, cursor);
+    hipLaunchKernelGGL(grid_scatter_kernel, dim3(gx, clouds), dim3(256), 0, st, pts, cs, stride, n, cell_of, max_cells, cursor, sorted);
+  }
   // one lane per query when that fills the chip (1024 SIMDs), four lanes per query for a few clouds in flight; same bits
   if ((int64_t)((n + KB - 1) / KB) * clouds >= 1024)
     hipLaunchKernelGGL(grid_knn_kernel, dim3((n + KB - 1) / KB, clouds), dim3(KB), 0, st, sorted, starts, gp, max_cells, n, out, ocs);
