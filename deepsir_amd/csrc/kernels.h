@@ -152,6 +152,7 @@ struct LseUvArgs {
   float* dist = nullptr; int64_t dist_cs = 0;            // [clouds][n * 16]
   double* stats_out = nullptr; int groups = 0;           // [clouds][groups][kGnWords]
   int n = 0, clouds = 0, KH = 0;
+  int vgrid = 0;                                         // virtual workgroups per cloud (filled by the launcher; a function of n alone)
 };
 bool launch_lse_uv_stats(const LseUvArgs& a, hipStream_t st);   // KH = 8 or 32; false => outside the envelope
 

@@ -50,18 +50,22 @@ __global__ __launch_bounds__(256) void lse_uv_stats_kernel(const LseUvArgs p) {
   float* UV = p.uv + cloud * p.uv_cs;
   float* D = p.dist + cloud * p.dist_cs;
   float s1[KQ], s2[KQ];
+  const int ntile = (p.n + PP - 1) / PP;
+  // VIRTUAL workgroups (p.vgrid per cloud, a function of n alone: ~4 steps each) fix which rows are summed together; the physical
+  // workgroup plays the virtual ones blockIdx.x, blockIdx.x + gridDim.x, ... (chip-filling launches: few physical workgroups, weights
+  // loaded once; one or two clouds: one physical workgroup per virtual one, four dependent gathers deep instead of sixteen)
+  for (int vb = blockIdx.x; vb < p.vgrid; vb += gridDim.x) {
 #pragma unroll
   for (int c = 0; c < KQ; ++c) { s1[c] = 0.f; s2[c] = 0.f; }
-  const int ntile = (p.n + PP - 1) / PP;
   // the next step's index is fetched while the current one is computed (index -> coordinates is a dependent pair of loads)
-  int tile = blockIdx.x;
+  int tile = vb;
   int jn = tile < ntile ? NB[(uint32_t)min(tile * PP + pl, p.n - 1) * 16u + (uint32_t)k] : 0;
-  for (; tile < ntile; tile += gridDim.x) {
+  for (; tile < ntile; tile += p.vgrid) {
     const int i = tile * PP + pl;
     const bool ok = i < p.n;
     const int ic = ok ? i : p.n - 1;
     const int j = jn;
-    if (tile + (int)gridDim.x < ntile) jn = NB[(uint32_t)min((tile + (int)gridDim.x) * PP + pl, p.n - 1) * 16u + (uint32_t)k];
+    if (tile + p.vgrid < ntile) jn = NB[(uint32_t)min((tile + p.vgrid) * PP + pl, p.n - 1) * 16u + (uint32_t)k];
     const float ix = X[(uint32_t)ic * 3u], iy = X[(uint32_t)ic * 3u + 1], iz = X[(uint32_t)ic * 3u + 2];
     const float jx = X[(uint32_t)j * 3u], jy = X[(uint32_t)j * 3u + 1], jz = X[(uint32_t)j * 3u + 2];
     const float dx = __fsub_rn(jx, ix), dy = __fsub_rn(jy, iy), dz = __fsub_rn(jz, iz);
@@ -95,23 +99,31 @@ __global__ __launch_bounds__(256) void lse_uv_stats_kernel(const LseUvArgs p) {
   }
   __syncthreads();
   gn_block_commit(s_red, 0, KH, KH / p.groups, p.stats_out + (int64_t)cloud * p.groups * kGnWords);
+  if (vb + (int)gridDim.x < p.vgrid) __syncthreads();      // s_red is free again before the next virtual workgroup's sums land in it
+  }  // vb
 }
 
 }  // namespace
 
-// workgroups per cloud: a function of n alone (a cloud's summation order - hence its bits - is the same alone or in a batch)
+// VIRTUAL workgroups per cloud: a function of n alone (a cloud's summation order - hence its bits - is the same alone or in a batch)
 bool launch_lse_uv_stats(const LseUvArgs& a, hipStream_t st) {
   if (a.n <= 0 || a.clouds <= 0) return true;
   if (!a.xyz || !a.neigh || !a.w8 || !a.uv || !a.dist || !a.stats_out || a.groups < 1 || (a.KH % a.groups) != 0) return false;
   if ((int64_t)a.n * 16 * 4 >= ((int64_t)1 << 32) || (int64_t)a.n * 2 * a.KH * 4 >= ((int64_t)1 << 32)) return false;
   const int pp = a.KH == 8 ? 16 : 4;       // points per workgroup step
   const int ntile = (a.n + pp - 1) / pp;
-  int blocks = (ntile + 15) / 16;          // ~16 steps per workgroup
-  if (blocks < 1) blocks = 1;
+  LseUvArgs b = a;
+  b.vgrid = (ntile + 3) / 4;               // virtual workgroups: ~4 steps each (the unit of the statistics' fp32 sums)
+  if (b.vgrid < 1) b.vgrid = 1;
+  // physical workgroups: ~16 steps each once that fills the chip, else about one residency round, never more than the virtual grid
+  const int natural = (ntile + 15) / 16;
+  int64_t want = (int64_t)natural * a.clouds >= 512 ? natural : (512 + a.clouds - 1) / a.clouds;
+  if (want < 1) want = 1;
+  const int blocks = (int)(want < b.vgrid ? want : b.vgrid);
   const dim3 grid(blocks, a.clouds);
   switch (a.KH) {
-    case 8: hipLaunchKernelGGL((lse_uv_stats_kernel<8, 1>), grid, dim3(256), 0, st, a); return true;
-    case 32: hipLaunchKernelGGL((lse_uv_stats_kernel<32, 4>), grid, dim3(256), 0, st, a); return true;
+    case 8: hipLaunchKernelGGL((lse_uv_stats_kernel<8, 1>), grid, dim3(256), 0, st, b); return true;
+    case 32: hipLaunchKernelGGL((lse_uv_stats_kernel<32, 4>), grid, dim3(256), 0, st, b); return true;
     default: return false;
   }
 }
