@@ -224,6 +224,30 @@ def test_hoisted_loop_invariants_are_bit_identical(tmp_path):
             assert np.array_equal(outs["hoisted"][k], outs[other][k]), f"{k} differs between hoisted and {other}"
 
 
+def test_round4_launch_restructurings_are_bit_identical(tmp_path):
+    """Round 4 changed HOW several layers are launched without touching what they compute: mlp1 + mlp_skip of the deep levels share a
+    launch (GemmArgs::c_split; DSIR_NO_PAIR: two launches), GroupNorm layers of pw_stream.hip play their virtual workgroups on fewer
+    physical ones in chip-filling launches (DSIR_STREAM_PHYS_BLOCKS=0: one per virtual workgroup), the KNN grid of a level is built by
+    one launch (DSIR_GRID_NO_BUILD: five).  64-pair registrations (every large-launch choice active) under each switch: same bits."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    switches = {"default": {}, "no_pair": {"DSIR_NO_PAIR": "1"}, "no_fold": {"DSIR_STREAM_PHYS_BLOCKS": "0"}, "no_build": {"DSIR_GRID_NO_BUILD": "1"}}
+    outs = {}
+    for name, extra in switches.items():
+        out = str(tmp_path / f"{name}.npz")
+        env = {k: v for k, v in os.environ.items() if not k.startswith("DSIR_")}
+        if extra:
+            env.update(extra)
+            env["DSIR_TUNING"] = "1"
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "ab_outputs.py"), out, "64"], env=env, capture_output=True, text=True,
+                           timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[name] = np.load(out)
+    for other in ("no_pair", "no_fold", "no_build"):
+        for k in outs["default"].files:
+            assert np.array_equal(outs["default"][k], outs[other][k]), f"{k} differs between default and {other}"
+
+
 def test_engine_on_the_callers_stream_gives_the_same_bits():
     """dsir_set_stream (include/dsir.h): the engine's launches ordered on torch's current stream instead of the context's own
     - no host synchronisation around a call - must not change a bit, on the default stream and on a side stream, and the
