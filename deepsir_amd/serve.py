@@ -15,7 +15,7 @@ small scheduler instead:
 * ``future.result()`` waits for that request's batch only.
 
 A pair's result does not depend on what shares its batch (every kernel's tiling is a function of the per-cloud shape alone,
-GroupNorm statistics meet in order-independent integer atomics): served results are bit-identical to the batched path's -
+GroupNorm statistics meet in exact, order-independent atomics on integer-valued fp64 limbs): served results are bit-identical to the batched path's -
 ``tests/test_serve.py`` asserts it.  Nothing here computes: all work is ``Engine.register`` (libdsir.so).
 """
 from __future__ import annotations

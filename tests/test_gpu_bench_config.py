@@ -314,7 +314,8 @@ def test_alternating_torch_streams_share_the_workspace_safely():
 
 
 def test_groupnorm_statistics_do_not_depend_on_arrival_order():
-    """GroupNorm statistics of a layer meet across workgroups in INTEGER atomics (csrc/device_utils.h, gn_stat_add): the totals
+    """GroupNorm statistics of a layer meet across workgroups in EXACT atomics - integer-valued fp64 limbs added with the hardware fp64 atomic
+    add, exact below 2^53 (csrc/device_utils.h, gn_block_commit): the totals
     - hence every bit downstream - cannot depend on the order in which workgroups arrive.  One 32-pair registration repeated 200
     times on two concurrently running engines (EnginePool, 2 HIP streams, kernels of both interleaving on the CUs): identical
     correspondences, logits and poses every time; the two halves of the batch also equal a single-engine run."""
