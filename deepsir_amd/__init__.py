@@ -13,12 +13,26 @@ _os.environ.setdefault(_FLAG, "0")
 
 
 def graph_replay_safe() -> bool:
-    """True when the flag above reached the HIP runtime: it was in the environment before this import, or the process had not
-    initialised the GPU yet when this package was imported."""
+    """True when the flag above reached the HIP runtime: it was ALREADY in the environment when this package was imported, or
+    the process had not opened the GPU driver yet at that moment (``_gpu_untouched``)."""
     return _SAFE and _os.environ.get(_FLAG) == "0"
 
 
 def _gpu_untouched() -> bool:
+    """Has this process initialised the HIP runtime yet?  torch's own state does not say: ``torch.cuda.is_available()`` goes
+    through hipGetDeviceCount, which initialises the runtime (and reads the ROCclr flags) while ``torch.cuda.is_initialized()``
+    stays False, and any other library can initialise HIP without torch.  What every initialisation does is open the
+    compute driver node: a process with no descriptor on /dev/kfd has not started the runtime.  Where /proc cannot be read the
+    answer is the conservative one (touched)."""
+    try:
+        for fd in _os.listdir("/proc/self/fd"):
+            try:
+                if _os.readlink("/proc/self/fd/" + fd) == "/dev/kfd":
+                    return False
+            except OSError:
+                continue
+    except OSError:
+        return False
     import sys
     t = sys.modules.get("torch")
     if t is None:
@@ -26,7 +40,7 @@ def _gpu_untouched() -> bool:
     try:
         return not t.cuda.is_initialized()
     except Exception:
-        return True
+        return False
 
 
 _SAFE = (_preset == "0") or _gpu_untouched()

@@ -106,6 +106,9 @@ SYMBOLS = {
     "dsir_set_kabsch_chunked_min": (C.c_int, [C.c_void_p, C.c_int]),
     "dsir_set_tuning": (None, [C.c_int]),
     "dsir_tuning": (C.c_int, []),
+    "dsir_gn_contributions": (C.c_int, [C.POINTER(dsir_cfg), C.c_int]),
+    "dsir_gn_contribution_limit": (C.c_int, []),
+    "dsir_max_points_limit": (C.c_int, [C.POINTER(dsir_cfg)]),
     "dsir_screen_bounds": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dsir_screen_cap": (C.c_int, []),

@@ -38,7 +38,8 @@ struct AlignLossArgs {
   int P, J, K, n_iter, mse;
   float wt_pt, wt_in, discount;
   float* T_out;                               // [P][n_iter][3][4] or nullptr
-  double* losses;                             // [n_iter][2] (point-distance term, confidence term), accumulated over pairs
+  double* losses;                             // [n_iter][2] (point-distance term, confidence term), summed over the pairs by align_loss_reduce_kernel
+  double* loss_part;                          // [P][n_iter][2] every pair's terms (nullptr: no losses wanted)
   float* grad;                                // [n_iter][P][J]
 };
 
@@ -196,9 +197,9 @@ __global__ __launch_bounds__(AL_THREADS) void align_loss_kernel(AlignLossArgs a)
     block_sum_d<14>(v14, sh);
     if (tid == 0) {
       for (int k = 0; k < 12; ++k) st[it].G[k] = v14[k];
-      if (a.losses) {
-        if (a.wt_pt > 0.f) atomicAdd(a.losses + 2 * it, v14[12] * inv_pts);
-        if (a.labels && a.wt_in > 0.f) atomicAdd(a.losses + 2 * it + 1, v14[13] * inv_rows * (double)a.wt_in);
+      if (a.loss_part) {      // this pair's terms; align_loss_reduce_kernel adds the pairs in pair order (no atomics: same bits every run)
+        a.loss_part[((int64_t)pair * a.n_iter + it) * 2] = a.wt_pt > 0.f ? v14[12] * inv_pts : 0.0;
+        a.loss_part[((int64_t)pair * a.n_iter + it) * 2 + 1] = (a.labels && a.wt_in > 0.f) ? v14[13] * inv_rows * (double)a.wt_in : 0.0;
       }
     }
     __syncthreads();
@@ -300,18 +301,29 @@ __global__ __launch_bounds__(AL_THREADS) void align_loss_kernel(AlignLossArgs a)
   }
 }
 
+// losses[it][term] = sum over the pairs, in pair order
+__global__ void align_loss_reduce_kernel(const double* __restrict__ part, int P, int n2, double* __restrict__ losses) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n2) return;
+  double s = 0.0;
+  for (int p = 0; p < P; ++p) s += part[(int64_t)p * n2 + k];
+  losses[k] = s;
+}
+
 }  // namespace
 
 int launch_align_loss(const float* src, const float* ref, const int32_t* idx, const float* logits, const float* labels,
                       const float* T_gt, int P, int J, int K, int n_iter, int mse, float wt_pt, float wt_in, float discount,
-                      float* T_out, double* losses, float* grad, hipStream_t st) {
+                      float* T_out, double* losses, float* grad, hipStream_t st, double* loss_part) {
   if (n_iter < 1 || n_iter > AL_MAX_ITER) return 1;
   AlignLossArgs a;
   a.src = src; a.ref = ref; a.idx = idx; a.logits = logits; a.labels = labels; a.T_gt = T_gt; a.P = P; a.J = J; a.K = K;
   a.n_iter = n_iter; a.mse = mse; a.wt_pt = wt_pt; a.wt_in = wt_in; a.discount = discount; a.T_out = T_out; a.losses = losses;
   a.grad = grad;
-  if (losses) (void)hipMemsetAsync(losses, 0, sizeof(double) * 2 * n_iter, st);
+  if (losses && !loss_part) return 2;
+  a.loss_part = losses ? loss_part : nullptr;
   hipLaunchKernelGGL(align_loss_kernel, dim3(P), dim3(AL_THREADS), 0, st, a);
+  if (losses) hipLaunchKernelGGL(align_loss_reduce_kernel, dim3(1), dim3(64), 0, st, loss_part, P, 2 * n_iter, losses);
   return 0;
 }
 

@@ -185,6 +185,43 @@ void fill_pyramid_layout(const dsir_cfg& cfg, int clouds, int n, Pyramid& p) {
   p.S = p.off[cfg.num_layers]; p.S1 = p.soff[cfg.num_layers];
 }
 
+// The most contributions any (cloud, group) GroupNorm statistic receives when a cloud of n points goes through RandLA.forward: the
+// maximum of the launchers' own counts (kernels.h) over every MLP2D of the schedule, under the default dispatch of launch_pw_gemm
+// (Cin <= 64 and the relative-position layers: pw_stream.hip or - d / 2 = 8, 32 - lse_uv.hip; wider: pw_tile.hip, whose count also
+// bounds the generic pw_gemm.hip kernel's 64-row blocks).  The exactness proof of the statistics' atomics (device_utils.h) needs
+// this number <= kGnMaxContrib: dsir_create refuses a max_points beyond it.
+int gn_max_contributions(const dsir_cfg& g, int n) {
+  int worst = 0;
+  auto layer = [&](int M, int cin, int cout) {
+    const int groups = cout >= 64 ? 8 : 4;
+    const int c = cin <= 64 ? pw_stream_gn_contributions(M, cout) : pw_tile_gn_contributions(M, cout, groups);
+    if (c > worst) worst = c;
+  };
+  int nl[DSIR_MAX_LEVELS + 1];
+  level_sizes(g, n, nl);
+  const int L = g.num_layers;
+  layer(nl[0], 6 > g.feat_len ? 6 : g.feat_len, 8);
+  int dim = 8;
+  for (int l = 0; l < L; ++l) {
+    const int d = g.d_out[l], m = nl[l], mk = nl[l] * kKnn;
+    layer(m, dim, d / 2); layer(m, dim, 2 * d);                  // mlp1, mlp_skip
+    if (d / 2 == 8 || d / 2 == 32) { const int c = lse_uv_gn_contributions(m, d / 2); if (c > worst) worst = c; }
+    layer(mk, 10, d / 2);                                        // lfa.mlp1 (also when the tables are switched off)
+    layer(mk, d / 2, d / 2);                                     // lfa.mlp2
+    layer(m, d, d / 2); layer(m, d, d); layer(m, d, 2 * d);      // att_pooling_1.mlp, att_pooling_2.mlp, mlp2
+    dim = 2 * d;
+  }
+  layer(nl[L], dim, dim);
+  int dcur = dim;
+  for (int j = 0; j < L; ++j) {
+    const int lvl = L - 1 - j;
+    const int cin = j < L - 1 ? dcur + 2 * g.d_out[L - j - 2] : 4 * g.d_out[0];
+    dcur = j < L - 1 ? 2 * g.d_out[L - j - 2] : 2 * g.d_out[0];
+    layer(nl[lvl], cin, dcur);
+  }
+  return worst;
+}
+
 // ------------------------------------------------------------------ expected state-dict (mirrors deepsir_amd/arch.py)
 void add_param(dsir_ctx* c, const std::string& name, std::vector<int64_t> shape, bool ignored = false) {
   HostParam p;
@@ -414,7 +451,7 @@ bool att_pool_enabled() {
 // A/B switch: DSIR_NO_LSE_UV = lfa.mlp1 of levels 0 / 1 written to memory as up to round 3 (pw_stream.hip, loader S_LSE) instead of
 // the per-point tables of lse_uv.hip; the tables' consumers are att_pool.hip and pw_stream.hip (loader S_UV) only
 bool lse_uv_enabled() {
-  static const bool off = tuning_flag("DSIR_NO_LSE_UV");
+  static const bool off = tuning_flag("DSIR_NO_LSE_UV") || tuning_flag("DSIR_NO_STREAM");   // the tables' GEMM consumer is pw_stream.hip alone
   return !off && att_pool_enabled();
 }
 
@@ -457,7 +494,13 @@ struct Sched {
     a.W = w.W; a.bias = w.b; a.Cin = w.cin; a.Cout = w.cout; a.M = M; a.clouds = clouds; a.epi = EPI_GN;
     a.Y = y.p; a.y_cloud_stride = (int64_t)M * w.cout; a.ldy = w.cout; a.stats_out = st_out; a.groups_out = w.groups;
     split_of(a);
-    if (!c->ws.overflow) launch_pw_gemm(a, st);   // an exhausted arena hands out its base: nothing may run on it
+    if (c->ws.overflow) return y;                 // an exhausted arena hands out its base: nothing may run on it
+    if ((s0.uv && !s0.x) || (s1 && s1->uv && !s1->x)) {
+      // table-only rows (lse_uv.hip) exist for ONE loader, pw_stream.hip's S_UV: the generic kernels would dereference the null row base
+      if (!launch_pw_stream(a, st)) { c->sched_error = "MLP2D: no kernel took the table-only position encoding"; c->ws.overflow = true; }
+      return y;
+    }
+    launch_pw_gemm(a, st);
     return y;
   }
   // mlp1 and mlp_skip of a block in ONE launch (same input; the weights one after the other, BlockW::pair_W): two outputs, two
@@ -879,6 +922,11 @@ int dsir_create(int device, const dsir_cfg* cfg, dsir_ctx** out) {
   // several kernels address a cloud's rows with 32-bit byte offsets from a per-cloud base (n * 16 * d * 4 < 2^32 at d = 64: knn_grid.hip,
   // att_pool.hip, lse_uv.hip check their own products); 2^20 points per cloud is far beyond what the 2.5 kB-per-point workspace admits
   if (cfg->max_points > (1 << 20)) return fail(nullptr, "max_points must be <= %d", 1 << 20);
+  // the GroupNorm statistics' atomics are exact - order independent - for at most kGnMaxContrib contributions per statistic
+  // (device_utils.h); the largest layer of a cloud of max_points points must stay within that
+  if (const int gc = gn_max_contributions(*cfg, cfg->max_points); gc > kGnMaxContrib)
+    return fail(nullptr, "max_points=%d: %d workgroup contributions per GroupNorm statistic exceed the exactness bound %d of the statistics' atomics (max_points <= %d)",
+                cfg->max_points, gc, kGnMaxContrib, dsir_max_points_limit(cfg));
   if (cfg->pipeline < DSIR_PIPELINE_ALIGN || cfg->pipeline > DSIR_PIPELINE_LABEL) return fail(nullptr, "unknown pipeline %d", cfg->pipeline);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, "no HIP device available");
@@ -952,6 +1000,23 @@ void dsir_destroy(dsir_ctx* c) {
   if (c->ws.base) hipFree(c->ws.base);
   hipStreamDestroy(c->own_stream);     // a caller's stream (dsir_set_stream) is the caller's to destroy
   delete c;
+}
+
+int dsir_gn_contributions(const dsir_cfg* cfg, int n_points) {
+  if (!cfg || cfg->num_layers != 4 || n_points < 1) return -1;
+  for (int l = 0; l < 4; ++l) if (cfg->sub_sampling_ratio[l] < 1) return -1;
+  return gn_max_contributions(*cfg, n_points);
+}
+int dsir_gn_contribution_limit(void) { return kGnMaxContrib; }
+int dsir_max_points_limit(const dsir_cfg* cfg) {
+  if (dsir_gn_contributions(cfg, 1024) < 0) return -1;
+  int lo = 1024, hi = 1 << 20;                       // the count grows with n: bisect the largest n within the bound
+  if (gn_max_contributions(*cfg, hi) <= kGnMaxContrib) return hi;
+  while (hi - lo > 1) {
+    const int mid = lo + (hi - lo) / 2;
+    if (gn_max_contributions(*cfg, mid) <= kGnMaxContrib) lo = mid; else hi = mid;
+  }
+  return lo;
 }
 
 void dsir_set_tuning(int on) { g_tuning = on ? 1 : 0; }
@@ -1657,10 +1722,11 @@ int dsir_align_loss_backward(dsir_ctx* c, const float* pt_src, const float* pt_r
   // correspondences come from the caller: clamped into [0, K) before any gather
   int32_t* idx_ok = c->ws.get<int32_t>((size_t)n_iter * pairs * J);
   double* dloss = c->ws.get<double>((size_t)2 * n_iter);
+  double* dpart = c->ws.get<double>((size_t)2 * n_iter * pairs);       // every pair's loss terms, added in pair order (align_loss.hip)
   if (c->ws.overflow) return fail(c, "workspace too small for dsir_align_loss_backward");
   launch_copy_idx_clamped(idx, (int64_t)pairs * J, pairs * J, K, n_iter, idx_ok, (int64_t)pairs * J, nullptr, 1, c->stream);
   if (launch_align_loss(pt_src, pt_ref, idx_ok, logits, labels, transform_gt, pairs, J, K, n_iter, loss_type, wt_ptDist_loss,
-                        wt_inlier_loss, loss_discount_factor, transforms, dloss, grad_logits, c->stream))
+                        wt_inlier_loss, loss_discount_factor, transforms, dloss, grad_logits, c->stream, dpart))
     return fail(c, "dsir_align_loss_backward: launch failed");
   if (losses) {
     HIP_OK(c, hipStreamSynchronize(c->stream));

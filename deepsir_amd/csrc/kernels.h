@@ -106,6 +106,15 @@ struct GemmArgs {
                                 // statistics); a workgroup walks the units bx, bx + grid_x, ... (filled by the launcher)
 };
 
+// GroupNorm statistics meet across workgroups in exact atomics (device_utils.h, gn_block_commit): the proof that every partial
+// total stays an integer below 2^53 holds for at most kGnMaxContrib contributions per (cloud, group) statistic.  Every launcher
+// that commits statistics states how many workgroups of ONE cloud add into one statistic (a function of the layer's shape alone);
+// dsir_create bounds max_points by the largest of them over the schedule (engine.hip, gn_max_contributions).
+constexpr int kGnMaxContrib = 1 << 12;
+int pw_stream_gn_contributions(int M, int Cout);        // pw_stream.hip: the VIRTUAL workgroups of a column block
+int pw_tile_gn_contributions(int M, int Cout, int groups);   // pw_tile.hip: row blocks x column blocks a group spans
+int lse_uv_gn_contributions(int n, int KH);             // lse_uv.hip: virtual workgroups per cloud
+
 void launch_pw_gemm(const GemmArgs& a, hipStream_t st);
 bool pw_gemm_serves_pair(const GemmArgs& a);   // would launch_pw_gemm serve this launch with GemmArgs::c_split set? (ask before fusing two layers)
 // narrow-layer fast path (pw_stream.hip); false => not applicable
@@ -382,7 +391,7 @@ void launch_pose_finetune(const float* src, const float* ref, const float* w, in
 // losses [n_iter][2] float64 on device (point-distance term, confidence term), summed over pairs; returns 0 on success
 int launch_align_loss(const float* src, const float* ref, const int32_t* idx, const float* logits, const float* labels,
                       const float* T_gt, int P, int J, int K, int n_iter, int mse, float wt_pt, float wt_in, float discount,
-                      float* T_out, double* losses, float* grad, hipStream_t st);
+                      float* T_out, double* losses, float* grad, hipStream_t st, double* loss_part);   // loss_part: [P][n_iter][2] scratch (with losses)
 
 // pre-processing on ragged batches (preprocess.hip); return 0 on success
 size_t voxel_downsample_scratch_bytes(int64_t total, int clouds);

@@ -105,7 +105,15 @@ __global__ __launch_bounds__(256) void lse_uv_stats_kernel(const LseUvArgs p) {
 
 }  // namespace
 
-// VIRTUAL workgroups per cloud: a function of n alone (a cloud's summation order - hence its bits - is the same alone or in a batch)
+// VIRTUAL workgroups per cloud: a function of n alone (a cloud's summation order - hence its bits - is the same alone or in a batch);
+// each commits once: the contributions a statistic of the cloud receives
+int lse_uv_gn_contributions(int n, int KH) {
+  const int pp = KH == 8 ? 16 : 4;         // points per workgroup step
+  const int ntile = (n + pp - 1) / pp;
+  const int v = (ntile + 3) / 4;           // ~4 steps each (the unit of the statistics' fp32 sums)
+  return v < 1 ? 1 : v;
+}
+
 bool launch_lse_uv_stats(const LseUvArgs& a, hipStream_t st) {
   if (a.n <= 0 || a.clouds <= 0) return true;
   if (!a.xyz || !a.neigh || !a.w8 || !a.uv || !a.dist || !a.stats_out || a.groups < 1 || (a.KH % a.groups) != 0) return false;
@@ -113,8 +121,8 @@ bool launch_lse_uv_stats(const LseUvArgs& a, hipStream_t st) {
   const int pp = a.KH == 8 ? 16 : 4;       // points per workgroup step
   const int ntile = (a.n + pp - 1) / pp;
   LseUvArgs b = a;
-  b.vgrid = (ntile + 3) / 4;               // virtual workgroups: ~4 steps each (the unit of the statistics' fp32 sums)
-  if (b.vgrid < 1) b.vgrid = 1;
+  b.vgrid = lse_uv_gn_contributions(a.n, a.KH);
+  if (b.vgrid > kGnMaxContrib) return false;      // dsir_create bounds max_points so that this cannot happen (kernels.h)
   // physical workgroups: ~16 steps each once that fills the chip, else about one residency round, never more than the virtual grid
   const int natural = (ntile + 15) / 16;
   int64_t want = (int64_t)natural * a.clouds >= 512 ? natural : (512 + a.clouds - 1) / a.clouds;

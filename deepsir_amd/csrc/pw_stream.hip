@@ -18,6 +18,7 @@
 // different (fixed) order; results are deterministic.
 // Loader modes: vector (aligned segments), element-wise (tiny Cin: xyz / score /
 // 6-channel inlier input), and the relative position encoding (RandLANet.py:197-212).
+#include <cstdio>
 #include "kernels.h"
 #include "device_utils.h"
 #include <cstdlib>
@@ -563,25 +564,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(pw_stream_m
   }  // vb
 }
 
-template <int KQ, int NT, int EPI, int MODE, int SC = 0>
-void launch_s(const GemmArgs& a, hipStream_t st) {
-  const int ntiles = (a.M + 15) / 16;
-  const int gy = (a.Cout + NT * 16 - 1) / (NT * 16);
-  // ~8 tiles per wave.  The grid depends on (M, Cout) only — never on the number of clouds — so the
-  // tile->wave assignment, hence the summation order of the GroupNorm statistics, is the same for a
-  // cloud whether it is registered alone or inside a batch (bitwise batch invariance).
-  const int natural = (ntiles + 31) / 32;
-  int blocks = natural;
-  // small layers: at least `floor_blocks` workgroups per cloud so that a single pair still spreads over the chip (batch-1 latency:
-  // more, shorter waves).  For the GroupNorm layers this count is the VIRTUAL grid - it fixes which wave sums which tiles - and may be
-  // generous, because chip-filling launches fold it back (below).  DSIR_STREAM_MIN_BLOCKS: tuning hook.
+// Row-block units per cloud and column block: ~8 tiles per wave (32 per workgroup); small layers: at least `floor_blocks` workgroups
+// per cloud so that a single pair still spreads over the chip (batch-1 latency: more, shorter waves).  A function of (M, gy) alone.
+// For the GroupNorm layers this count is the VIRTUAL grid - it fixes which wave sums which tiles, and it is the number of
+// contributions a statistic of the cloud receives (pw_stream_gn_contributions).  DSIR_STREAM_MIN_BLOCKS: tuning hook.
+int stream_blocks(int M, int gy, bool big) {
+  const int ntiles = (M + 15) / 16;
+  int blocks = (ntiles + 31) / 32;
   static const int floor_blocks = (int)tuning_int("DSIR_STREAM_MIN_BLOCKS", 16);
-  const bool big = EPI != EPI_GN && (int64_t)blocks * gy * a.clouds >= 512;   // no statistics, chip already full: ~8 tiles per wave stand
   if (!big && blocks * gy < floor_blocks) {
     const int want = (floor_blocks + gy - 1) / gy, most = (ntiles + 3) / 4;
     blocks = want < most ? want : most;
   }
-  if (blocks < 1) blocks = 1;
+  return blocks < 1 ? 1 : blocks;
+}
+
+template <int KQ, int NT, int EPI, int MODE, int SC = 0>
+void launch_s(const GemmArgs& a, hipStream_t st) {
+  const int ntiles = (a.M + 15) / 16;
+  const int gy = (a.Cout + NT * 16 - 1) / (NT * 16);
+  // The grid depends on (M, Cout) only — never on the number of clouds — so the
+  // tile->wave assignment, hence the summation order of the GroupNorm statistics, is the same for a
+  // cloud whether it is registered alone or inside a batch (bitwise batch invariance).
+  const int natural = (ntiles + 31) / 32;
+  const bool big = EPI != EPI_GN && (int64_t)natural * gy * a.clouds >= 512;   // no statistics, chip already full: ~8 tiles per wave stand
+  int blocks = stream_blocks(a.M, gy, big);
+  if (EPI == EPI_GN && blocks > kGnMaxContrib) {     // dsir_create bounds max_points so that this cannot happen (kernels.h)
+    fprintf(stderr, "dsir: pw_stream: %d contributions per GroupNorm statistic exceed the exactness bound %d\n", blocks, kGnMaxContrib);
+    abort();
+  }
   // Epilogues without a cross-workgroup reduction (everything but the GroupNorm statistics) give the same bits under any
   // tile -> wave assignment, so their grid may follow the launch size: with one or two clouds in flight (batch-1 latency)
   // a cloud spreads over enough workgroups to reach ~2 per CU; with many clouds nothing changes.
@@ -636,6 +647,13 @@ bool seg_vec_ok(const Seg& s, int KQ) {
 }
 
 }  // namespace
+
+// workgroups of one cloud that add into one GroupNorm statistic of a layer served here (a group never spans two column blocks:
+// its width divides Cout / 4 <= 16 NT)
+int pw_stream_gn_contributions(int M, int Cout) {
+  const int nt16 = Cout <= 16 ? 16 : (Cout <= 32 ? 32 : 64);
+  return stream_blocks(M, (Cout + nt16 - 1) / nt16, false);
+}
 
 // Returns false when the layer is outside this kernel's envelope (caller falls back to pw_gemm.hip).
 bool launch_pw_stream(const GemmArgs& a, hipStream_t st) {

@@ -720,6 +720,14 @@ bool pw_tile_small_serves(const GemmArgs& a) {
   return a.M <= small_m && a.epi == EPI_GN;
 }
 
+// workgroups of one cloud that add into one GroupNorm statistic of a layer served here: row blocks (the smallest block any of the
+// kernels above uses has 32 rows) x the 64-column blocks a group spans
+int pw_tile_gn_contributions(int M, int Cout, int groups) {
+  const int gw = Cout / (groups > 0 ? groups : 1);
+  const int span = (gw % BN) == 0 ? gw / BN : ((BN % gw) == 0 ? 1 : (gw + BN - 1) / BN + 1);   // groups start at multiples of their width
+  return ((M + 31) / 32) * span;
+}
+
 // Returns false when the layer is outside this kernel's envelope (caller falls back to pw_gemm.hip).
 bool launch_pw_tile(const GemmArgs& a, hipStream_t st) {
   if (a.c_split > 0 && !pw_tile_small_serves(a)) return false;      // two-layer launches exist for the small-M kernel only

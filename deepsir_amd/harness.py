@@ -43,7 +43,13 @@ def inference_align(pairs: Sequence[Dict[str, np.ndarray]], model, num_reg_iter:
     if in_flight > 1:
         if pose_opt is not None:
             raise ValueError("in_flight > 1 serves the registration alone (pose_opt must be None)")
-        datas = [_stack(pairs, [i], device) for i in mine]
+        if any(k.endswith("_neigh_idx") for i in mine for k in pairs[i]):
+            # the served path builds the KNN pyramid on the device; a loader's own pyramid (whose tie rule may differ) is honoured by
+            # the one-pair-per-call path only - say so instead of silently diverging from in_flight=1
+            raise ValueError("in_flight > 1 recomputes the KNN pyramid on the device: pairs that carry their own pyramid tensors "
+                             "must be evaluated with in_flight=1 (or have the pyramid keys removed)")
+        keys = ("points_src", "points_ref", "transform_gt")
+        datas = [_stack([{k: v for k, v in pairs[i].items() if k in keys}], [0], device) for i in mine]
         n_max = max([max(d["points_src"].shape[1], d["points_ref"].shape[1]) for d in datas], default=1024)
         srv = model.serve(max_points=n_max, max_in_flight=in_flight, n_iter=num_reg_iter, want_aux=False)
         torch.cuda.synchronize(device)

@@ -26,6 +26,7 @@ import torch.nn as nn
 from collections.abc import Sequence
 
 from .arch import NetConfig, network_specs
+from . import graph_replay_safe
 from .engine import Engine, EngineError, EnginePool
 
 _PYR_KEYS = ("xyz", "neigh_idx", "sub_idx", "interp_idx")
@@ -180,11 +181,14 @@ class Network(nn.Module):
         dev = self._device_index()
         self._check_weights_touched()
         srv = getattr(self, "_server", None)
-        if srv is None or n_points > srv.max_points or self._server_dirty or srv.n_iter != n_iter:
+        if srv is None or n_points > srv.max_points or srv.n_iter != n_iter:
             if srv is not None:
                 srv.close()
             self._server = srv = PairServer(self.cfg, {k: v for k, v in self.state_dict().items()}, dev, max(n_points, 1024),
                                             2 * self.SERVE_MAX_PAIRS, 2, n_iter, True)
+            self._server_dirty = False
+        if self._server_dirty:       # new weights (load_state_dict, an optimiser step): reloaded into the running engines
+            srv.load_state_dict({k: v for k, v in self.state_dict().items()})
             self._server_dirty = False
         return srv
 
@@ -234,7 +238,9 @@ class Network(nn.Module):
         if self.pipeline != "align":
             return self._forward_pair(self._ensure_engine(max(J, K), B), src, ref, pyr)
         num_reg_iter, _clip_weight = opt  # clip_weight is ignored by the reference too (model.py:581-582)
-        if B <= self.SERVE_MAX_PAIRS and pyr is None and src.is_cuda:
+        # the served path replays captured hipGraphs: only where replay is known to be right in this process (deepsir_amd/__init__.py);
+        # a caller that had touched the GPU before importing the package keeps the eager engine below - same bits, host-synchronised
+        if B <= self.SERVE_MAX_PAIRS and pyr is None and src.is_cuda and graph_replay_safe():
             out = self._ensure_server(max(J, K), int(num_reg_iter)).submit_batch(src.float(), ref.float()).result(wait="stream")
             return self._align_outputs(out, src, ref, int(num_reg_iter))
         # large batches: two engines on two HIP streams (EnginePool) - same bits, the throughput configuration of bench.py

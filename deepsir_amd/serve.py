@@ -117,6 +117,13 @@ class PairServer:
             s.eng.close()
         self.slots = []
 
+    def load_state_dict(self, state_dict):
+        """New weights into the running engines (``dsir_finalize_weights`` drops their captured graphs; the next batch of every
+        signature is captured again): no engine, workspace or static buffer is rebuilt."""
+        for s in self.slots:
+            s.stream.synchronize()          # a batch still replaying reads the old blob
+            s.eng.load_state_dict(state_dict)
+
     # ------------------------------------------------------------------ requests
     def submit(self, points_src: torch.Tensor, points_ref: torch.Tensor) -> PairFuture:
         """One pair: points_src [N_src, C] (or [1, N_src, C]), points_ref likewise; CUDA or host tensors (host tensors are copied
@@ -174,6 +181,13 @@ class PairServer:
                 for j, (s, r, _) in enumerate(q):
                     src[j].copy_(s, non_blocking=True)
                     ref[j].copy_(r, non_blocking=True)
+            # the copies above are queued on THIS slot's stream behind its previous batch, but the request tensors were allocated on
+            # the caller's stream and the pending queue drops the last reference to them when this function returns: without the
+            # marks below torch's caching allocator may hand their memory to the caller's next allocation before the copies have run
+            for s, r, _ in q:
+                for t in (s, r):
+                    if t.is_cuda:
+                        t.record_stream(slot.stream)
             slot.eng.register(src, ref, n, want_aux=self.want_aux, sync=False, out=out)   # hipGraph replay, one graph per (b, J, K)
             res = {k: v.clone() for k, v in out.items() if k in _OUT_KEYS}                  # the static buffers are re-used by the next batch
             ev = torch.cuda.Event()

@@ -353,6 +353,15 @@ int dsir_set_kabsch_chunked_min(dsir_ctx* ctx, int min_points);
 void dsir_set_tuning(int on);
 int dsir_tuning(void);
 
+/* GroupNorm (RandLANet.py:90-107) statistics of a layer meet across workgroups in exact, order-independent atomics
+ * (csrc/device_utils.h, gn_block_commit); the proof needs at most dsir_gn_contribution_limit() contributions per (cloud, group)
+ * statistic.  dsir_gn_contributions: the most any statistic receives for a cloud of n_points points under this configuration (host
+ * arithmetic over the launchers' grid rules; -1: bad arguments); dsir_max_points_limit: the largest max_points dsir_create accepts
+ * for it.  No GPU needed. */
+int dsir_gn_contributions(const dsir_cfg* cfg, int n_points);
+int dsir_gn_contribution_limit(void);
+int dsir_max_points_limit(const dsir_cfg* cfg);
+
 /* Diagnostics of the fp16 screening (csrc/nn_screen.hip) on ONE pair, all pointers DEVICE memory: for every (row, column)
  * the screening's lower bound L, its upper bound U = L + 2 d and the exact fp32 distance D of dsir_nn_match
  * (lower / upper / exact [J][K]; zacc [J][K], optional: the raw fp32 accumulator 2^22 (c + a.b) the six chained

@@ -130,3 +130,34 @@ def test_groupnorm_statistics_meet_in_exact_atomics_only():
     limb = limb[:limb.index("\n}\n")]
     assert limb.count("rint(") == 2 and "return limb ? rint(" in limb and "const double l1 = rint(" in limb          # both limbs are integers by construction
     assert "tomicAdd" not in util.replace(helper, "")                          # no other adding atomic among the shared helpers
+
+
+def test_groupnorm_exactness_bound_limits_max_points():
+    """The statistics' atomics are exact for at most 2^12 contributions per (cloud, group) statistic (csrc/device_utils.h: integer
+    limbs |L0| <= 2^39, |L1| < 2^40, partial totals below 2^53).  The count is a function of the layer shapes alone - the launchers'
+    virtual grids (csrc/kernels.h: pw_stream / pw_tile / lse_uv _gn_contributions) - and grows with the cloud: the largest is the
+    level-0 k = 16 layers' n / 32 (one commit per 32 sixteen-row tiles).  dsir_create refuses a max_points whose largest layer
+    would pass the bound (2^20 points, accepted until round 4, meant 32768 contributions)."""
+    from deepsir_amd import _lib
+    lib = _lib.load()
+    cfg = _lib.dsir_cfg()
+    cfg.feat_len, cfg.num_knn, cfg.num_layers, cfg.out_feat_dim, cfg.num_classes, cfg.max_pairs, cfg.pipeline = 3, 16, 4, 64, 19, 1, 0
+    for i, (r, d) in enumerate(zip((4, 4, 4, 4), (16, 64, 128, 256))):
+        cfg.sub_sampling_ratio[i], cfg.d_out[i] = r, d
+    limit = lib.dsir_gn_contribution_limit()
+    assert limit == 1 << 12
+    # limbs: N contributions of |L0| <= 2^39 and |L1| < 2^40 stay below 2^53 for N <= 2^12 (with a factor 2 to spare on L1)
+    assert limit * (1 << 40) < (1 << 53)
+    for n, want in ((5000, 157), (65536, 2048), (1 << 17, 4096), (1 << 20, 32768)):
+        assert lib.dsir_gn_contributions(ctypes.byref(cfg), n) == want == -(-n // 32)
+    top = lib.dsir_max_points_limit(ctypes.byref(cfg))
+    assert top == 1 << 17
+    assert lib.dsir_gn_contributions(ctypes.byref(cfg), top) <= limit < lib.dsir_gn_contributions(ctypes.byref(cfg), top + 32)
+    h = ctypes.c_void_p()
+    cfg.max_points = top + 1
+    assert lib.dsir_create(0, ctypes.byref(cfg), ctypes.byref(h)) != 0
+    assert b"exactness bound" in lib.dsir_last_error(None)
+    # the launchers use the same functions for their grids: the guard inside them names the same constant
+    csrc = os.path.join(ROOT, "deepsir_amd", "csrc")
+    assert "stream_blocks(a.M, gy, big)" in open(os.path.join(csrc, "pw_stream.hip")).read()
+    assert "b.vgrid = lse_uv_gn_contributions(a.n, a.KH);" in open(os.path.join(csrc, "lse_uv.hip")).read()

@@ -146,6 +146,34 @@ def test_knn_grid_adversarial_clouds_bit_exact():
     assert np.array_equal(neigh[0, 16384:16384 + 4096].cpu().numpy(), knn(kitti[:4096], kitti[:4096], 16))
 
 
+def test_knn_pyramid_65536_points_bit_exact():
+    """C5's pyramid (65536 / 16384 / 4096 / 1024 points: three grid levels, the interpolation search through the grid, one brute-force
+    level) against the brute-force oracle, ALL four levels, neigh / sub / interp bit for bit - the other large-cloud tests feed the
+    engine's own pyramid to the oracle and would not see a wrong 16th neighbour (VERDICT r4, weak 1a).  The cloud is C5's: crop +
+    jitter + resampling WITH replacement, i.e. it holds exact duplicates (distance ties)."""
+    from deepsir_amd.arch import NetConfig
+    from deepsir_amd.synth import make_pair
+    from deepsir_amd.weights import generate_state_dict
+    from oracle.knn import knn_pyramid
+    cfg = NetConfig(feat_len=3)
+    n = 65536
+    from deepsir_amd.engine import Engine
+    eng = Engine(cfg, 0, max_points=n, max_pairs=1)
+    eng.load_state_dict(generate_state_dict(cfg, 0))
+    pts = make_pair(n, 9005, 3, "3dmatch", True)["points_src"]          # [1, n, 3]
+    xyz, neigh, sub, interp = eng.knn_pyramid(cu(pts))
+    eng.close()
+    torch.set_num_threads(max(1, min(16, torch.get_num_threads())))
+    ref = knn_pyramid(pts[0], 16, cfg.sub_sampling_ratio)
+    assert np.array_equal(xyz[0].cpu().numpy(), ref["xyz"])
+    off = 0
+    for l, nl in enumerate((65536, 16384, 4096, 1024)):
+        assert np.array_equal(neigh[0, off:off + nl].cpu().numpy(), ref["neigh_idx"][off:off + nl]), f"neigh_idx, level {l}"
+        assert np.array_equal(interp[0, off:off + nl].cpu().numpy(), ref["interp_idx"][off:off + nl]), f"interp_idx, level {l}"
+        off += nl
+    assert np.array_equal(sub[0].cpu().numpy(), ref["sub_idx"])
+
+
 def test_knn_rejects_small_cloud():
     from deepsir_amd.arch import NetConfig
     from deepsir_amd.engine import EngineError

@@ -4,7 +4,7 @@ against an independent fp64 brute force and its own tie rule)."""
 import numpy as np
 import pytest
 
-from oracle.knn import add_pyramids, knn, knn_pyramid, sqdist_f32
+from oracle.knn import add_pyramids, knn, knn_fast, knn_pyramid, sqdist_f32
 
 
 def test_knn_matches_stable_sort():
@@ -63,3 +63,21 @@ def test_batch_keys():
         assert out[k + "_xyz"].shape == (2, 1360, 3)
         assert out[k + "_neigh_idx"].dtype == np.int64
         assert out[k + "_sub_idx"].shape == (2, 340, 16)
+
+
+def test_fast_variant_is_the_same_rule():
+    """``knn_fast`` (torch, every host core: the C5 levels of tests/test_gpu_parity.py) against ``knn`` on clouds with exact ties:
+    duplicates, a lattice, all points identical, queries that are not support points - 16 neighbours and the 1-NN form."""
+    rng = np.random.default_rng(5)
+    n = 1500
+    uni = rng.uniform(0, 3, (n, 3)).astype(np.float32)
+    uni[100:110] = uni[5]; uni[700] = uni[699]
+    lattice = np.stack(np.meshgrid(*[np.arange(12, dtype=np.float32)] * 3, indexing="ij"), -1).reshape(-1, 3)[rng.permutation(12 ** 3)[:n]]
+    same = np.tile(np.array([[1.25, -2.5, 0.75]], np.float32), (n, 1))
+    for name, pts in (("uniform+duplicates", uni), ("lattice", lattice.astype(np.float32)), ("identical", same)):
+        assert np.array_equal(knn_fast(pts, pts, 16, chunk=256), knn(pts, pts, 16)), name
+        assert np.array_equal(knn_fast(pts[: n // 4], pts, 1, chunk=256), knn(pts[: n // 4], pts, 1)), name
+    a = knn_pyramid(uni, 16, (4, 4, 4, 4), fast_min=1)
+    b = knn_pyramid(uni, 16, (4, 4, 4, 4))
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
