@@ -100,6 +100,9 @@ SYMBOLS = {
     "dsir_match_timer_device": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), c_i64_p]),
     "dsir_enable_match_timer": (C.c_int, [C.c_void_p, C.c_int]),
     "dsir_enable_graph": (C.c_int, [C.c_void_p, C.c_int]),
+    "dsir_graph_stats": (C.c_int, [C.c_void_p, c_i64_p]),
+    "dsir_enable_walk": (C.c_int, [C.c_void_p, C.c_int]),
+    "dsir_walk_trace": (C.c_int, [C.c_void_p, C.c_int, c_i64_p, c_i64_p]),
     "dsir_screen_stats": (C.c_int, [C.c_void_p, C.c_int, c_i64_p]),
     "dsir_prune_stats": (C.c_int, [C.c_void_p, C.c_int, c_i64_p]),
     "dsir_set_prune_thresholds": (C.c_int, [C.c_void_p, C.c_int, C.c_int64]),

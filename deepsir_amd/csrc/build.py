@@ -9,8 +9,8 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 ROOT = os.path.dirname(PKG)
-SOURCES = ["engine.hip", "pw_gemm.hip", "pw_stream.hip", "pw_tile.hip", "att_pool.hip", "lse_uv.hip", "head_mlp.hip", "head_mlp_h.hip", "agg_chain.hip", "agg_chain_h.hip", "select.hip", "misc.hip", "knn.hip", "knn_grid.hip", "score.hip", "nn_match.hip", "nn_screen.hip", "nn_prune.hip", "kabsch.hip", "icp.hip", "finetune.hip", "align_loss.hip", "train_ops.hip", "metrics.hip", "preprocess.hip"]
-HEADERS = ["kernels.h", "device_utils.h", "svd3.h", os.path.join(ROOT, "include", "dsir.h"), os.path.join(ROOT, "include", "dsir_train.h")]
+SOURCES = ["engine.hip", "pw_gemm.hip", "pw_stream.hip", "pw_tile.hip", "walk.hip", "att_pool.hip", "lse_uv.hip", "head_mlp.hip", "head_mlp_h.hip", "agg_chain.hip", "agg_chain_h.hip", "select.hip", "misc.hip", "knn.hip", "knn_grid.hip", "score.hip", "nn_match.hip", "nn_screen.hip", "nn_prune.hip", "kabsch.hip", "icp.hip", "finetune.hip", "align_loss.hip", "train_ops.hip", "metrics.hip", "preprocess.hip"]
+HEADERS = ["kernels.h", "device_utils.h", "svd3.h", "pw_tile_body.h", "att_pool_body.h", "misc_body.h", os.path.join(ROOT, "include", "dsir.h"), os.path.join(ROOT, "include", "dsir_train.h")]
 OUT = os.path.join(PKG, "libdsir.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"),
          "-I" + HERE, "-Wall", "-Wno-unused-function", "-Wno-unused-value"]

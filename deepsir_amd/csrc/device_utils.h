@@ -34,6 +34,17 @@ __device__ __forceinline__ int xcd_contiguous(int id, int nwg) {
   return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3);
 }
 
+// LDS handed to a device body as a byte region (pw_tile_body.h, att_pool_body.h, misc_body.h): the body carves its arrays in a fixed
+// order, every piece padded to 16 bytes.  With the region a static __shared__ array of the calling kernel the addresses fold to
+// constants exactly as named __shared__ arrays would.
+constexpr size_t smem_pad(size_t bytes) { return (bytes + 15) & ~(size_t)15; }
+template <typename T>
+__device__ __forceinline__ T* smem_carve(char*& p, size_t count) {
+  T* r = reinterpret_cast<T*>(p);
+  p += smem_pad(sizeof(T) * count);
+  return r;
+}
+
 // index half of a packed (order-preserving distance bits << 32 | column) arg-min slot.  A slot still at its preset
 // (all ones: every distance of the row was NaN, nothing ever won) yields 0, never -1: consumers gather by it.
 __device__ __forceinline__ int32_t packed_index(unsigned long long p) {
@@ -114,7 +125,13 @@ __device__ __forceinline__ double gn_rstd(double var) {
   r = fma(r, fma(-0.5 * v * r, r, 0.5), r);
   return r;
 }
-__device__ __forceinline__ double gn_stat_get(const double* slot) { return fma(slot[0], 0x1p24, slot[1] * 0x1p-16); }
+// The two limbs are read with agent-scope (sc1) loads: they are produced by memory-side atomics, and inside the deep-level walker
+// (walk.hip) their producers may run in the same launch as the reader - the same pattern as polling a counter.
+__device__ __forceinline__ double gn_stat_get(const double* slot) {
+  const double l1 = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const double l0 = __hip_atomic_load(slot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return fma(l1, 0x1p24, l0 * 0x1p-16);
+}
 
 // Butterfly steps across the four 16-lane rows of a wave with the gfx950 VALU lane swaps instead of ds_bpermute
 // (no LDS round trip, no lgkmcnt wait).  v_permlane16_swap exchanges the odd rows of its first operand with the

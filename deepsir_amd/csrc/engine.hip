@@ -122,11 +122,31 @@ struct dsir_ctx {
   bool use_graph = false;
   // captured registrations, one per distinct call signature (sizes AND buffer addresses): a server that batches 1 .. K
   // single-pair requests into one call replays K graphs in turn (deepsir_amd/serve.py); the oldest is evicted beyond kMaxGraphs
-  struct Graph { std::vector<unsigned char> key; hipGraphExec_t exec; };
+  struct Graph { std::vector<unsigned char> key; hipGraphExec_t exec; void* walk_block; };   // walk_block: the graph's walker programs (device)
+  int64_t graph_nodes[4] = {0, 0, 0, 0};   // the latest captured registration: nodes in all, kernel / memset / memcpy nodes (dsir_graph_stats)
+  // ---- deep-level walker (walk.hip): the programs of one call's RandLA passes live in device memory
+  static constexpr int kWalkSlots = 12;        // programs per call (1 extractor pass or 2, up to 10 inlier passes)
+  static constexpr int kWalkClouds = 16;       // the walker serves launches of up to that many clouds
+  int walk_mode = 0;                           // 1: the deep levels of a pass as one launch (dsir_enable_walk / DSIR_WALK=1); OFF by default -
+                                               // measured slower than the launches it replaces (walk.hip, "What it measured")
+  int walk_used = 0;                           // programs of the current call
+  WalkProgram* walk_dev = nullptr;             // eager calls: device programs, filled by in-stream copies from ...
+  WalkProgram* walk_host[2] = {nullptr, nullptr};   // ... pinned staging, two sets taken in turn by consecutive calls
+  hipEvent_t walk_ev[2] = {nullptr, nullptr};  // recorded after a call's last copy from the set
+  bool walk_ev_armed[2] = {false, false};
+  int walk_set = 0;
+  unsigned* walk_ctr = nullptr;                // [kWalkSlots][kWalkClouds][kWalkCtrWords] tile queues / completion counters
+  unsigned long long* walk_trace = nullptr;    // measurement (DSIR_WALK_TRACE, dsir_walk_trace): [kWalkSlots][kWalkMaxPhases][4] device-clock stamps
+  int walk_wpc = 0;                            // tuning hook (DSIR_WALK_WPC): workgroups per cloud, 0 = by launch size
+  int walk_flags = 0;                          // tuning hook (DSIR_WALK_FLAGS): WalkProgram::flags
+  // a registration under capture: programs are collected on the host and uploaded ONCE, after the capture, into the graph's own block
+  bool capturing = false;
+  std::vector<unsigned char> cap_host;
+  WalkProgram* cap_dev = nullptr;
   std::vector<Graph> graphs;
   static constexpr size_t kMaxGraphs = 16;
   void drop_graphs() {
-    for (auto& g : graphs) hipGraphExecDestroy(g.exec);
+    for (auto& g : graphs) { hipGraphExecDestroy(g.exec); if (g.walk_block) hipFree(g.walk_block); }
     graphs.clear();
   }
   struct MatchEvents { hipEvent_t op0, op1, k0, k1; };   // whole operation / its dominant kernel alone
@@ -456,10 +476,80 @@ bool lse_uv_enabled() {
 }
 
 // ------------------------------------------------------------------ schedule helpers
+// Upload a finished walker program and launch it (walk.hip).  Eager calls: in-stream copy from pinned staging; a registration under
+// capture: collected on the host, uploaded once after the capture (dsir_register), the kernel node holds the final device address.
+int walk_flush(dsir_ctx* c, WalkProgram& P, hipStream_t st) {
+  if (P.nphases <= 0) return 0;
+  if (c->walk_used >= dsir_ctx::kWalkSlots) return fail(c, "walker: more than %d programs in one call", dsir_ctx::kWalkSlots);
+  const int slot = c->walk_used++;
+  P.ctr = c->walk_ctr + (size_t)slot * dsir_ctx::kWalkClouds * kWalkCtrWords;
+  P.trace = c->walk_trace ? c->walk_trace + (size_t)slot * kWalkMaxPhases * 4 : nullptr;
+  const size_t bytes = offsetof(WalkProgram, job) + (size_t)P.nphases * sizeof(WalkJob);
+  const WalkProgram* dev;
+  if (c->capturing) {
+    std::memcpy(c->cap_host.data() + (size_t)slot * sizeof(WalkProgram), &P, bytes);
+    dev = c->cap_dev + slot;
+  } else {
+    WalkProgram* h = c->walk_host[c->walk_set] + slot;
+    std::memcpy(reinterpret_cast<void*>(h), &P, bytes);
+    HIP_OK(c, hipMemcpyAsync(c->walk_dev + slot, h, bytes, hipMemcpyHostToDevice, st));
+    dev = c->walk_dev + slot;
+  }
+  // queues and counters of this program: part of the region a registration zeroes in its opening launch; otherwise here
+  if (!c->stats_prezeroed) HIP_OK(c, hipMemsetAsync(P.ctr, 0, sizeof(unsigned) * P.clouds * kWalkCtrWords, st));
+  launch_walk(P, dev, st);
+  P.nphases = 0;
+  return 0;
+}
+// a call that may run RandLA passes: its programs start at slot 0; eager calls take the other staging set (the previous call's copies
+// may still be queued) after making sure that set's own last copy has run
+int walk_begin_call(dsir_ctx* c) {
+  c->walk_used = 0;
+  if (c->capturing || !c->walk_dev) return 0;
+  c->walk_set ^= 1;
+  if (c->walk_ev_armed[c->walk_set]) { HIP_OK(c, hipEventSynchronize(c->walk_ev[c->walk_set])); c->walk_ev_armed[c->walk_set] = false; }
+  return 0;
+}
+int walk_end_call(dsir_ctx* c) {
+  if (c->capturing || !c->walk_dev || c->walk_used == 0) return 0;
+  HIP_OK(c, hipEventRecord(c->walk_ev[c->walk_set], c->stream));
+  c->walk_ev_armed[c->walk_set] = true;
+  return 0;
+}
+
 struct Sched {
   dsir_ctx* c;
   hipStream_t st;
   int clouds;
+  // deep-level walker: while `rec` is set, layers whose kernel the walker holds become PHASES of one launch instead of launches
+  WalkProgram* rec = nullptr;
+  int rec_wpc = 1;
+  int rec_error = 0;
+  // launch what has been recorded; recording stops when the call has no program slot left (the rest of the pass: plain launches)
+  void rec_flush() {
+    if (!rec) return;
+    if (rec->nphases > 0 && walk_flush(c, *rec, st)) rec_error = 1;
+    if (c->walk_used >= dsir_ctx::kWalkSlots) rec = nullptr;
+  }
+  // false: not recorded (no room) - the caller launches the layer itself
+  bool rec_push(const WalkJob& j) {
+    if (!rec) return false;
+    if (rec->nphases == kWalkMaxPhases) { rec_flush(); if (!rec) return false; }
+    WalkJob& d = rec->job[rec->nphases];
+    d = j;
+    d.dep = rec->nphases > 0 ? rec->nphases - 1 : -1;     // the deep half of a pass is a chain: every phase reads the one before
+    ++rec->nphases;
+    return true;
+  }
+  // a point-wise GEMM launch: a phase when recording and plannable, else (after flushing what was recorded: order) its own launch
+  void gemm(const GemmArgs& a) {
+    if (rec) {
+      WalkJob j;
+      if (walk_plan_gemm(a, &j) && rec_push(j)) return;
+      rec_flush();
+    }
+    launch_pw_gemm(a, st);
+  }
 
   double* stats_slot(int groups) {
     double* p = c->stats + c->stats_top;
@@ -497,10 +587,11 @@ struct Sched {
     if (c->ws.overflow) return y;                 // an exhausted arena hands out its base: nothing may run on it
     if ((s0.uv && !s0.x) || (s1 && s1->uv && !s1->x)) {
       // table-only rows (lse_uv.hip) exist for ONE loader, pw_stream.hip's S_UV: the generic kernels would dereference the null row base
+      rec_flush();
       if (!launch_pw_stream(a, st)) { c->sched_error = "MLP2D: no kernel took the table-only position encoding"; c->ws.overflow = true; }
       return y;
     }
-    launch_pw_gemm(a, st);
+    gemm(a);
     return y;
   }
   // mlp1 and mlp_skip of a block in ONE launch (same input; the weights one after the other, BlockW::pair_W): two outputs, two
@@ -525,7 +616,7 @@ struct Sched {
     y2.gn = GnRef{st2, w2.gamma, w2.beta, w2.groups, 1.0 / ((double)(w2.cout / w2.groups) * (double)M)};
     a.Y = y1.p; a.y_cloud_stride = (int64_t)M * w1.cout; a.stats_out = st1;
     a.Y2 = y2.p; a.y2_cloud_stride = (int64_t)M * w2.cout; a.stats_out2 = st2;
-    if (!c->ws.overflow) launch_pw_gemm(a, st);
+    if (!c->ws.overflow) gemm(a);
     return true;
   }
   // lfa.mlp1 split by linearity (lse_uv.hip): per-point tables + dist + statistics, no output rows.  uv_buf / dist_buf: caller-owned
@@ -544,6 +635,7 @@ struct Sched {
     a.xyz = xyz; a.xyz_cs = xyz_cs; a.neigh = neigh; a.neigh_cs = neigh_cs; a.w8 = w8;
     a.uv = uv; a.uv_cs = (int64_t)n * 2 * w.cout; a.dist = dist; a.dist_cs = M;
     a.stats_out = st_out; a.groups = w.groups; a.n = n; a.clouds = clouds; a.KH = w.cout;
+    rec_flush();
     if (!c->ws.overflow && !launch_lse_uv_stats(a, st)) { c->sched_error = "lse_uv: layer outside the kernel's envelope"; c->ws.overflow = true; }
     return y;
   }
@@ -560,6 +652,7 @@ struct Sched {
     a.W = w.W; a.bias = w.b; a.Cin = 10; a.Cout = w.cout; a.M = M; a.clouds = clouds; a.epi = EPI_GN;
     a.Y = y.p; a.y_cloud_stride = (int64_t)M * w.cout; a.ldy = w.cout; a.stats_out = st_out; a.groups_out = w.groups;
     split_of(a);
+    rec_flush();
     if (!c->ws.overflow) launch_pw_gemm(a, st);   // an exhausted arena hands out its base: nothing may run on it
     return y;
   }
@@ -582,7 +675,13 @@ struct Sched {
       const size_t off = (size_t)(w.fc - c->dweights);
       a.Wh = c->dweights16 + off; a.Wl = c->dweights16 + c->nweights + off; a.ldw = w.d;
       a.Y = y.p; a.y_cs = (int64_t)n * w.d; a.n = n; a.clouds = clouds;
-      if (!c->ws.overflow && launch_att_full(a, w.d / 2, st)) return y;
+      if (c->ws.overflow) return y;
+      if (rec) {
+        WalkJob j;
+        if (walk_plan_att_full(a, w.d / 2, rec_wpc, &j) && rec_push(j)) return y;
+        rec_flush();
+      }
+      if (launch_att_full(a, w.d / 2, st)) return y;
     }
     if (!enc.p && w.d >= 64) {     // table-only rows have no other consumer (lse_uv_enabled() excludes this)
       if (!c->ws.overflow) c->sched_error = "attentive pooling: no kernel took the table-only position encoding";
@@ -599,7 +698,7 @@ struct Sched {
       g.epi = EPI_LINEAR; g.Y = G; g.y_cloud_stride = (int64_t)n * w.d; g.ldy = w.d;
       if (c->ws.overflow) return y;
       split_of(g);
-      launch_pw_gemm(g, st);
+      gemm(g);
       GemmArgs a2;
       a2.amode = A_SEGS; a2.nseg = 1; a2.seg[0] = seg_of(enc);
       a2.W = w.fc + w.d / 2; a2.ldw = w.d; a2.bias = nullptr; a2.Cin = w.d / 2; a2.Cout = w.d; a2.M = n * kKnn;
@@ -608,6 +707,11 @@ struct Sched {
       a2.s2 = s2; a2.s2_mode = s2 ? s2_mode : 0; a2.s2_cloud_stride = (int64_t)n * kKnn * w.d;
       split_of(a2);
       // G's column order is the consumer's (up_fc_g): d <= 128 belongs to pw_stream.hip, d = 256 to pw_tile.hip
+      if (rec && w.d > 128) {
+        WalkJob j;
+        if (walk_plan_gemm(a2, &j) && rec_push(j)) return y;
+      }
+      rec_flush();
       if (w.d <= 128 ? launch_pw_stream(a2, st) : launch_pw_tile(a2, st)) return y;
     }
     if (att_pool_enabled() && w.d == 16 && f.C == 8 && enc.C == 8 && c->dweights16 && w.fc >= c->dweights && w.fc < c->dweights + c->nweights) {
@@ -620,6 +724,7 @@ struct Sched {
       const size_t off = (size_t)(w.fc - c->dweights);
       a.Wh = c->dweights16 + off; a.Wl = c->dweights16 + c->nweights + off; a.ldw = w.d;
       a.Y = y.p; a.y_cs = (int64_t)n * w.d; a.n = n; a.clouds = clouds;
+      rec_flush();
       if (!c->ws.overflow && launch_att_pool16(a, st)) return y;
     }
     if (!enc.p) {     // table-only rows have no other consumer (lse_uv_enabled() excludes this)
@@ -634,6 +739,7 @@ struct Sched {
     a.W = w.fc; a.bias = nullptr; a.Cin = w.d; a.Cout = w.d; a.M = n * kKnn; a.clouds = clouds; a.epi = EPI_ATT;
     a.Y = y.p; a.y_cloud_stride = (int64_t)n * w.d; a.ldy = w.d;
     split_of(a);
+    rec_flush();
     if (!c->ws.overflow) launch_pw_gemm(a, st);   // an exhausted arena hands out its base: nothing may run on it
     return y;
   }
@@ -648,6 +754,7 @@ struct Sched {
     a.Y = y.p; a.y_cloud_stride = (int64_t)M * w.cout; a.ldy = w.cout;
     a.residual = residual; a.res_cloud_stride = (int64_t)M * w.cout; a.ldres = w.cout;
     split_of(a);
+    rec_flush();
     if (!c->ws.overflow) launch_pw_gemm(a, st);   // an exhausted arena hands out its base: nothing may run on it
     return y;
   }
@@ -695,30 +802,55 @@ int randla_forward(dsir_ctx* c, const RandlaW& w, const Seg& in0, const Seg* in1
   }
 
   const int64_t xyz_cs = (int64_t)py.S * 3, neigh_cs = (int64_t)py.S * kKnn, sub_cs = (int64_t)py.S1 * kKnn, interp_cs = py.S;
+  // Deep-level walker (walk.hip): with a few clouds in flight the layers from level 1's pooling down to the decoder block of level 2
+  // run as phases of ONE launch.  Which launches become phases is decided layer by layer (Sched::gemm / att: the same kernels, the
+  // same bits); the position-encoding branch of the deep levels (lfa.mlp1, lfa.mlp2: row-streaming kernels the walker does not hold,
+  // inputs the pyramid alone) is computed ahead of the chain so that it does not cut the chain in pieces.
+  static const int walk_from = 2;                            // first level inside the walker
+  const bool walk = c->walk_mode && c->walk_dev && py.clouds <= dsir_ctx::kWalkClouds && L > walk_from &&
+                    c->walk_used < dsir_ctx::kWalkSlots;
+  WalkProgram wprog;
+  wprog.clouds = py.clouds;
+  wprog.flags = c->walk_flags;
+  wprog.wpc = c->walk_wpc > 0 ? c->walk_wpc : (py.clouds <= 8 ? 32 : 16);   // 256 workgroups: one per CU (the walker holds the widest bodies' registers)
+  const bool reuse = cache && cache->valid;
+  auto enc_of = [&](int l) {      // lfa.mlp1 of level l (RandLANet.py:176-177): per-point tables (levels 0 / 1) or the stored rows
+    const BlockW& b = w.blk[l];
+    const int n = py.nl[l];
+    const float* xyz_l = py.xyz + (int64_t)py.off[l] * 3;
+    const int32_t* nb_l = py.neigh + (int64_t)py.off[l] * kKnn;
+    const bool uvl = b.lse_w8 && lse_uv_enabled();     // this level's lfa.mlp1 rows are rebuilt from per-point tables, never stored
+    return reuse ? cache->enc[l]
+           : uvl ? s.lse_uv(b.lfa1, b.lse_w8, xyz_l, xyz_cs, nb_l, neigh_cs, n, cache ? cache->uv_buf[l] : nullptr,
+                            cache ? cache->dist_buf[l] : nullptr, cache ? cache->enc_stats[l] : nullptr)
+                 : s.mlp2d_lse(b.lfa1, xyz_l, xyz_cs, nb_l, neigh_cs, n, cache ? cache->enc_buf[l] : nullptr,
+                               cache ? cache->enc_stats[l] : nullptr);
+  };
+  auto enc2_of = [&](int l, const Act& enc) {   // lfa.mlp2 on top of it (RandLANet.py:186)
+    const BlockW& b = w.blk[l];
+    const int n = py.nl[l];
+    const int32_t* nb_l = py.neigh + (int64_t)py.off[l] * kKnn;
+    return reuse ? cache->enc2[l]
+                 : s.mlp2d(b.lfa2, Sched::seg_of(enc, enc.uv ? nb_l : nullptr, enc.uv ? neigh_cs : 0), nullptr, n * kKnn, true,
+                           cache ? cache->enc2_buf[l] : nullptr, cache ? cache->enc2_stats[l] : nullptr);
+  };
+  Act enc_pre[DSIR_MAX_LEVELS], enc2_pre[DSIR_MAX_LEVELS];
   Act x = s.mlp2d(w.pre, in0, in1, py.nl[0], true);
   std::vector<Act> skips;
   for (int l = 0; l < L; ++l) {
     const BlockW& b = w.blk[l];
     const int n = py.nl[l];
-    const float* xyz_l = py.xyz + (int64_t)py.off[l] * 3;
     const int32_t* nb_l = py.neigh + (int64_t)py.off[l] * kKnn;
     const Seg xin = Sched::seg_of(x);
     Act f, skipb;
     const bool paired = s.mlp2d_pair(b, xin, n, f, skipb);
     if (!paired) f = s.mlp2d(b.mlp1, xin, nullptr, n, true);
-    const bool reuse = cache && cache->valid;
-    const bool uvl = b.lse_w8 && lse_uv_enabled();     // this level's lfa.mlp1 rows are rebuilt from per-point tables, never stored
-    Act enc = reuse ? cache->enc[l]
-              : uvl ? s.lse_uv(b.lfa1, b.lse_w8, xyz_l, xyz_cs, nb_l, neigh_cs, n, cache ? cache->uv_buf[l] : nullptr,
-                               cache ? cache->dist_buf[l] : nullptr, cache ? cache->enc_stats[l] : nullptr)
-                    : s.mlp2d_lse(b.lfa1, xyz_l, xyz_cs, nb_l, neigh_cs, n, cache ? cache->enc_buf[l] : nullptr,
-                                  cache ? cache->enc_stats[l] : nullptr);
+    const bool ahead = walk && l >= walk_from;       // computed before the chain started (below)
+    Act enc = ahead ? enc_pre[l] : enc_of(l);
     const int s2_mode = reuse ? 2 : 1;      // iteration 0 stores the pyramid-only half of the scores, later iterations load it
     Act agg = s.att(b.att1, f, enc, nb_l, neigh_cs, n, cache ? cache->s2_buf[l][0] : nullptr, s2_mode);
     Act a1 = s.mlp2d(b.att1.mlp, Sched::seg_of(agg), nullptr, n, true);
-    Act enc2 = reuse ? cache->enc2[l]
-                     : s.mlp2d(b.lfa2, Sched::seg_of(enc, enc.uv ? nb_l : nullptr, enc.uv ? neigh_cs : 0), nullptr, n * kKnn, true,
-                               cache ? cache->enc2_buf[l] : nullptr, cache ? cache->enc2_stats[l] : nullptr);
+    Act enc2 = ahead ? enc2_pre[l] : enc2_of(l, enc);
     if (cache && !reuse) { cache->enc[l] = enc; cache->enc2[l] = enc2; }
     Act agg2 = s.att(b.att2, a1, enc2, nb_l, neigh_cs, n, cache ? cache->s2_buf[l][1] : nullptr, s2_mode);
     Act a2 = s.mlp2d(b.att2.mlp, Sched::seg_of(agg2), nullptr, n, true);
@@ -740,9 +872,20 @@ int randla_forward(dsir_ctx* c, const RandlaW& w, const Seg& in0, const Seg* in1
       launch_gather_max(enc_out.p, (int64_t)n * enc_out.C, py.sub + (int64_t)py.soff[l] * kKnn, sub_cs, samp.C, samp.rows,
                         py.clouds, samp.p, st);
     } else {
+      if (walk && l == walk_from - 1) {
+        // the chain starts with this level's pooling: first the deep levels' position-encoding branch, as launches of their own
+        for (int q = walk_from; q < L; ++q) { enc_pre[q] = enc_of(q); enc2_pre[q] = enc2_of(q, enc_pre[q]); }
+        if (c->ws.overflow) return fail(c, "workspace exhausted in randla_forward (raise max_points / max_pairs)");
+        s.rec = &wprog; s.rec_wpc = wprog.wpc;
+      }
       // deeper levels: only the pooled ("randomly sampled") rows are ever read — combine inside the pooling kernel
-      launch_gather_max_combine(mainb.p, mainb.gn, skipb.p, skipb.gn, n, py.sub + (int64_t)py.soff[l] * kKnn, sub_cs,
-                                samp.C, samp.rows, py.clouds, samp.p, st);
+      GmcArgs ga{mainb.p, mainb.gn, skipb.p, skipb.gn, n, py.sub + (int64_t)py.soff[l] * kKnn, sub_cs, samp.C, samp.rows, samp.p, 0};
+      WalkJob wj;
+      if (!(s.rec && walk_plan_gmc(ga, s.rec_wpc, &wj) && s.rec_push(wj))) {
+        s.rec_flush();
+        launch_gather_max_combine(mainb.p, mainb.gn, skipb.p, skipb.gn, n, py.sub + (int64_t)py.soff[l] * kKnn, sub_cs,
+                                  samp.C, samp.rows, py.clouds, samp.p, st);
+      }
     }
     if (l == 0) skips.push_back(enc_out);
     skips.push_back(samp);
@@ -754,8 +897,11 @@ int randla_forward(dsir_ctx* c, const RandlaW& w, const Seg& in0, const Seg* in1
     const Act& sk = skips[skips.size() - 2 - j];
     const Seg s0 = Sched::seg_of(sk);
     const Seg s1 = Sched::seg_of(x, py.interp + py.off[lvl], interp_cs);
+    if (s.rec && lvl < walk_from) { s.rec_flush(); s.rec = nullptr; }      // the chain ends with the decoder block of level walk_from
     x = s.mlp2d(w.dec[j], s0, &s1, py.nl[lvl], true);
   }
+  if (s.rec) { s.rec_flush(); s.rec = nullptr; }
+  if (s.rec_error) return 1;
   const int n0 = py.nl[0];
   bool fused = false;
   static const bool no_head = tuning_flag("DSIR_NO_HEAD");   // A/B switch
@@ -788,12 +934,12 @@ int randla_forward(dsir_ctx* c, const RandlaW& w, const Seg& in0, const Seg* in1
 }
 
 // mlp_feat (loop invariant part of Network.aggregation, model.py:218)
-float* run_mlp_feat(dsir_ctx* c, const float* feat0, int clouds, int n) {
+float* run_mlp_feat(dsir_ctx* c, const float* feat0, int clouds, int n, float* out = nullptr) {   // out: caller-owned [clouds][n][64] or the arena
   Sched s{c, c->stream, clouds};
   const NetW& w = c->net;
   Act h = s.linear(w.mlp_feat[0], plain_seg(feat0, (int64_t)n * 64, 64, 64), nullptr, n, EPI_ACT);
   h = s.linear(w.mlp_feat[1], Sched::seg_of(h), nullptr, n, EPI_ACT);
-  h = s.linear(w.mlp_feat[2], Sched::seg_of(h), nullptr, n, EPI_LINEAR);
+  h = s.linear(w.mlp_feat[2], Sched::seg_of(h), nullptr, n, EPI_LINEAR, out);
   return h.p;
 }
 // normalize(mlp_proj(F + mlp_att([xyz; score])))   (model.py:223-234)
@@ -976,6 +1122,31 @@ int dsir_create(int device, const dsir_cfg* cfg, dsir_ctx** out) {
     delete c;
     return fail(nullptr, "cannot allocate the statistics arena");
   }
+  {
+    // deep-level walker: device programs + two pinned staging sets + the tile queues / completion counters of one call's programs
+    const size_t pb = sizeof(WalkProgram) * dsir_ctx::kWalkSlots;
+    const size_t cb = sizeof(unsigned) * dsir_ctx::kWalkSlots * dsir_ctx::kWalkClouds * kWalkCtrWords;
+    bool ok = hipMalloc((void**)&c->walk_dev, pb) == hipSuccess && hipMalloc((void**)&c->walk_ctr, cb) == hipSuccess &&
+              hipMemset(c->walk_ctr, 0, cb) == hipSuccess;
+    for (int k = 0; k < 2 && ok; ++k)
+      ok = hipHostMalloc((void**)&c->walk_host[k], pb, hipHostMallocDefault) == hipSuccess &&
+           hipEventCreateWithFlags(&c->walk_ev[k], hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+      for (int k = 0; k < 2; ++k) { if (c->walk_host[k]) hipHostFree(c->walk_host[k]); if (c->walk_ev[k]) hipEventDestroy(c->walk_ev[k]); }
+      if (c->walk_dev) hipFree(c->walk_dev);
+      if (c->walk_ctr) hipFree(c->walk_ctr);
+      hipFree(c->stats); hipFree(c->ws.base); hipStreamDestroy(c->stream);
+      delete c;
+      return fail(nullptr, "cannot allocate the walker's program buffers");
+    }
+    c->walk_mode = tuning_flag("DSIR_WALK") ? 1 : 0;
+    c->walk_wpc = (int)tuning_int("DSIR_WALK_WPC", 0);
+    c->walk_flags = (int)tuning_int("DSIR_WALK_FLAGS", 0);
+    if (tuning_flag("DSIR_WALK_TRACE")) {
+      const size_t tb = sizeof(unsigned long long) * dsir_ctx::kWalkSlots * kWalkMaxPhases * 4;
+      if (hipMalloc((void**)&c->walk_trace, tb) != hipSuccess) c->walk_trace = nullptr;
+    }
+  }
   if (hipMalloc((void**)&c->screen_acc, 6 * sizeof(unsigned long long)) != hipSuccess ||
       hipMemset(c->screen_acc, 0, 6 * sizeof(unsigned long long)) != hipSuccess) {
     hipFree(c->stats); hipFree(c->ws.base); hipStreamDestroy(c->stream);
@@ -996,6 +1167,10 @@ void dsir_destroy(dsir_ctx* c) {
   if (c->dweights16) hipFree(c->dweights16);
   if (c->match_ts) hipFree(c->match_ts);
   if (c->screen_acc) hipFree(c->screen_acc);
+  for (int k = 0; k < 2; ++k) { if (c->walk_host[k]) hipHostFree(c->walk_host[k]); if (c->walk_ev[k]) hipEventDestroy(c->walk_ev[k]); }
+  if (c->walk_dev) hipFree(c->walk_dev);
+  if (c->walk_ctr) hipFree(c->walk_ctr);
+  if (c->walk_trace) hipFree(c->walk_trace);
   if (c->stats) hipFree(c->stats);
   if (c->ws.base) hipFree(c->ws.base);
   hipStreamDestroy(c->own_stream);     // a caller's stream (dsir_set_stream) is the caller's to destroy
@@ -1168,7 +1343,9 @@ int dsir_randla_forward(dsir_ctx* c, int which, const float* features, int cin, 
   if (py.nl[3] < kKnn) return fail(c, "cloud too small (n=%d)", n);
   py.xyz = xyz; py.neigh = neigh; py.sub = sub; py.interp = interp;
   const Seg in0 = plain_seg(features, (int64_t)n * cin, cin, cin);
+  if (int r = walk_begin_call(c)) return r;
   if (int r = randla_forward(c, w, in0, nullptr, py, feat, logits)) return r;
+  if (int r = walk_end_call(c)) return r;
   return post(c);
 }
 
@@ -1299,8 +1476,10 @@ struct PairStage {
   int32_t *label_s, *label_r;     // only when want_label
   float *rxyz;                    // == pr.xyz
 };
+// pre: fills / copies the caller wants done before anything else; the stage adds its own (staging the input clouds, presetting the
+// score reductions) and issues them all as ONE launch (launch_mem_ops)
 static int forward_pair_stage(dsir_ctx* c, const dsir_pair_batch* in, bool want_score, bool want_label, PairStage& S,
-                              int32_t* invalid = nullptr) {
+                              int32_t* invalid = nullptr, MemOps pre = MemOps()) {
   const dsir_cfg& g = c->cfg;
   const int P = in->pairs, J = in->n_src, K = in->n_ref, cin = g.feat_len;
   if (P < 1 || P > g.max_pairs) return fail(c, "pairs=%d outside [1,%d]", P, g.max_pairs);
@@ -1340,11 +1519,18 @@ static int forward_pair_stage(dsir_ctx* c, const dsir_pair_batch* in, bool want_
   int32_t* rneigh = pneigh + (size_t)P * ps.S * kKnn;
   int32_t* rsub = psub + (size_t)P * ps.S1 * kKnn;
   int32_t* rinterp = pinterp + (size_t)P * ps.S;
-  HIP_OK(c, hipMemcpyAsync(feats_in, in->points_src, sizeof(float) * P * J * cin, hipMemcpyDeviceToDevice, st));
-  HIP_OK(c, hipMemcpyAsync(feats_in + (size_t)P * J * cin, in->points_ref, sizeof(float) * P * K * cin, hipMemcpyDeviceToDevice, st));
+  // the score stage's reduction targets (max feature, label weight, probability per cloud) live from here on: preset to -inf below
+  float* score_red = want_score ? ws.get<float>((size_t)2 * P * 4) : nullptr;
+  if (ws.overflow) return fail(c, "workspace exhausted (raise max_points / max_pairs)");
+  pre.copy(feats_in, in->points_src, sizeof(float) * P * J * cin);
+  pre.copy(feats_in + (size_t)P * J * cin, in->points_ref, sizeof(float) * P * K * cin);
+  pre.fill(score_red, sizeof(float) * 2 * P * 4, 0xff800000u);
   if (have_py) {
-    HIP_OK(c, hipMemcpyAsync(pxyz, in->src_xyz, sizeof(float) * P * ps.S * 3, hipMemcpyDeviceToDevice, st));
-    HIP_OK(c, hipMemcpyAsync(rxyz, in->ref_xyz, sizeof(float) * P * pr.S * 3, hipMemcpyDeviceToDevice, st));
+    pre.copy(pxyz, in->src_xyz, sizeof(float) * P * ps.S * 3);
+    pre.copy(rxyz, in->ref_xyz, sizeof(float) * P * pr.S * 3);
+  }
+  launch_mem_ops(pre, st);
+  if (have_py) {
     // caller-supplied indices: copied with every entry clamped into its level's range (a bad index can never fault a
     // gather), out-of-range entries reported through bit 1 of the pair's invalid flag
     auto copy_idx = [&](const Pyramid& py, const int32_t* nb, const int32_t* sb, const int32_t* ip, int32_t* nbo, int32_t* sbo,
@@ -1375,9 +1561,9 @@ static int forward_pair_stage(dsir_ctx* c, const dsir_pair_batch* in, bool want_
     pa.clouds = 2 * P;
     if (int r = randla_forward(c, c->net.feat, plain_seg(feats_in, (int64_t)J * cin, cin, cin), nullptr, pa, feat_all, logit_all)) return r;
     if (want_score) {
-      sc.red = ws.get<float>((size_t)2 * P * 4); sc.prob = ws.get<float>((size_t)2 * P * J); sc.label = ws.get<int32_t>((size_t)2 * P * J);
+      sc.red = score_red; sc.prob = ws.get<float>((size_t)2 * P * J); sc.label = ws.get<int32_t>((size_t)2 * P * J);
       launch_score(feat_all, logit_all, g.num_classes, pxyz, (int64_t)ps.S * 3, pneigh, (int64_t)ps.S * kKnn, 2 * P, J, sc,
-                   score_all, label_all, st);
+                   score_all, label_all, st, /*red_preset=*/true);
     }
   } else {
     if (int r = randla_forward(c, c->net.feat, plain_seg(feats_in, (int64_t)J * cin, cin, cin), nullptr, ps, feat_s, logit_s)) return r;
@@ -1386,9 +1572,10 @@ static int forward_pair_stage(dsir_ctx* c, const dsir_pair_batch* in, bool want_
     ws.release(mark0);
     if (want_score) {
       const int nmax = J > K ? J : K;
-      sc.red = ws.get<float>((size_t)P * 4); sc.prob = ws.get<float>((size_t)P * nmax); sc.label = ws.get<int32_t>((size_t)P * nmax);
-      launch_score(feat_s, logit_s, g.num_classes, pxyz, (int64_t)ps.S * 3, pneigh, (int64_t)ps.S * kKnn, P, J, sc, score_s, label_s, st);
-      launch_score(feat_r, logit_r, g.num_classes, rxyz, (int64_t)pr.S * 3, rneigh, (int64_t)pr.S * kKnn, P, K, sc, score_r, label_r, st);
+      sc.red = score_red; sc.prob = ws.get<float>((size_t)P * nmax); sc.label = ws.get<int32_t>((size_t)P * nmax);
+      launch_score(feat_s, logit_s, g.num_classes, pxyz, (int64_t)ps.S * 3, pneigh, (int64_t)ps.S * kKnn, P, J, sc, score_s, label_s, st, true);
+      sc.red = score_red + (size_t)P * 4;      // the ref clouds' own targets (the src launch is still reading the first set)
+      launch_score(feat_r, logit_r, g.num_classes, rxyz, (int64_t)pr.S * 3, rneigh, (int64_t)pr.S * kKnn, P, K, sc, score_r, label_r, st, true);
     }
   }
   ws.release(mark0);
@@ -1409,19 +1596,29 @@ static int register_enqueue(dsir_ctx* c, const dsir_pair_batch* in, int n_iter, 
   hipStream_t st = c->stream;
   Arena& ws = c->ws;
   PairStage S;
-  if (out->invalid) HIP_OK(c, hipMemsetAsync(out->invalid, 0, sizeof(int32_t) * P, st));
-  // GroupNorm statistics of ALL passes of this call (feature extractor on 2 P clouds, n_iter inlier passes on P) zeroed by one
-  // memset instead of one per pass (a launch each: 22 us of a 3.6 ms single-pair registration)
+  // What opens a registration goes out as ONE launch (launch_mem_ops, issued by forward_pair_stage together with the staging of the
+  // input clouds): the pairs' flags, and the GroupNorm statistics of ALL passes of this call (feature extractor on 2 P clouds, n_iter
+  // inlier passes on P) plus those of the inlier model's cached position-encoding branch (EncCache) in one zeroed region - round 4
+  // spent six memset / memcpy launches here
+  MemOps pre;
+  pre.fill(out->invalid, sizeof(int32_t) * P);
+  if (int r = walk_begin_call(c)) return r;
   struct StatsGuard { dsir_ctx* c; ~StatsGuard() { c->stats_prezeroed = false; c->stats_base = 0; } } stats_guard{c};
+  const size_t cache_stats = (size_t)2 * g.num_layers * P * 8 * kGnWords;      // EncCache: two layers per level
+  double* cache_stats_at = nullptr;
   {
     const size_t total = (size_t)40 * 8 * kGnWords * ((size_t)2 * P + (size_t)n_iter * P);
-    if (total <= c->stats_cap) {
-      HIP_OK(c, hipMemsetAsync(c->stats, 0, total * sizeof(double), st));
+    if (total + cache_stats <= c->stats_cap) {
+      pre.fill(c->stats, (total + cache_stats) * sizeof(double));
+      // ... and the tile queues / completion counters of the deep-level walker's programs (walk.hip), one per pass
+      if (c->walk_mode && c->walk_ctr && P <= dsir_ctx::kWalkClouds)
+        pre.fill(c->walk_ctr, sizeof(unsigned) * dsir_ctx::kWalkSlots * dsir_ctx::kWalkClouds * kWalkCtrWords);
+      cache_stats_at = c->stats + total;
       c->stats_prezeroed = true;
       c->stats_base = 0;
     }
   }
-  if (int r = forward_pair_stage(c, in, true, false, S, out->invalid)) return r;
+  if (int r = forward_pair_stage(c, in, true, false, S, out->invalid, pre)) return r;
   const Pyramid& ps = S.ps; const Pyramid& pr = S.pr;
   float *feat_s = S.feat_s, *feat_r = S.feat_r, *score_s = S.score_s, *score_r = S.score_r, *rxyz = S.rxyz;
   const float* pxyz = ps.xyz;
@@ -1487,8 +1684,11 @@ static int register_enqueue(dsir_ctx* c, const dsir_pair_batch* in, int n_iter, 
       }
       nstats += 2 * (size_t)P * 8 * kGnWords;
     }
-    double* cst = ws.get<double>(nstats);
-    if (!ws.overflow) HIP_OK(c, hipMemsetAsync(cst, 0, nstats * sizeof(double), st));
+    double* cst = cache_stats_at;                  // zeroed by the opening launch
+    if (!cst || nstats > cache_stats) {            // more iterations than the statistics arena holds side by side: own storage, own memset
+      cst = ws.get<double>(nstats);
+      if (!ws.overflow) HIP_OK(c, hipMemsetAsync(cst, 0, nstats * sizeof(double), st));
+    }
     for (int l = 0; l < g.num_layers; ++l) {
       enc_cache.enc_stats[l] = cst + (size_t)(2 * l) * P * 8 * kGnWords;
       enc_cache.enc2_stats[l] = cst + (size_t)(2 * l + 1) * P * 8 * kGnWords;
@@ -1505,8 +1705,7 @@ static int register_enqueue(dsir_ctx* c, const dsir_pair_batch* in, int n_iter, 
       launch_split16_norm(desc_r, (int64_t)P * K, sc_bh, sc_bl, sc_sb, st);
     }
     if (prune && launch_prune_ref(rxyz, (int64_t)pr.S * 3, desc_r, sc_bh, sc_bl, sc_sb, P, J, K, pr_scratch, st)) return fail(c, "pruned search: sorting the ref side failed");
-    float* F_tmp = run_mlp_feat(c, feat_s, P, J);
-    HIP_OK(c, hipMemcpyAsync(F_s, F_tmp, sizeof(float) * P * J * 64, hipMemcpyDeviceToDevice, st));
+    run_mlp_feat(c, feat_s, P, J, F_s);       // straight into the storage that outlives the iterations
     ws.release(mark1);
   }
   // xyz_cur = level-0 src coordinates
@@ -1565,6 +1764,7 @@ static int register_enqueue(dsir_ctx* c, const dsir_pair_batch* in, int n_iter, 
     launch_kabsch(a, st);
   }
   if (c->ws.overflow) return fail(c, "workspace exhausted (raise max_points / max_pairs in dsir_cfg)");
+  if (int r = walk_end_call(c)) return r;
   return 0;
 }
 
@@ -1588,21 +1788,56 @@ int dsir_register(dsir_ctx* c, const dsir_pair_batch* in, int n_iter, const dsir
     if (g.key == key) { exec = g.exec; break; }
   if (!exec) {
     HIP_OK(c, hipStreamSynchronize(c->stream));
-    HIP_OK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+    // the walker programs of this registration get a device block of their own (the kernel nodes hold addresses inside it); they are
+    // collected on the host while the launches are captured and uploaded once, below
+    void* walk_block = nullptr;
+    if (c->walk_mode && c->walk_dev) {
+      HIP_OK(c, hipMalloc(&walk_block, sizeof(WalkProgram) * dsir_ctx::kWalkSlots));
+      c->cap_host.assign(sizeof(WalkProgram) * dsir_ctx::kWalkSlots, 0);
+      c->cap_dev = reinterpret_cast<WalkProgram*>(walk_block);
+    }
+    if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+      if (walk_block) hipFree(walk_block);
+      return fail(c, "hipStreamBeginCapture failed");
+    }
+    c->capturing = true;
     const int rc = register_enqueue(c, in, n_iter, out);
+    c->capturing = false;
     hipGraph_t graph = nullptr;
     const hipError_t e = hipStreamEndCapture(c->stream, &graph);
-    if (rc != 0) { if (graph) hipGraphDestroy(graph); return rc; }
-    if (e != hipSuccess || !graph) return fail(c, "hipStreamEndCapture: %s", hipGetErrorString(e));
+    if (rc != 0) { if (graph) hipGraphDestroy(graph); if (walk_block) hipFree(walk_block); return rc; }
+    if (e != hipSuccess || !graph) { if (walk_block) hipFree(walk_block); return fail(c, "hipStreamEndCapture: %s", hipGetErrorString(e)); }
+    if (walk_block && c->walk_used > 0)
+      HIP_OK(c, hipMemcpy(walk_block, c->cap_host.data(), sizeof(WalkProgram) * (size_t)c->walk_used, hipMemcpyHostToDevice));
+    c->cap_dev = nullptr;
+    {
+      // what one registration costs in launches: the node census of the captured graph (dsir_graph_stats)
+      size_t nn = 0;
+      c->graph_nodes[0] = c->graph_nodes[1] = c->graph_nodes[2] = c->graph_nodes[3] = 0;
+      if (hipGraphGetNodes(graph, nullptr, &nn) == hipSuccess && nn > 0) {
+        std::vector<hipGraphNode_t> nodes(nn);
+        if (hipGraphGetNodes(graph, nodes.data(), &nn) == hipSuccess) {
+          c->graph_nodes[0] = (int64_t)nn;
+          for (size_t i = 0; i < nn; ++i) {
+            hipGraphNodeType t;
+            if (hipGraphNodeGetType(nodes[i], &t) != hipSuccess) continue;
+            if (t == hipGraphNodeTypeKernel) ++c->graph_nodes[1];
+            else if (t == hipGraphNodeTypeMemset) ++c->graph_nodes[2];
+            else if (t == hipGraphNodeTypeMemcpy) ++c->graph_nodes[3];
+          }
+        }
+      }
+    }
     const hipError_t e2 = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
     hipGraphDestroy(graph);
-    if (e2 != hipSuccess) return fail(c, "hipGraphInstantiate: %s", hipGetErrorString(e2));
+    if (e2 != hipSuccess) { if (walk_block) hipFree(walk_block); return fail(c, "hipGraphInstantiate: %s", hipGetErrorString(e2)); }
     if (c->graphs.size() >= dsir_ctx::kMaxGraphs) {
       HIP_OK(c, hipStreamSynchronize(c->stream));     // the evicted graph may still be replaying
       hipGraphExecDestroy(c->graphs.front().exec);
+      if (c->graphs.front().walk_block) hipFree(c->graphs.front().walk_block);
       c->graphs.erase(c->graphs.begin());
     }
-    c->graphs.push_back({key, exec});
+    c->graphs.push_back({key, exec, walk_block});
   }
   HIP_OK(c, hipGraphLaunch(exec, c->stream));
   return post(c);
@@ -1674,7 +1909,9 @@ int dsir_forward_pair(dsir_ctx* c, const dsir_pair_batch* in, int num_sub, const
   }
   const bool scored = g.pipeline != DSIR_PIPELINE_LABEL;
   PairStage S;
+  if (int r = walk_begin_call(c)) return r;
   if (int r = forward_pair_stage(c, in, scored, scored, S)) return r;
+  if (int r = walk_end_call(c)) return r;
   if (int r = emit_cloud_out(c, S.ps, S.feat_s, S.logit_s, S.score_s, S.label_s, in->pairs, in->n_src, num_sub, src)) return r;
   if (int r = emit_cloud_out(c, S.pr, S.feat_r, S.logit_r, S.score_r, S.label_r, in->pairs, in->n_ref, num_sub, ref)) return r;
   return post(c);
@@ -1733,6 +1970,12 @@ int dsir_align_loss_backward(dsir_ctx* c, const float* pt_src, const float* pt_r
     HIP_OK(c, hipMemcpy(losses, dloss, sizeof(double) * 2 * n_iter, hipMemcpyDeviceToHost));
   }
   return post(c);
+}
+
+int dsir_graph_stats(dsir_ctx* c, int64_t* out) {
+  if (!c || !out) return 1;
+  for (int i = 0; i < 4; ++i) out[i] = c->graph_nodes[i];
+  return 0;
 }
 
 int dsir_enable_graph(dsir_ctx* c, int enable) {
@@ -1910,6 +2153,34 @@ int dsir_set_prune_thresholds(dsir_ctx* c, int min_points, int64_t min_rows) {
 int dsir_set_kabsch_chunked_min(dsir_ctx* c, int min_points) {
   if (!c) return 1;
   c->kabsch_chunked_min = min_points > 0 ? min_points : 0;
+  // a captured registration has the choice baked in
+  c->drop_graphs();
+  return 0;
+}
+
+int dsir_walk_trace(dsir_ctx* c, int reset, int64_t* out, int64_t* clock_khz) {
+  if (!c) return 1;
+  HIP_OK(c, hipSetDevice(c->device));
+  HIP_OK(c, hipStreamSynchronize(c->stream));
+  const size_t n = (size_t)dsir_ctx::kWalkSlots * kWalkMaxPhases * 4;
+  if (!c->walk_trace) return fail(c, "dsir_walk_trace: tracing is off (DSIR_TUNING=1 DSIR_WALK_TRACE=1 before dsir_create)");
+  if (out) HIP_OK(c, hipMemcpy(out, c->walk_trace, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  if (reset) {
+    std::vector<unsigned long long> init(n);
+    for (size_t i = 0; i < n; ++i) init[i] = (i & 3) < 2 ? ~0ull : 0ull;      // two minima, two maxima
+    HIP_OK(c, hipMemcpy(c->walk_trace, init.data(), n * sizeof(unsigned long long), hipMemcpyHostToDevice));
+  }
+  if (clock_khz) {
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device) != hipSuccess || khz <= 0) khz = 100000;
+    *clock_khz = khz;
+  }
+  return 0;
+}
+
+int dsir_enable_walk(dsir_ctx* c, int enable) {
+  if (!c) return 1;
+  c->walk_mode = enable != 0;
   // a captured registration has the choice baked in
   c->drop_graphs();
   return 0;

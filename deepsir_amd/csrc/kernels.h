@@ -227,7 +227,61 @@ void launch_gather_max(const float* in, int64_t in_cloud_stride, const int32_t* 
 void launch_gather_max_combine(const float* a, GnRef ga, const float* b, GnRef gb, int rows_in, const int32_t* idx,
                                int64_t idx_cloud_stride, int C, int rows_out, int clouds, float* out, hipStream_t st);
 
+// walk.hip - the deep pyramid levels of RandLA.forward (levels >= 2, mlp_mid, the first decoder blocks) as ONE launch.
+// With a few clouds in flight (the reference's batch of one, served batches of up to 8 pairs) those layers are ~20 dependent launches
+// of 5 - 16 us each, most of it the fixed cost of a launch (4.5 - 5 us per dependent kernel node of a replayed graph, measured:
+// profiles/README.md round 5).  The walker runs the same tile bodies (pw_tile_body.h, att_pool_body.h, misc_body.h) as PHASES of one
+// persistent launch: a phase is a set of independent workgroup tiles per cloud; the workgroups of a cloud take tiles from the
+// phase's queue (one returning atomic each - no workgroup ever waits for one that is not running) and start phase p when every
+// tile of phase p - 1 has been published (plain stores -> s_waitcnt -> barrier -> agent-scope release fence -> counter add;
+// consumer: relaxed poll -> agent-scope acquire fence -> barrier): 1.0 - 1.4 us per hand-off (tools/ubench/xcd_sync.hip).
+// Same code on the same operands in the same order per output element, GroupNorm statistics in exact atomics: same bits as the
+// separate launches.
+struct GmcArgs {            // launch_gather_max_combine's operands
+  const float* a; GnRef ga; const float* b; GnRef gb; int rows_in; const int32_t* idx; int64_t idx_cs; int C, rows_out; float* out; int bpc;
+};
+enum WalkKind { WK_TILE_SMALL = 0, WK_TILE_ATT2 = 1, WK_ATT_FULL64 = 2, WK_GMC = 3 };
+struct WalkJob {            // one phase
+  int kind = 0;
+  int v0 = 0, v1 = 0;       // WK_TILE_SMALL: RTS (1 | 2), epilogue (EPI_GN | EPI_LINEAR); WK_TILE_ATT2: RT (1 | 2), GemmArgs::s2_mode
+  int gx = 1, gy = 1;       // gx * gy tiles per cloud; tile j = (bx = j % gx, by = j / gx)
+  int dep = -1;             // the phase whose tiles must all be published before a tile of this one starts (-1: none)
+  GemmArgs gemm;
+  AttPool16Args att;
+  GmcArgs gmc = {};
+};
+constexpr int kWalkMaxPhases = 32;
+constexpr int kWalkCtrWords = 2 * kWalkMaxPhases + 2;      // per cloud: {next, done} per phase, then {error flag, pad}
+struct WalkProgram {
+  int nphases = 0, clouds = 0, wpc = 1;    // wpc: workgroups per cloud
+  int flags = 0;                           // bit 0: a cloud's workgroups are blockIdx % clouds (all XCDs) instead of one XCD slot; bit 1: no program prefetch
+  unsigned* ctr = nullptr;                 // [clouds][kWalkCtrWords], zero before the launch
+  unsigned long long* trace = nullptr;     // measurement (DSIR_WALK_TRACE): [kWalkMaxPhases][4] device-clock stamps of cloud 0 - earliest tile
+                                           // picked up, earliest tile past its wait, latest body end, latest publish - preset to ~0 / 0
+  WalkJob job[kWalkMaxPhases];
+};
+// can these launches be phases?  (the same predicates the stand-alone launchers apply, plus the instantiations walk.hip holds)
+bool walk_plan_gemm(const GemmArgs& a, WalkJob* out);      // pw_tile.hip: the small-M GroupNorm / linear kernels, split attentive pooling
+bool walk_plan_att_full(const AttPool16Args& a, int KH, int wpc, WalkJob* out);      // att_pool.hip (KH = 64); wpc: workgroups a cloud will have
+bool walk_plan_gmc(const GmcArgs& a, int wpc, WalkJob* out);                         // misc.hip
+// prog: DEVICE copy of the program (host copy for the grid geometry)
+void launch_walk(const WalkProgram& host, const WalkProgram* prog, hipStream_t st);
+
 void launch_narrow_i64(const int64_t* src, int32_t* dst, int64_t n, hipStream_t st);
+
+// Several device fills / copies in ONE launch (misc.hip): what opens a registration - zeroing flags and the statistics arena,
+// staging the two input clouds side by side, presetting reduction targets - was six memset / memcpy launches (round 4).
+// Sizes and addresses are multiples of 4 bytes; 16-byte accesses where an operation is aligned for them.
+struct MemOp { void* dst; const void* src; size_t bytes; uint32_t fill; };     // src == nullptr: every 32-bit word = fill
+struct MemOps {
+  static constexpr int kMax = 10;
+  int n = 0;
+  MemOp op[kMax];
+  void fill(void* dst, size_t bytes, uint32_t word = 0) { if (dst && bytes) op[n++] = MemOp{dst, nullptr, bytes, word}; }
+  void copy(void* dst, const void* src, size_t bytes) { if (dst && src && bytes) op[n++] = MemOp{dst, src, bytes, 0u}; }
+  bool full() const { return n >= kMax; }
+};
+void launch_mem_ops(const MemOps& m, hipStream_t st);    // no-op when m.n == 0
 
 // Caller-supplied index tensors are copied with every entry clamped into its valid range (no gather can leave its
 // tensor); an out-of-range entry raises bit 1 (value 2) of flag[cloud % flag_mod] (flag may be nullptr).
@@ -275,9 +329,10 @@ struct ScoreScratch {  // per cloud: [0]=max feat, [1]=max label weight, [2]=max
   float* prob;         // [clouds][n]
   int32_t* label;      // [clouds][n]
 };
+// red_preset: s.red already holds -inf in every word (a registration presets it in its opening launch_mem_ops)
 void launch_score(const float* feat, const float* logits, int ncls, const float* xyz, int64_t xyz_cloud_stride,
                   const int32_t* neigh, int64_t neigh_cloud_stride, int clouds, int n, ScoreScratch s, float* score,
-                  int32_t* label_out, hipStream_t st);
+                  int32_t* label_out, hipStream_t st, bool red_preset = false);
 
 // fused distance GEMM + row arg-min (matchnet.py:96-113 + model.py:566); ev0/ev1 (optional) bracket the main kernel
 size_t nn_match_scratch_bytes(int pairs, int J, int K);

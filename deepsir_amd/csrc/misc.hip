@@ -1,24 +1,13 @@
 // Element-wise / gather helpers of the RandLA encoder.
 #include "kernels.h"
 #include "device_utils.h"
+#include "misc_body.h"
 
 namespace dsir {
 
 namespace {
 
-__device__ __forceinline__ void gn_scale_shift(const GnRef& g, int cloud, int c, int C, float& scale, float& shift) {
-  const int grp = c / (C / g.groups);
-  const double* st = g.stats + ((int64_t)cloud * g.groups + grp) * kGnWords;
-  const double mean = gn_stat_get(st) * g.inv_count;
-  double var = gn_stat_get(st + 2) * g.inv_count - mean * mean;
-  var = var > 0.0 ? var : 0.0;
-  const double rstd = gn_rstd(var);
-  const double sc = (double)g.gamma[c] * rstd;
-  scale = (float)sc;
-  shift = (float)((double)g.beta[c] - mean * sc);
-}
-
-__device__ __forceinline__ float lrelu(float v) { return v < 0.f ? 0.2f * v : v; }
+using namespace miscb;
 
 // y = LeakyReLU(GN(a) + GN(b)) ; one thread per 4 channels (16-byte accesses), channels fastest (coalesced).
 // C is a multiple of 4 (32..512) and every tensor base is 16-byte aligned (arena allocations).
@@ -79,59 +68,16 @@ __global__ __launch_bounds__(256) void gather_max_kernel(const float* __restrict
   }
 }
 
-// Same pooling with the residual combine fused in: the block output LeakyReLU(GN(a) + GN(b)) is evaluated on
-// the fly for the 16 pooled neighbours and never materialised (levels >= 1, where nothing else reads it).
+// Same pooling with the residual combine fused in (body: misc_body.h, shared with the deep-level walker): the block output
+// LeakyReLU(GN(a) + GN(b)) is evaluated on the fly for the 16 pooled neighbours and never materialised (levels >= 1).
 __global__ __launch_bounds__(256) void gather_max_combine_kernel(const float* __restrict__ a, GnRef ga,
                                                                  const float* __restrict__ b, GnRef gb, int rows_in,
                                                                  const int32_t* __restrict__ idx, int64_t idx_cs, int C,
                                                                  int rows_out, float* __restrict__ out, int bpc) {
-  __shared__ float sa[512], ha[512], sb[512], hb[512];
+  __shared__ __attribute__((aligned(16))) char smem[gmc_smem_bytes()];
   // 1-D grid of bpc workgroups per cloud, XCD-aware: a cloud's workgroups share one L2 (every input row is gathered ~4 times)
   const int wi = xcd_contiguous(blockIdx.x, gridDim.x);
-  const int cloud = wi / bpc, bx = wi % bpc;
-  const int C4 = C >> 2;
-  const int64_t total4 = (int64_t)rows_out * C4;
-  const float* pa = a + (int64_t)cloud * rows_in * C;
-  const float* pb = b + (int64_t)cloud * rows_in * C;
-  float4* o4 = reinterpret_cast<float4*>(out + (int64_t)cloud * rows_out * C);
-  // the first element's neighbour list is fetched before the statistics chain that opens the workgroup, every next one during
-  // the current element's gathers (index -> row is a dependent pair of loads)
-  const int64_t e0 = (int64_t)bx * blockDim.x + threadIdx.x, estep = (int64_t)bpc * blockDim.x;
-  int nbn[kKnn];
-  {
-    const int4* ip = reinterpret_cast<const int4*>(idx + cloud * idx_cs + (int64_t)(int)(min(e0, total4 - 1) / C4) * kKnn);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) { const int4 v = ip[q]; nbn[4 * q] = v.x; nbn[4 * q + 1] = v.y; nbn[4 * q + 2] = v.z; nbn[4 * q + 3] = v.w; }
-  }
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    gn_scale_shift(ga, cloud, c, C, sa[c], ha[c]);
-    gn_scale_shift(gb, cloud, c, C, sb[c], hb[c]);
-  }
-  __syncthreads();
-  for (int64_t e = e0; e < total4; e += estep) {
-    const int c = (int)(e % C4) * 4;
-    int nb[kKnn];
-#pragma unroll
-    for (int k = 0; k < kKnn; ++k) nb[k] = nbn[k];
-    if (e + estep < total4) {
-      const int4* ip = reinterpret_cast<const int4*>(idx + cloud * idx_cs + (int64_t)(int)((e + estep) / C4) * kKnn);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) { const int4 v = ip[q]; nbn[4 * q] = v.x; nbn[4 * q + 1] = v.y; nbn[4 * q + 2] = v.z; nbn[4 * q + 3] = v.w; }
-    }
-    const float4 s1 = *reinterpret_cast<const float4*>(&sa[c]), h1 = *reinterpret_cast<const float4*>(&ha[c]);
-    const float4 s2 = *reinterpret_cast<const float4*>(&sb[c]), h2 = *reinterpret_cast<const float4*>(&hb[c]);
-    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-#pragma unroll
-    for (int k = 0; k < kKnn; ++k) {
-      const int64_t o = (int64_t)nb[k] * C + c;
-      const float4 x = *reinterpret_cast<const float4*>(pa + o), z = *reinterpret_cast<const float4*>(pb + o);
-      m.x = fmaxf(m.x, lrelu(fmaf(x.x, s1.x, h1.x) + fmaf(z.x, s2.x, h2.x)));
-      m.y = fmaxf(m.y, lrelu(fmaf(x.y, s1.y, h1.y) + fmaf(z.y, s2.y, h2.y)));
-      m.z = fmaxf(m.z, lrelu(fmaf(x.z, s1.z, h1.z) + fmaf(z.z, s2.z, h2.z)));
-      m.w = fmaxf(m.w, lrelu(fmaf(x.w, s1.w, h1.w) + fmaf(z.w, s2.w, h2.w)));
-    }
-    o4[e] = m;
-  }
+  gather_max_combine_body(a, ga, b, gb, rows_in, idx, idx_cs, C, rows_out, out, bpc, wi % bpc, wi / bpc, smem);
 }
 
 __global__ void narrow_i64_kernel(const int64_t* __restrict__ src, int32_t* __restrict__ dst, int64_t n) {
@@ -242,6 +188,47 @@ void launch_gather_max_combine(const float* a, GnRef ga, const float* b, GnRef g
   const int bpc = grid_for((int64_t)rows_out * C / 4);
   hipLaunchKernelGGL(gather_max_combine_kernel, dim3((unsigned)((int64_t)bpc * clouds)), dim3(256), 0, st, a, ga, b, gb, rows_in, idx,
                      idx_cs, C, rows_out, out, bpc);
+}
+
+// launch_gather_max_combine as a phase of the deep-level walker (walk.hip): at most wpc blocks per cloud (an element's result does not
+// depend on the cut)
+bool walk_plan_gmc(const GmcArgs& a, int wpc, WalkJob* out) {
+  if (a.rows_out <= 0 || a.C > 512 || (a.C % 4) != 0) return false;
+  int bpc = grid_for((int64_t)a.rows_out * a.C / 4);
+  if (bpc > wpc) bpc = wpc < 1 ? 1 : wpc;
+  out->kind = WK_GMC; out->v0 = out->v1 = 0;
+  out->gmc = a;
+  out->gmc.bpc = bpc;
+  out->gx = bpc; out->gy = 1;
+  return true;
+}
+
+namespace {
+// blockIdx.y = operation; a workgroup walks its operation's 16-byte (or, unaligned, 4-byte) words grid-stride
+__global__ __launch_bounds__(256) void mem_ops_kernel(const MemOps m) {
+  const MemOp o = m.op[blockIdx.y];
+  const size_t step = (size_t)gridDim.x * blockDim.x, t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool wide = ((reinterpret_cast<uintptr_t>(o.dst) | reinterpret_cast<uintptr_t>(o.src) | o.bytes) & 15) == 0;
+  if (wide) {
+    uint4* d = reinterpret_cast<uint4*>(o.dst);
+    const uint4* s = reinterpret_cast<const uint4*>(o.src);
+    const uint4 f = make_uint4(o.fill, o.fill, o.fill, o.fill);
+    for (size_t i = t0; i < o.bytes / 16; i += step) d[i] = s ? s[i] : f;
+  } else {
+    uint32_t* d = reinterpret_cast<uint32_t*>(o.dst);
+    const uint32_t* s = reinterpret_cast<const uint32_t*>(o.src);
+    for (size_t i = t0; i < o.bytes / 4; i += step) d[i] = s ? s[i] : o.fill;
+  }
+}
+}  // namespace
+
+void launch_mem_ops(const MemOps& m, hipStream_t st) {
+  if (m.n <= 0) return;
+  size_t most = 0;
+  for (int i = 0; i < m.n; ++i) most = m.op[i].bytes > most ? m.op[i].bytes : most;
+  size_t gx = (most / 16 + 255) / 256;          // one 16-byte word per thread up to 1024 workgroups per operation, grid-stride beyond
+  gx = gx < 1 ? 1 : (gx > 1024 ? 1024 : gx);
+  hipLaunchKernelGGL(mem_ops_kernel, dim3((unsigned)gx, (unsigned)m.n), dim3(256), 0, st, m);
 }
 
 void launch_narrow_i64(const int64_t* src, int32_t* dst, int64_t n, hipStream_t st) {

@@ -132,8 +132,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void s
 
 void launch_score(const float* feat, const float* logits, int ncls, const float* xyz, int64_t xyz_cs,
                   const int32_t* neigh, int64_t neigh_cs, int clouds, int n, ScoreScratch s, float* score,
-                  int32_t* label_out, hipStream_t st) {
-  hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(s.red), 0xff800000u, (size_t)clouds * 4, st);  // -inf
+                  int32_t* label_out, hipStream_t st, bool red_preset) {
+  if (!red_preset) hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(s.red), 0xff800000u, (size_t)clouds * 4, st);  // -inf
   int gx = (n + 255) / 256;
   if (gx > 256) gx = 256;
   hipLaunchKernelGGL(score_reduce_kernel, dim3(gx, clouds), dim3(256), 0, st, feat, logits, ncls, n, s);

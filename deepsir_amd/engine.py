@@ -490,6 +490,17 @@ class Engine:
                                   "import deepsir_amd before creating CUDA tensors, or export the variable")
         self._call(self.lib.dsir_enable_graph(self.h, 1 if on else 0))
 
+    def graph_stats(self) -> Dict[str, int]:
+        """Launch census of the registration this engine captured last (include/dsir.h, dsir_graph_stats)."""
+        out = (C.c_int64 * 4)()
+        self._call(self.lib.dsir_graph_stats(self.h, out))
+        return {"nodes": int(out[0]), "kernels": int(out[1]), "memsets": int(out[2]), "memcpys": int(out[3])}
+
+    def enable_walk(self, on=True):
+        """A/B switch: the deep pyramid levels of a RandLA pass as one persistent launch (csrc/walk.hip; up to 16 clouds per launch;
+        OFF by default - fewer launches, but measured slower) or every layer its own launch.  Same bits either way (include/dsir.h)."""
+        self._call(self.lib.dsir_enable_walk(self.h, 1 if on else 0))
+
     def enable_match_timer(self, on=True):
         self._call(self.lib.dsir_enable_match_timer(self.h, 1 if on else 0))
 

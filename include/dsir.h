@@ -293,6 +293,21 @@ int dsir_align_loss_backward(dsir_ctx* ctx, const float* pt_src, const float* pt
  * initialises): the runtime's graph packet capture replays a captured registration wrongly from its third launch on once
  * the host has waited between launches (tools/graph_replay_check.py).  The Python host sets it on import. */
 int dsir_enable_graph(dsir_ctx* ctx, int enable);
+/* Launch census of the registration captured LAST by this context (dsir_enable_graph): out (HOST, 4 x i64) = graph nodes in all,
+ * kernel nodes, memset nodes, memcpy nodes - what one dsir_register call of that signature costs in launches.  Zeros before the
+ * first capture. */
+int dsir_graph_stats(dsir_ctx* ctx, int64_t* out);
+/* A/B switch (measurement / test): the deep pyramid levels of RandLA.forward (RandLANet.py:215-230, :339-359; levels 2 / 3, mlp_mid,
+ * the first two decoder blocks) as ONE persistent launch whose phases are the former launches' tiles (csrc/walk.hip), for launches of
+ * up to 16 clouds.  OFF by default: it removes 114 of a single-pair registration's 305 launches but is slower than they are (3.46 ms
+ * against 3.09 ms per registration on MI355X: a dependent launch costs ~1.5 us, a phase hand-off ~2 us, and the tile bodies' own
+ * latency chains - what the time is made of - are the same).  Same kernels' code on the same operands, statistics in exact atomics:
+ * same bits either way (tests/test_gpu_walk.py). */
+int dsir_enable_walk(dsir_ctx* ctx, int enable);
+/* Measurement: with DSIR_TUNING=1 DSIR_WALK_TRACE=1 in the environment at dsir_create the walker stamps, per program of a call
+ * (12 slots) and phase (32), the device clock of cloud 0's earliest tile picked up, earliest tile past its wait, latest tile body
+ * end and latest publish: out (HOST, 12 x 32 x 4 i64), clock_khz the clock's rate.  reset: re-arm the stamps.  Synchronises. */
+int dsir_walk_trace(dsir_ctx* ctx, int reset, int64_t* out, int64_t* clock_khz);
 
 /* Test/measurement hooks. */
 /* Wall-clock-free kernel timing of the dominant kernel (nn_match) accumulated

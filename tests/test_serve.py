@@ -91,3 +91,87 @@ def test_network_forward_small_batches_are_asynchronous_and_exact():
     assert torch.allclose(ep5["perm_matrices"][0], want["logits"][0, :1] + 0.5, atol=1e-5)
     del opt
     eng.close()
+
+
+def test_graph_replay_guard_sees_a_gpu_touched_before_the_import():
+    """a HIP call before ``import deepsir_amd`` (``torch.cuda.is_available()``, or any library calling hipGetDeviceCount)
+    initialises the HIP runtime - the ROCclr flag that makes hipGraph replay right can no longer reach it - while
+    ``torch.cuda.is_initialized()`` stays False.  The guard reads
+    /dev/kfd descriptors instead of torch's state: such a process is NOT replay-safe, ``Engine.enable_graph`` refuses, and
+    ``Network.forward`` keeps the eager engine - same bits as the served path of a process that imported the package first.
+    Also: a request whose tensors are dropped right after ``submit`` is served from intact inputs (record_stream)."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = r'''
+import sys, argparse, hashlib
+order = sys.argv[1]
+import torch
+if order == "late":
+    torch.cuda.is_available()
+    import ctypes                        # "any other library": the HIP runtime initialised behind torch's back
+    n = ctypes.c_int(0)
+    assert ctypes.CDLL("libamdhip64.so.7").hipGetDeviceCount(ctypes.byref(n)) == 0 and n.value >= 1
+    assert not torch.cuda.is_initialized()          # torch's own state does not show it
+import deepsir_amd
+safe = deepsir_amd.graph_replay_safe()
+from deepsir_amd.arch import NetConfig
+from deepsir_amd.engine import Engine, EngineError
+from deepsir_amd.model import Network
+from deepsir_amd.synth import make_batch
+from deepsir_amd.weights import generate_state_dict, to_torch_state_dict
+cfg = NetConfig(feat_len=3)
+sd = generate_state_dict(cfg, 0)
+refused = False
+eng = Engine(cfg, 0, max_points=2048, max_pairs=1)
+try:
+    eng.enable_graph(True)
+except EngineError:
+    refused = True
+eng.close()
+args = argparse.Namespace(pipeline="align", num_sub=-1, num_knn=16, out_feat_dim=64, clip_weight_thresh=0.0, feat_len=3,
+                          d_out=[16, 64, 128, 256], num_points=2048, sub_sampling_ratio=[4, 4, 4, 4], use_ppf=False, num_reg_iter=3)
+net = Network(args); net.load_state_dict(to_torch_state_dict(sd)); net = net.cuda().eval()
+b = make_batch(2048, [901, 902], 3)
+h = hashlib.sha256()
+for i in range(2):
+    for rep in range(3):                 # replays with the host waiting in between: what the broken path gets wrong from the third on
+        T, ep = net({"points_src": torch.from_numpy(b["points_src"][i:i + 1]).cuda(), "points_ref": torch.from_numpy(b["points_ref"][i:i + 1]).cuda()}, (3, True))
+        t = torch.stack(T, 1).cpu().numpy().tobytes()
+        torch.cuda.synchronize()
+    h.update(t)
+print("RESULT", int(safe), int(refused), int(net._server is not None), h.hexdigest())
+'''
+    env = {k: v for k, v in os.environ.items() if k != "DEBUG_CLR_GRAPH_PACKET_CAPTURE"}
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    got = {}
+    for order in ("early", "late"):
+        r = subprocess.run([sys.executable, "-c", code, order], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got[order] = [l for l in r.stdout.splitlines() if l.startswith("RESULT")][-1].split()[1:]
+    assert got["early"][:3] == ["1", "0", "1"], got        # safe, graph accepted, forward used the server
+    assert got["late"][:3] == ["0", "1", "0"], got         # not safe, graph refused, forward stayed eager
+    assert got["early"][3] == got["late"][3], "eager and served registrations differ"
+
+
+def test_request_tensors_may_be_dropped_right_after_submit():
+    """serve.py marks request tensors as used by the slot's stream: memory of a request freed right after ``submit`` is not handed
+    to the caller's next allocation before the queued copy has read it."""
+    from deepsir_amd.engine import Engine
+    from deepsir_amd.serve import PairServer
+    cfg, sd, src, ref, _ = _setup(6, 2048, 1200)
+    eng = Engine(cfg, 0, max_points=2048, max_pairs=1)
+    eng.load_state_dict(sd)
+    want = [eng.register(src[i:i + 1], ref[i:i + 1], 2, want_aux=False)["transforms"][0].clone() for i in range(6)]
+    srv = PairServer(cfg, sd, 0, max_points=2048, max_in_flight=2, engines=1, n_iter=2, want_aux=False)
+    futs = []
+    for i in range(6):
+        s, r = src[i].clone(), ref[i].clone()
+        futs.append(srv.submit(s, r))
+        del s, r
+        junk = [torch.full((2048, 3), float("nan"), device="cuda") for _ in range(4)]      # would land in the freed blocks
+        del junk
+    for i, f in enumerate(futs):
+        assert torch.equal(f.result()["transforms"], want[i]), i
+    srv.close(); eng.close()
