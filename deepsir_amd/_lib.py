@@ -92,6 +92,9 @@ SYMBOLS = {
     "dsir_align_loss_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                            C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p,
                                            C.POINTER(C.c_double), C.c_void_p]),
+    "dsir_align_loss_backward2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                            C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p,
+                                            C.POINTER(C.c_double), C.c_void_p, C.POINTER(C.c_double)]),
     "dsir_match_timer": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), c_i64_p]),
     "dsir_match_timer2": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), c_i64_p]),
     "dsir_enable_screen": (C.c_int, [C.c_void_p, C.c_int]),

@@ -1946,10 +1946,10 @@ int dsir_pose_finetune(dsir_ctx* c, const float* xyz_src, const float* xyz_ref, 
   return post(c);
 }
 
-int dsir_align_loss_backward(dsir_ctx* c, const float* pt_src, const float* pt_ref, const int32_t* idx, const float* logits,
+int dsir_align_loss_backward2(dsir_ctx* c, const float* pt_src, const float* pt_ref, const int32_t* idx, const float* logits,
                              const float* labels, const float* transform_gt, int pairs, int J, int K, int n_iter, int loss_type,
                              float wt_ptDist_loss, float wt_inlier_loss, float loss_discount_factor, float* transforms,
-                             double* losses, float* grad_logits) {
+                             double* losses, float* grad_logits, double* losses_per_pair) {
   if (!c) return 1;
   if (!pt_src || !pt_ref || !idx || !logits || !transform_gt || !grad_logits || pairs < 1 || J < 1 || K < 1 || n_iter < 1 ||
       n_iter > 8 || (loss_type != 0 && loss_type != 1))
@@ -1965,11 +1965,24 @@ int dsir_align_loss_backward(dsir_ctx* c, const float* pt_src, const float* pt_r
   if (launch_align_loss(pt_src, pt_ref, idx_ok, logits, labels, transform_gt, pairs, J, K, n_iter, loss_type, wt_ptDist_loss,
                         wt_inlier_loss, loss_discount_factor, transforms, dloss, grad_logits, c->stream, dpart))
     return fail(c, "dsir_align_loss_backward: launch failed");
-  if (losses) {
+  if (losses || losses_per_pair) {
     HIP_OK(c, hipStreamSynchronize(c->stream));
-    HIP_OK(c, hipMemcpy(losses, dloss, sizeof(double) * 2 * n_iter, hipMemcpyDeviceToHost));
+    if (losses) HIP_OK(c, hipMemcpy(losses, dloss, sizeof(double) * 2 * n_iter, hipMemcpyDeviceToHost));
+    if (losses_per_pair) {
+      // the kernel's per-pair partials carry the batch mean's 1 / pairs: a pair's own mean is pairs x its share
+      HIP_OK(c, hipMemcpy(losses_per_pair, dpart, sizeof(double) * 2 * n_iter * pairs, hipMemcpyDeviceToHost));
+      for (size_t k = 0; k < (size_t)2 * n_iter * pairs; ++k) losses_per_pair[k] *= (double)pairs;
+    }
   }
   return post(c);
+}
+
+int dsir_align_loss_backward(dsir_ctx* c, const float* pt_src, const float* pt_ref, const int32_t* idx, const float* logits,
+                             const float* labels, const float* transform_gt, int pairs, int J, int K, int n_iter, int loss_type,
+                             float wt_ptDist_loss, float wt_inlier_loss, float loss_discount_factor, float* transforms,
+                             double* losses, float* grad_logits) {
+  return dsir_align_loss_backward2(c, pt_src, pt_ref, idx, logits, labels, transform_gt, pairs, J, K, n_iter, loss_type, wt_ptDist_loss,
+                                   wt_inlier_loss, loss_discount_factor, transforms, losses, grad_logits, nullptr);
 }
 
 int dsir_graph_stats(dsir_ctx* c, int64_t* out) {

@@ -447,7 +447,8 @@ class Engine:
         return T, stats
 
     def align_loss_backward(self, pt_src, pt_ref, idx, logits, labels, transform_gt, loss_type: str = "mae",
-                            wt_ptDist_loss: float = 1.0, wt_inlier_loss: float = 1.0, loss_discount_factor: float = 0.5):
+                            wt_ptDist_loss: float = 1.0, wt_inlier_loss: float = 1.0, loss_discount_factor: float = 0.5,
+                            per_pair: bool = False):
         """ScanAlignmentLoss (reduction='mean') + its gradient down to the inlier logits (include/dsir.h).
         pt_src [P,J,3], pt_ref [P,K,3], idx [n,P,J] i32, logits [n,P,J], labels [n,P,J] or None, transform_gt [P,3,4]
         -> dict(losses {mae_i|mse_i, outlier_i, total}, grad_logits [n,P,J], transforms [P,n,3,4])."""
@@ -465,10 +466,11 @@ class Engine:
         T = self._empty((P, n, 3, 4))
         grad = self._empty((n, P, J))
         losses = (C.c_double * (2 * n))()
+        pp = (C.c_double * (2 * n * P))() if per_pair else None
         self._pre()
-        self._call(self.lib.dsir_align_loss_backward(self.h, _ptr(pt_src), _ptr(pt_ref), _ptr(idx), _ptr(logits), _ptr(labels),
-                                                     _ptr(transform_gt), P, J, K, n, lt, float(wt_ptDist_loss), float(wt_inlier_loss),
-                                                     float(loss_discount_factor), _ptr(T), losses, _ptr(grad)))
+        self._call(self.lib.dsir_align_loss_backward2(self.h, _ptr(pt_src), _ptr(pt_ref), _ptr(idx), _ptr(logits), _ptr(labels),
+                                                      _ptr(transform_gt), P, J, K, n, lt, float(wt_ptDist_loss), float(wt_inlier_loss),
+                                                      float(loss_discount_factor), _ptr(T), losses, _ptr(grad), pp))
         self.sync()
         d, total = {}, 0.0
         for i in range(n):
@@ -478,7 +480,19 @@ class Engine:
             if wt_inlier_loss > 0 and labels is not None:
                 d[f"outlier_{i}"] = losses[2 * i + 1]; total += disc * losses[2 * i + 1]
         d["total"] = total
-        return {"losses": d, "grad_logits": grad, "transforms": T}
+        out = {"losses": d, "grad_logits": grad, "transforms": T}
+        if per_pair:      # reduction='none' (loss.py:779, :836): every pair's own terms, [P] each
+            a = np.frombuffer(pp, dtype=np.float64).reshape(P, n, 2)
+            dd, tot = {}, np.zeros(P)
+            for i in range(n):
+                disc = loss_discount_factor ** (n - i - 1)
+                if wt_ptDist_loss > 0:
+                    dd[f"{loss_type}_{i}"] = a[:, i, 0].copy(); tot += disc * a[:, i, 0]
+                if wt_inlier_loss > 0 and labels is not None:
+                    dd[f"outlier_{i}"] = a[:, i, 1].copy(); tot += disc * a[:, i, 1]
+            dd["total"] = tot
+            out["losses_per_pair"] = dd
+        return out
 
     def enable_graph(self, on=True):
         """Replay dsir_register through a captured hipGraph (same buffers on every call; one graph per call signature)."""

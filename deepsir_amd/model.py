@@ -140,6 +140,17 @@ class Network(nn.Module):
         self._seen_version = -1
         self._server = None
         self._server_dirty = True
+        # the loss modules the reference's training loop calls (model.py:173-195; train.py:409, :421, :426): call contract restated
+        # over the HIP loss operators (deepsir_amd/autograd.py)
+        from .autograd import DetDesLoss, ScanAlignmentLoss, SemanticLoss
+        if self.pipeline == "align":
+            self.loss_align_fun = ScanAlignmentLoss(self, args)
+        elif self.pipeline == "feat":
+            self.loss_feat_fun = DetDesLoss(self, args)
+        else:
+            self.loss_label_fun = SemanticLoss(self, args)
+        self._tstate = None               # trainers of the training-mode forward (their storage IS the module's parameters)
+        self.dropout_masks = None         # test aid: {'fe_src', 'fe_ref', 'inlier'} keep flags instead of random Dropout draws
 
     # ---- checkpoint plumbing
     def load_state_dict(self, state_dict, strict: bool = True):
@@ -227,9 +238,190 @@ class Network(nn.Module):
                 endpoints[f"score_{side}"] = o["score"]                               # [B, M]
         return None, endpoints
 
+    # ---- forward in TRAINING mode (train.py:379 my_model.train(); :401): outputs with a grad_fn that leads into the parameters
+    def _training_state(self, dev: torch.device):
+        """The pipeline's trainers (deepsir_amd/train.py) over THIS module's tensors: after the first training forward a trainable
+        ``nn.Parameter`` (and every BatchNorm running statistic) is a view of its trainer's flat device buffer, so what
+        ``optimizer.step()`` writes is what the next training forward computes with - no copies either way."""
+        from . import train as T
+        st = self._tstate
+        named = dict(self.named_parameters())
+        named.update(dict(self.named_buffers()))
+        if st is not None:
+            k0, v0 = next(iter(st["main"].params.items()))
+            if st["dev"] == dev and named[k0].data_ptr() == v0.data_ptr():
+                return st
+        sd = self.state_dict()
+        if self.pipeline == "align":
+            main = T.RandlaTrainer(self.cfg, sd, "inlier_model", 6, 1, dev)
+            frozen = (T.RandlaTrainer(self.cfg, sd, "feat_extractor", self.cfg.feat_len, self.cfg.num_classes, dev), T.AggregationTrainer(self.cfg, sd, dev))
+        elif self.pipeline == "label":
+            main, frozen = T.RandlaTrainer(self.cfg, sd, "feat_extractor", self.cfg.feat_len, self.cfg.num_classes, dev), ()
+        else:
+            main = T.AggregationTrainer(self.cfg, sd, dev)
+            frozen = (T.RandlaTrainer(self.cfg, sd, "feat_extractor", self.cfg.feat_len, self.cfg.num_classes, dev),)
+        with torch.no_grad():
+            for tr in (main,) + tuple(frozen):
+                for k, v in list(tr.params.items()) + list(tr.buffers.items()):
+                    named[k].data = v.view(named[k].shape)
+        eng = Engine(self.cfg, dev.index or 0, 1024, 1)          # the weight-free operators of the training forward (score, arg-min, Kabsch, loss)
+        eng.load_state_dict({k: v for k, v in sd.items()})
+        self._tstate = st = {"dev": dev, "main": main, "frozen": frozen, "engine": eng, "names": [k for k in main.params if named[k].requires_grad]}
+        st["params"] = [named[k] for k in st["names"]]
+        return st
+
+    def _train_engine(self, st, n_points: int, pairs: int) -> Engine:
+        eng = st["engine"]
+        if n_points > eng.max_points or pairs > eng.max_pairs:
+            eng.close()
+            eng = Engine(self.cfg, st["dev"].index or 0, max(n_points, eng.max_points), max(pairs, eng.max_pairs))
+            eng.load_state_dict({k: v for k, v in self.state_dict().items()})
+            st["engine"] = eng
+        return eng
+
+    def _pyramids(self, eng: Engine, data, src, ref) -> dict:
+        batch = {"points_src": src, "points_ref": ref}
+        for s_, pts in (("src", src), ("ref", ref)):
+            if all(f"points_{s_}_{k}" in data for k in _PYR_KEYS):
+                pyr = [data[f"points_{s_}_xyz"].float()] + [data[f"points_{s_}_{k}"].to(torch.int32) for k in _PYR_KEYS[1:]]
+            else:
+                pyr = eng.knn_pyramid(pts)
+            batch[f"{s_}_xyz"], batch[f"{s_}_neigh"], batch[f"{s_}_sub"], batch[f"{s_}_interp"] = [t.contiguous() for t in pyr]
+        return batch
+
+    def _draw_masks(self, shapes: Dict[str, tuple], dev) -> Optional[dict]:
+        """Dropout(0.5) keep flags of one training forward (RandLANet.py:363-367): drawn from torch's global generator like
+        nn.Dropout's, unless the test aid ``self.dropout_masks`` supplies them."""
+        from . import train as T
+        if self.dropout_masks is not None:
+            return self.dropout_masks
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+        return {k: T.dropout_keep_masks(seed + 7919 * i, shp, dev) for i, (k, shp) in enumerate(shapes.items())}
+
+    def _forward_train(self, data: Dict[str, torch.Tensor], opt=None):
+        from . import se3
+        from . import train as T
+        from .autograd import run_taped
+        src, ref = data["points_src"].float().contiguous(), data["points_ref"].float().contiguous()
+        if not src.is_cuda:
+            raise EngineError("Network is on the CPU: this engine has no CPU path; call .to('cuda') / .cuda() first")
+        dev = src.device
+        B, J, _ = src.shape
+        K = ref.shape[1]
+        st = self._training_state(dev)
+        eng = self._train_engine(st, max(J, K), B)
+        main, frozen, params, names = st["main"], st["frozen"], st["params"], st["names"]
+        batch = self._pyramids(eng, data, src, ref)
+        self._dirty = self._pool_dirty = self._server_dirty = True      # running statistics move now, the weights at optimizer.step()
+
+        def param_grads(tr):
+            g = tr.flat_g.clone()              # ONE copy: autograd may keep what it is handed, the trainer's buffer is zeroed by the next forward
+            out = []
+            for k, p in zip(names, params):
+                v = tr.grads[k]
+                off = v.data_ptr() - tr.flat_g.data_ptr()
+                out.append(g[off // 4: off // 4 + v.numel()].view(p.shape))
+            return out
+
+        if self.pipeline == "align":
+            n_iter = int(opt[0]) if opt is not None else self.cfg.num_reg_iter
+            fe, ag = frozen
+            masks = self._draw_masks({"fe_src": (B, J, 64), "fe_ref": (B, K, 64), "inlier": (n_iter, B, J, 64)}, dev)
+            box = {}
+
+            def run():
+                main.zero_grad()
+                fw = T.forward_align_train(eng, main, fe, ag, batch, n_iter, masks)
+                box["fw"] = fw
+
+                def back(grads):
+                    g = grads[0]
+                    for it in range(n_iter):
+                        main.backward(fw["tapes"][it], g[it].contiguous(), shared=fw["shared"])
+                    main.backward_shared(fw["shared"])
+                    return param_grads(main)
+                return (fw["logits"],), back
+
+            (logits,) = run_taped(params, run, 1)
+            fw = box["fw"]
+            transforms, cum = [], None
+            for it in range(n_iter):                                   # se3_torch.concatenate(R_t, transforms[-1]), model.py:595
+                cum = fw["T"][it] if cum is None else se3.concatenate(fw["T"][it], cum)
+                transforms.append(cum.detach())
+            invalid = fw["invalid"][0]
+            for f_ in fw["invalid"][1:]:
+                invalid = invalid | f_
+            endpoints = {"pt_src": src[:, :, :3].contiguous(), "pt_ref": ref[:, :, :3].contiguous(),
+                         "perm_matrices": [logits[i] for i in range(n_iter)], "pred_pairs": _LazyPredPairs(fw["idx"]),
+                         "invalid_gradient": _LazyFlag(invalid), "pt_ref_new": fw["pt_ref_new"],
+                         "_train": {"engine": eng, "idx": fw["idx"], "logits": logits}}
+            return transforms, endpoints
+
+        if self.pipeline == "label":
+            masks = self._draw_masks({"fe_src": (B, J, 64), "fe_ref": (B, K, 64)}, dev)
+            box = {}
+
+            def run():
+                main.zero_grad()
+                outs, tapes = [], []
+                for s_ in ("src", "ref"):
+                    lg, tape = main.forward(batch[f"points_{s_}"], batch[f"{s_}_xyz"], batch[f"{s_}_neigh"], batch[f"{s_}_sub"], batch[f"{s_}_interp"],
+                                            masks.get(f"fe_{s_}"))
+                    outs.append(lg); tapes.append(tape)
+                box["tapes"] = tapes
+
+                def back(grads):
+                    for tape, g, lg in zip(tapes, grads, outs):
+                        if g is not None:
+                            main.backward(tape, g.reshape(-1, lg.shape[-1]).contiguous())
+                    return param_grads(main)
+                return tuple(outs), back
+
+            lg_s, lg_r = run_taped(params, run, 2)
+            endpoints = {}
+            for s_, lg, tape, pts in (("src", lg_s, box["tapes"][0], src), ("ref", lg_r, box["tapes"][1], ref)):
+                endpoints[f"pt_{s_}"] = pts[:, :, :3].permute(0, 2, 1).contiguous()
+                endpoints[f"feat_{s_}"] = torch.nn.functional.normalize(tape.misc["feat"].detach(), dim=2).permute(0, 2, 1).contiguous()
+                endpoints[f"logits_{s_}"] = lg.permute(0, 2, 1)
+            return None, endpoints
+
+        # feat: the frozen extractor in training mode picks the key points, the aggregation layers are taped
+        if self.cfg.num_sub <= 0:
+            raise EngineError("pipeline='feat' trains on the top-num_sub key points: set args.num_sub > 0")
+        masks = self._draw_masks({"fe_src": (B, J, 64), "fe_ref": (B, K, 64)}, dev)
+        inp = T.feat_pipeline_inputs_train(eng, frozen[0], batch, self.cfg.num_sub, masks)
+
+        def run():
+            main.zero_grad()
+            d_s, tape_s = main.forward(inp["xyz_src"], inp["feat_src"], inp["score_src"])
+            d_r, tape_r = main.forward(inp["xyz_ref"], inp["feat_ref"], inp["score_ref"])
+
+            def back(grads):
+                if grads[0] is not None:
+                    main.backward(tape_s, grads[0])
+                if grads[1] is not None:
+                    main.backward(tape_r, grads[1])
+                return param_grads(main)
+            return (d_s, d_r), back
+
+        d_s, d_r = run_taped(params, run, 2)
+        endpoints = {}
+        for s_, d in (("src", d_s), ("ref", d_r)):
+            endpoints[f"pt_{s_}"] = inp[f"xyz_{s_}"].permute(0, 2, 1).contiguous()
+            endpoints[f"feat_{s_}"] = d.permute(0, 2, 1)
+            endpoints[f"score_{s_}"] = inp[f"score_{s_}"]
+        return None, endpoints
+
     # ---- forward = forward_align_4 for 'align'
-    @torch.no_grad()
     def forward(self, data: Dict[str, torch.Tensor], opt=None):
+        """Evaluation mode (or under ``torch.no_grad()``): the inference engine.  Training mode with gradients enabled - the state the
+        reference's loop calls it in (train.py:379, :401) - the training forward on the device, outputs carrying a grad_fn."""
+        if self.training and torch.is_grad_enabled():
+            return self._forward_train(data, opt)
+        with torch.no_grad():
+            return self._forward_eval(data, opt)
+
+    def _forward_eval(self, data: Dict[str, torch.Tensor], opt=None):
         src, ref = data["points_src"], data["points_ref"]
         B, J, _ = src.shape
         K = ref.shape[1]

@@ -697,7 +697,8 @@ def forward_align_train(engine, inlier: RandlaTrainer, extractor: RandlaTrainer,
     xyz0, f_s, sc_s = side["src"]
     xyz_r, f_r, sc_r = side["ref"]
     P, J, _ = xyz0.shape
-    idxs, logits, tapes, invalid = [], [], [], []
+    idxs, logits, tapes, invalid, Ts = [], [], [], [], []
+    pt_ref_new = None
     shared: dict = {}                       # the inlier model's position-encoding branch: once per step (RandlaTrainer.forward)
     cur = xyz0
     for it in range(n_iter):
@@ -711,10 +712,12 @@ def forward_align_train(engine, inlier: RandlaTrainer, extractor: RandlaTrainer,
         lg = lg.reshape(P, J)
         T_it, bad_it = engine.kabsch(cur, cat[:, :, 3:].contiguous(), o.sigmoid(lg.contiguous()))
         invalid.append(bad_it)
+        Ts.append(T_it)
+        pt_ref_new = cat[:, :, 3:].contiguous()
         cur = o.inlier_input(cur, xyz_r, idx, T_it)[:, :, :3].contiguous()        # xyz_src <- R_t.detach() xyz_src (model.py:587)
         idxs.append(idx); logits.append(lg); tapes.append(tape)
     return {"idx": torch.stack(idxs).contiguous(), "logits": torch.stack(logits).contiguous(), "tapes": tapes, "xyz_src": xyz0,
-            "xyz_ref": xyz_r, "invalid": invalid, "shared": shared}
+            "xyz_ref": xyz_r, "invalid": invalid, "shared": shared, "T": Ts, "pt_ref_new": pt_ref_new}
 
 
 def train_step_align_full(engine, inlier: RandlaTrainer, extractor: RandlaTrainer, aggregation: "AggregationTrainer", batch: dict,

@@ -280,11 +280,17 @@ int dsir_pose_finetune(dsir_ctx* ctx, const float* xyz_src, const float* xyz_ref
  * loss_type 0 = mae, 1 = mse; wt_ptDist_loss only gates the point-distance term (> 0), as in the reference.
  * Outputs: transforms [P][n_iter][3][4] cumulative poses replayed from the logits (or NULL); losses = HOST float64
  * [n_iter][2] {mae_i | mse_i, outlier_i} (total = sum_i discount^(n_iter-1-i) (term_i + outlier_i)) or NULL;
- * grad_logits [n_iter][P][J] = d total / d logits.  n_iter <= 8. */
+ * grad_logits [n_iter][P][J] = d total / d logits.  n_iter <= 8.
+ * dsir_align_loss_backward2: the same call with one more output, losses_per_pair = HOST float64 [P][n_iter][2] or NULL: every pair's own
+ * terms as reduction='none' reports them (loss.py:779, :836: the mean over that pair's points / rows alone; validate_align, train.py:136). */
 int dsir_align_loss_backward(dsir_ctx* ctx, const float* pt_src, const float* pt_ref, const int32_t* idx, const float* logits,
                              const float* labels, const float* transform_gt, int pairs, int J, int K, int n_iter, int loss_type,
                              float wt_ptDist_loss, float wt_inlier_loss, float loss_discount_factor, float* transforms,
                              double* losses, float* grad_logits);
+int dsir_align_loss_backward2(dsir_ctx* ctx, const float* pt_src, const float* pt_ref, const int32_t* idx, const float* logits,
+                              const float* labels, const float* transform_gt, int pairs, int J, int K, int n_iter, int loss_type,
+                              float wt_ptDist_loss, float wt_inlier_loss, float loss_discount_factor, float* transforms,
+                              double* losses, float* grad_logits, double* losses_per_pair);
 
 /* Launch-bound small batches: capture the whole dsir_register launch sequence into a hipGraph once per
  * call signature (sizes and buffer addresses) and replay it; the context keeps the graphs of its 16 most recent signatures
