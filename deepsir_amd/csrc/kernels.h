@@ -210,6 +210,9 @@ void split_weights_f16(const float* w, size_t n, uint16_t* hi, uint16_t* lo);   
 size_t topk_scratch_bytes(int clouds, int n);
 // idx_out [clouds][k] = the k highest scores of every cloud, descending, ties in ascending index; score_out optional
 int launch_topk(const float* score, int clouds, int n, int k, int32_t* idx_out, float* score_out, void* scratch, hipStream_t st);
+// inverse of a gather index [clouds][m] into [clouds][n]: order [clouds * m] (sources by destination, ascending inside), offsets [clouds * n + 1]
+size_t scatter_plan_scratch_bytes(int64_t total);
+int launch_scatter_plan(const int32_t* idx, int m, int clouds, int n, int32_t* order, int32_t* offsets, void* scratch, hipStream_t st);
 void launch_gather_rows(const float* in, int64_t in_cloud_stride, int ld, const int32_t* idx, int C, int m, int clouds, float* out,
                         hipStream_t st);
 void launch_gather_i32(const int32_t* in, int64_t in_cloud_stride, const int32_t* idx, int m, int clouds, int32_t* out,

@@ -109,6 +109,58 @@ int launch_topk(const float* score, int clouds, int n, int k, int32_t* idx_out, 
   return 0;
 }
 
+namespace {
+// key = destination row of source e (cloud * n + clamped index), value = e
+__global__ __launch_bounds__(256) void plan_key_kernel(const int32_t* __restrict__ idx, int64_t total, int m, int n, uint32_t* __restrict__ key,
+                                                       uint32_t* __restrict__ val) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    int i = idx[e];
+    i = i < 0 ? 0 : (i >= n ? n - 1 : i);
+    key[e] = (uint32_t)((e / m) * n + i);
+    val[e] = (uint32_t)e;
+  }
+}
+// offsets[d] = first position of the sorted keys that is >= d, d in [0, dests]
+__global__ __launch_bounds__(256) void plan_offsets_kernel(const uint32_t* __restrict__ key, int64_t total, int64_t dests, int32_t* __restrict__ offsets) {
+  for (int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; d <= dests; d += (int64_t)gridDim.x * blockDim.x) {
+    int64_t lo = 0, hi = total;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if ((int64_t)key[mid] < d) lo = mid + 1; else hi = mid;
+    }
+    offsets[d] = (int32_t)lo;
+  }
+}
+}  // namespace
+
+// The inverse of a gather index (train_ops.hip: the backward of gather_neighbour / nearest_interpolation / random_sample is a sum
+// over the SOURCES of every destination row): order = the sources grouped by destination, ascending source inside a group (one
+// stable radix sort of (destination, source) pairs - a library sort, not the hot path), offsets = the groups' bounds.  With it the
+// backward operators sum in a fixed order instead of racing float atomics.
+size_t scatter_plan_scratch_bytes(int64_t total) {
+  size_t sort_tmp = 0;
+  hipcub::DeviceRadixSort::SortPairs(nullptr, sort_tmp, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr,
+                                     (int)total);
+  return 3 * align256((size_t)total * 4) + align256(sort_tmp);
+}
+int launch_scatter_plan(const int32_t* idx, int m, int clouds, int n, int32_t* order, int32_t* offsets, void* scratch, hipStream_t st) {
+  const int64_t total = (int64_t)clouds * m, dests = (int64_t)clouds * n;
+  if (total <= 0 || total > 0x7fffffffll || dests > 0x7fffffffll) return 1;
+  char* p = reinterpret_cast<char*>(scratch);
+  auto take = [&](size_t bytes) { char* r = p; p += align256(bytes); return r; };
+  uint32_t* k0 = reinterpret_cast<uint32_t*>(take((size_t)total * 4));
+  uint32_t* k1 = reinterpret_cast<uint32_t*>(take((size_t)total * 4));
+  uint32_t* v0 = reinterpret_cast<uint32_t*>(take((size_t)total * 4));
+  size_t sort_tmp = 0;
+  hipcub::DeviceRadixSort::SortPairs(nullptr, sort_tmp, k0, k1, v0, reinterpret_cast<uint32_t*>(order), (int)total);
+  int bits = 1;
+  while (((int64_t)1 << bits) < dests) ++bits;
+  hipLaunchKernelGGL(plan_key_kernel, dim3(grid_for(total)), dim3(256), 0, st, idx, total, m, n, k0, v0);
+  if (hipcub::DeviceRadixSort::SortPairs(p, sort_tmp, k0, k1, v0, reinterpret_cast<uint32_t*>(order), (int)total, 0, bits, st) != hipSuccess) return 2;
+  hipLaunchKernelGGL(plan_offsets_kernel, dim3(grid_for(dests + 1)), dim3(256), 0, st, k1, total, dests, offsets);
+  return 0;
+}
+
 void launch_gather_rows(const float* in, int64_t in_cloud_stride, int ld, const int32_t* idx, int C, int m, int clouds, float* out,
                         hipStream_t st) {
   hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for((int64_t)clouds * m * C)), dim3(256), 0, st, in, in_cloud_stride, ld, idx, C,

@@ -408,15 +408,16 @@ __global__ void t_gather_kernel(const float* __restrict__ X, int n, int C, const
   }
 }
 
-__global__ void t_scatter_add_kernel(const float* __restrict__ dY, int ldy, int col_off, const int32_t* __restrict__ idx, int m,
-                                     float* __restrict__ dX, int n, int C, int64_t total) {
+// backward of a gather: dX[d][c] = sum of dY over the sources of destination row d, in ascending source order (the plan of
+// launch_scatter_plan): every sum has one order - no float atomics, same bits every run
+__global__ void t_scatter_sum_kernel(const float* __restrict__ dY, int ldy, int col_off, const int32_t* __restrict__ order,
+                                     const int32_t* __restrict__ offsets, float* __restrict__ dX, int C, int64_t total) {
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
     const int c = (int)(e % C);
-    const int64_t j = e / C;
-    const int64_t cloud = j / m;
-    int i = idx[j];
-    i = i < 0 ? 0 : (i >= n ? n - 1 : i);
-    atomicAdd(dX + (cloud * n + i) * C + c, dY[j * ldy + col_off + c]);
+    const int64_t d = e / C;                 // cloud * n + i
+    float s = 0.f;
+    for (int q = offsets[d]; q < offsets[d + 1]; ++q) s += dY[(int64_t)order[q] * ldy + col_off + c];
+    dX[e] = s;
   }
 }
 
@@ -558,12 +559,22 @@ __global__ void t_maxpool_fwd_kernel(const float* __restrict__ X, int n, int C, 
   }
 }
 
-__global__ void t_maxpool_bwd_kernel(const float* __restrict__ dOut, const int32_t* __restrict__ arg, int m, int C, float* __restrict__ dX,
-                                     int n, int64_t total) {
+// backward of the max over k pooled rows: dX[i][c] = sum of dOut[j][c] over the pooled outputs j whose winner for channel c was row i,
+// walked through the inverse of the pool index in ascending (j, t) order; a row listed twice by one output counts once
+__global__ void t_maxpool_bwd_kernel(const float* __restrict__ dOut, const int32_t* __restrict__ arg, const int32_t* __restrict__ order,
+                                     const int32_t* __restrict__ offsets, int m, int k, int C, float* __restrict__ dX, int n, int64_t total) {
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
     const int c = (int)(e % C);
-    const int64_t cloud = (e / C) / m;
-    atomicAdd(dX + (cloud * n + arg[e]) * C + c, dOut[e]);
+    const int64_t d = e / C;                 // cloud * n + i
+    const int i = (int)(d % n);
+    float s = 0.f;
+    int64_t prev = -1;
+    for (int q = offsets[d]; q < offsets[d + 1]; ++q) {
+      const int64_t j = (int64_t)order[q] / k;           // cloud * m + output row
+      if (j != prev && arg[j * C + c] == i) s += dOut[j * C + c];
+      prev = j;
+    }
+    dX[e] = s;
   }
 }
 
@@ -1016,11 +1027,19 @@ int dsir_t_gather(void* stream, const float* X, int n, int C, const int32_t* idx
   return done();
 }
 
-int dsir_t_scatter_add(void* stream, const float* dY, int ldy, int col_off, const int32_t* idx, int m, int clouds, float* dX, int n,
-                       int C) {
-  if (!dY || !idx || !dX || n < 1 || C < 1 || m < 1 || clouds < 1) return (int)hipErrorInvalidValue;
-  const int64_t total = (int64_t)clouds * m * C;
-  hipLaunchKernelGGL(t_scatter_add_kernel, dim3(grid1(total)), dim3(256), 0, (hipStream_t)stream, dY, ldy, col_off, idx, m, dX, n, C, total);
+size_t dsir_t_scatter_plan_scratch(int64_t total) { return total > 0 && total <= 0x7fffffffll ? scatter_plan_scratch_bytes(total) : 0; }
+
+int dsir_t_scatter_plan(void* stream, const int32_t* idx, int m, int clouds, int n, int32_t* order, int32_t* offsets, void* scratch) {
+  if (!idx || !order || !offsets || !scratch || m < 1 || clouds < 1 || n < 1) return (int)hipErrorInvalidValue;
+  if (int r = launch_scatter_plan(idx, m, clouds, n, order, offsets, scratch, (hipStream_t)stream)) return r;
+  return done();
+}
+
+int dsir_t_scatter_add(void* stream, const float* dY, int ldy, int col_off, const int32_t* order, const int32_t* offsets, int clouds,
+                       float* dX, int n, int C) {
+  if (!dY || !order || !offsets || !dX || n < 1 || C < 1 || clouds < 1) return (int)hipErrorInvalidValue;
+  const int64_t total = (int64_t)clouds * n * C;
+  hipLaunchKernelGGL(t_scatter_sum_kernel, dim3(grid1(total)), dim3(256), 0, (hipStream_t)stream, dY, ldy, col_off, order, offsets, dX, C, total);
   return done();
 }
 
@@ -1062,10 +1081,11 @@ int dsir_t_maxpool_fwd(void* stream, const float* X, int n, int C, const int32_t
   return done();
 }
 
-int dsir_t_maxpool_bwd(void* stream, const float* dOut, const int32_t* arg, int m, int C, int clouds, float* dX, int n) {
-  if (!dOut || !arg || !dX || n < 1 || C < 1 || m < 1 || clouds < 1) return (int)hipErrorInvalidValue;
-  const int64_t total = (int64_t)clouds * m * C;
-  hipLaunchKernelGGL(t_maxpool_bwd_kernel, dim3(grid1(total)), dim3(256), 0, (hipStream_t)stream, dOut, arg, m, C, dX, n, total);
+int dsir_t_maxpool_bwd(void* stream, const float* dOut, const int32_t* arg, const int32_t* order, const int32_t* offsets, int m, int k, int C,
+                       int clouds, float* dX, int n) {
+  if (!dOut || !arg || !order || !offsets || !dX || n < 1 || C < 1 || m < 1 || k < 1 || clouds < 1) return (int)hipErrorInvalidValue;
+  const int64_t total = (int64_t)clouds * n * C;
+  hipLaunchKernelGGL(t_maxpool_bwd_kernel, dim3(grid1(total)), dim3(256), 0, (hipStream_t)stream, dOut, arg, order, offsets, m, k, C, dX, n, total);
   return done();
 }
 

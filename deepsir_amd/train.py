@@ -55,6 +55,7 @@ class _Ops:
         self.lib = _lib.load()
         self.device = device
         self._scratch: Optional[torch.Tensor] = None
+        self._plans: dict = {}
         self.stream = 0
         self.begin()
 
@@ -129,10 +130,34 @@ class _Ops:
         self._ok(self.lib.dsir_t_gather(self.stream, _ptr(x), n, C_, _ptr(idx), m, clouds, _ptr(out), out.shape[-1], col_off),
                  "dsir_t_gather")
 
+    def plan(self, idx: torch.Tensor, n: int):
+        """The inverse of a gather index idx [clouds][m] into [clouds][n] (include/dsir_train.h, dsir_t_scatter_plan): (order, offsets).
+        Cached per index tensor for the duration of one step (``new_step`` drops the cache): the neighbour index of a level serves
+        three scatter-adds per pass, and every registration iteration of an `align` step runs on the same pyramid.  The cache holds
+        the index tensor itself, so its storage cannot be handed to another tensor while the entry lives."""
+        clouds, m = idx.shape
+        key = (idx.data_ptr(), clouds, m, n)
+        hit = self._plans.get(key)
+        if hit is not None:
+            return hit[1], hit[2]
+        order = torch.empty(clouds * m, dtype=torch.int32, device=self.device)
+        offsets = torch.empty(clouds * n + 1, dtype=torch.int32, device=self.device)
+        nb = int(self.lib.dsir_t_scatter_plan_scratch(clouds * m))
+        scratch = torch.empty(nb, dtype=torch.uint8, device=self.device)
+        self._ok(self.lib.dsir_t_scatter_plan(self.stream, _ptr(idx), m, clouds, n, _ptr(order), _ptr(offsets), _ptr(scratch)),
+                 "dsir_t_scatter_plan")
+        self._plans[key] = (idx, order, offsets)
+        return order, offsets
+
+    def new_step(self) -> None:
+        """Start of an optimisation step: index tensors may have new contents, plans are rebuilt on demand."""
+        self._plans = {}
+
     def scatter_add(self, dy: torch.Tensor, col_off: int, C_: int, idx: torch.Tensor, n: int) -> torch.Tensor:
         clouds, m = idx.shape
-        dx = torch.zeros(clouds, n, C_, dtype=torch.float32, device=self.device)
-        self._ok(self.lib.dsir_t_scatter_add(self.stream, _ptr(dy), dy.shape[-1], col_off, _ptr(idx), m, clouds, _ptr(dx), n, C_),
+        order, offsets = self.plan(idx, n)
+        dx = torch.empty(clouds, n, C_, dtype=torch.float32, device=self.device)
+        self._ok(self.lib.dsir_t_scatter_add(self.stream, _ptr(dy), dy.shape[-1], col_off, _ptr(order), _ptr(offsets), clouds, _ptr(dx), n, C_),
                  "dsir_t_scatter_add")
         return dx
 
@@ -164,10 +189,14 @@ class _Ops:
                  "dsir_t_maxpool_fwd")
         return out, arg
 
-    def maxpool_bwd(self, dout: torch.Tensor, arg: torch.Tensor, n: int) -> torch.Tensor:
+    def maxpool_bwd(self, dout: torch.Tensor, arg: torch.Tensor, pool: torch.Tensor, n: int) -> torch.Tensor:
+        """pool [clouds][m][k]: the index the forward pooled with (its inverse orders the sum)."""
         clouds, m, C_ = arg.shape
-        dx = torch.zeros(clouds, n, C_, dtype=torch.float32, device=self.device)
-        self._ok(self.lib.dsir_t_maxpool_bwd(self.stream, _ptr(dout), _ptr(arg), m, C_, clouds, _ptr(dx), n), "dsir_t_maxpool_bwd")
+        k = pool.shape[2]
+        order, offsets = self.plan(pool.reshape(clouds, m * k), n)
+        dx = torch.empty(clouds, n, C_, dtype=torch.float32, device=self.device)
+        self._ok(self.lib.dsir_t_maxpool_bwd(self.stream, _ptr(dout), _ptr(arg), _ptr(order), _ptr(offsets), m, k, C_, clouds, _ptr(dx), n),
+                 "dsir_t_maxpool_bwd")
         return dx
 
     def add_leaky_fwd(self, a, b):
@@ -314,6 +343,7 @@ class _ParamStore:
 
     def zero_grad(self) -> None:
         self.flat_g.zero_()
+        self.ops.new_step()
 
     def grads_have_nan(self) -> bool:
         """train.py:437-441 ("Gradients include NaN values. Parameters will not be updated"): one kernel, one 4-byte read."""
@@ -593,7 +623,7 @@ class RandlaTrainer(_ParamStore):
             else:
                 fc.append((pos, h, None, None))
                 h = y
-        tape.misc["net"] = dict(clouds=clouds, N=N, n=n, skips_shapes=[s.shape for s in skips], args=args, dec=dec, xf=xf, fc=fc,
+        tape.misc["net"] = dict(clouds=clouds, N=N, n=n, skips_shapes=[s.shape for s in skips], args=args, pools=pyr["sub"], dec=dec, xf=xf, fc=fc,
                                 mask=dropout_mask, L=L)
         tape.misc["feat"] = feat.reshape(clouds, N, -1)            # RandLA.forward's first output (before the dropout)
         return h.reshape(clouds, N, self.num_classes), tape
@@ -633,7 +663,7 @@ class RandlaTrainer(_ParamStore):
         dmid = self._mlp2d_bwd(tape, pf + ".mlp_mid", dx).reshape(shapes[-1])
         dskips[-1] = o.acc(dskips[-1], dmid).reshape(shapes[-1])
         for l in reversed(range(L)):
-            denc = o.maxpool_bwd(dskips[l + 1].contiguous(), net["args"][l], n[l])                   # [clouds][n_l][2 d_l]
+            denc = o.maxpool_bwd(dskips[l + 1].contiguous(), net["args"][l], net["pools"][l], n[l])  # [clouds][n_l][2 d_l]
             if l == 0 and dskips[0] is not None:
                 o.axpy(1.0, dskips[0].contiguous(), denc)
             dfeat = self._res_block_bwd(tape, f"{pf}.dilated_res_blocks.{l}", denc, need_dx=True, shared=shared)

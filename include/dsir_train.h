@@ -53,8 +53,16 @@ int dsir_t_bn_running(void* stream, const float* stats, int C, int64_t M, float 
 /* gather_neighbour_V2 / nearest_interpolation (network/tools.py:197-221, RandLANet.py:393-408):
  * Y[cloud][j][col_off + c] = X[cloud][idx[cloud][j]][c], j < m, c < C; X [clouds][n][C]; backward = scatter-add. */
 int dsir_t_gather(void* stream, const float* X, int n, int C, const int32_t* idx, int m, int clouds, float* Y, int ldy, int col_off);
-int dsir_t_scatter_add(void* stream, const float* dY, int ldy, int col_off, const int32_t* idx, int m, int clouds, float* dX,
-                       int n, int C);
+/* The backward of a gather is a sum over the SOURCES of every destination row.  It is taken in a fixed order - ascending source row -
+ * through the inverse of the index (a "plan": one stable sort of (destination, source) pairs per index tensor, re-used by every
+ * operator that shares the index), so a gradient has the same bits on every run (up to round 4: float atomics, 2e-6 of its scale
+ * between runs).  dsir_t_scatter_plan: idx [clouds][m] into [clouds][n] -> order [clouds * m] i32 (sources grouped by destination),
+ * offsets [clouds * n + 1] i32; scratch: dsir_t_scatter_plan_scratch(clouds * m) bytes.
+ * dsir_t_scatter_add: dX[cloud][i][c] = sum over the sources j of row i of dY[cloud m + j][col_off + c]  (overwrites dX). */
+size_t dsir_t_scatter_plan_scratch(int64_t total);
+int dsir_t_scatter_plan(void* stream, const int32_t* idx, int m, int clouds, int n, int32_t* order, int32_t* offsets, void* scratch);
+int dsir_t_scatter_add(void* stream, const float* dY, int ldy, int col_off, const int32_t* order, const int32_t* offsets, int clouds,
+                       float* dX, int n, int C);
 
 /* Building_block.relative_pos_encoding (RandLANet.py:197-212): out[cloud][i k + j][10] = {|pj - pi|, pj - pi, pi, pj};
  * xyz [clouds][n][3], idx [clouds][n][k].  No backward: the coordinates are data. */
@@ -74,10 +82,12 @@ int dsir_t_attpool_bwd(void* stream, const float* dOut, const float* cat, const 
                        float* dS);
 
 /* RandLA.random_sample (RandLANet.py:374-391): out[cloud][j][c] = max_t X[cloud][pool[cloud][j][t]][c]; arg = the row
- * that won (first of equals); backward adds dOut to that row. */
+ * that won (first of equals); backward adds dOut to that row, in ascending order of the outputs (no float atomics). */
 int dsir_t_maxpool_fwd(void* stream, const float* X, int n, int C, const int32_t* pool, int m, int k, int clouds, float* out,
                        int32_t* arg);
-int dsir_t_maxpool_bwd(void* stream, const float* dOut, const int32_t* arg, int m, int C, int clouds, float* dX, int n);
+/* backward: order / offsets = the plan of the pool index viewed as [clouds][m k] (dsir_t_scatter_plan); overwrites dX [clouds][n][C] */
+int dsir_t_maxpool_bwd(void* stream, const float* dOut, const int32_t* arg, const int32_t* order, const int32_t* offsets, int m, int k, int C,
+                       int clouds, float* dX, int n);
 
 /* SemanticLoss.compute_loss (network/loss.py:930-960, :919-928): F.cross_entropy(weight = class weights, reduction 'mean')
  * over the points whose label is not 0 ("unlabeled"), class = label - 1; logits [rows][C] point-major, labels [rows] in 0..C.

@@ -130,6 +130,10 @@ def test_groupnorm_statistics_meet_in_exact_atomics_only():
     limb = limb[:limb.index("\n}\n")]
     assert limb.count("rint(") == 2 and "return limb ? rint(" in limb and "const double l1 = rint(" in limb          # both limbs are integers by construction
     assert "tomicAdd" not in util.replace(helper, "")                          # no other adding atomic among the shared helpers
+    # the training path: the backward of the gathers sums through the index's inverse in a fixed order, the loss
+    # terms are added in pair order - no adding atomic at all in these files
+    for f in ("train_ops.hip", "align_loss.hip"):
+        assert "tomicAdd" not in _strip_comments(open(os.path.join(csrc, f)).read()), f
 
 
 def test_groupnorm_exactness_bound_limits_max_points():

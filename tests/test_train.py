@@ -173,7 +173,18 @@ def test_ops_against_torch_autograd():
     assert torch.equal(cat[:, 5:].cpu(), ref.detach().reshape(-1, C_))
     dy = rnd(clouds * n * 16, C_ + 5)
     ref.backward(dy[:, 5:].reshape(clouds, n * 16, C_))
-    assert torch.allclose(o.scatter_add(dy.to(_dev()), 5, C_, idx.int().to(_dev()), n).cpu(), x.grad, rtol=1e-4, atol=1e-4)
+    idx_d = idx.int().to(_dev())
+    got = o.scatter_add(dy.to(_dev()), 5, C_, idx_d, n)
+    assert torch.allclose(got.cpu(), x.grad, rtol=1e-4, atol=1e-4)
+    # the sum over a row's sources runs in ascending source order through the index's inverse (dsir_t_scatter_plan): no float
+    # atomics, every run the same bits - and exactly the sequential fp32 sum in that order
+    for _ in range(3):
+        o.new_step()
+        assert torch.equal(o.scatter_add(dy.to(_dev()), 5, C_, idx_d, n), got)
+    seq = torch.zeros(n, C_)
+    for j in range(n * 16):
+        seq[idx[0, j]] += dy[j, 5:]
+    assert torch.equal(got[0].cpu(), seq)
     x.grad = None
     pool = torch.randint(0, n, (clouds, m, 16), generator=g)
     ref = torch.gather(x, 1, pool.reshape(clouds, m * 16, 1).expand(-1, -1, C_)).reshape(clouds, m, 16, C_).max(dim=2)[0]
@@ -181,7 +192,11 @@ def test_ops_against_torch_autograd():
     assert torch.equal(out.cpu(), ref.detach())
     dp = rnd(clouds, m, C_)
     ref.backward(dp)
-    assert torch.allclose(o.maxpool_bwd(dp.to(_dev()), arg, n).cpu(), x.grad, rtol=1e-5, atol=1e-5)
+    pool_d = pool.int().to(_dev())
+    gp = o.maxpool_bwd(dp.to(_dev()), arg, pool_d, n)
+    assert torch.allclose(gp.cpu(), x.grad, rtol=1e-5, atol=1e-5)
+    o.new_step()
+    assert torch.equal(o.maxpool_bwd(dp.to(_dev()), arg, pool_d, n), gp)
     pts = 130
     cat = rnd(pts, 16, C_).requires_grad_()
     sc = rnd(pts, 16, C_).requires_grad_()
