@@ -393,7 +393,7 @@ def main():
     screened = sstats["screened_searches"] > 0
 
     # ------------------------------------------------------------------ rank-0 extras (outside the timed region)
-    model_only = single = single_ex = companion = latency = training = line_stress = concurrent_single = throughput_curve = config4 = None
+    model_only = single = single_ex = companion = latency = training = line_stress = concurrent_single = throughput_curve = config4 = large_cfgs = None
     checks = []
     if a.timed_only:
         a.no_cpu_baseline = a.no_latency = a.no_companion = True
@@ -514,9 +514,31 @@ def main():
                 eng.register(s1, r1, n_iter, want_aux=False, sync=False, out={"transforms": o1["transforms"]})
             eng.sync()
             ms = (time.perf_counter() - t1) / reps * 1e3
+            e0 = eng.engines[0] if hasattr(eng, "engines") else eng
+            census = e0.graph_stats()
+            # the same registration with the deep-level walker (csrc/walk.hip: levels 2 / 3 + mlp_mid + two decoder blocks of every pass as
+            # one persistent launch; off by default): fewer launches, same bits, and what it costs
+            e0.enable_walk(True)
+            ow = {"transforms": torch.empty_like(o1["transforms"])}
+            for _ in range(3):
+                eng.register(s1, r1, n_iter, want_aux=False, sync=False, out=ow)
+            eng.sync()
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                eng.register(s1, r1, n_iter, want_aux=False, sync=False, out=ow)
+            eng.sync()
+            ms_w = (time.perf_counter() - t1) / reps * 1e3
+            census_w = e0.graph_stats()
+            same_w = bool(torch.equal(ow["transforms"], o1["transforms"]))
+            e0.enable_walk(False)
             eng.enable_graph(False)
             latency = {"pairs_in_flight": 1, "ms_per_pair": round(ms, 4), "pairs_per_s": round(1e3 / ms, 2), "hipgraph": True,
-                       "note": "the reference's own evaluation mode (test.py:56 BATCH_SIZE = 1, BASELINE configs[1] 'batch=1')"}
+                       "launches_per_registration": census,
+                       "deep_level_walker": {"ms_per_pair": round(ms_w, 4), "launches_per_registration": census_w, "equal_bits": same_w,
+                                             "note": "dsir_enable_walk(1): 114 launches fewer, slower - a launch boundary costs ~1.5 us, a phase "
+                                                     "hand-off ~2 us, and the tiles' own latency chains are what the time is made of (csrc/walk.hip)"},
+                       "note": "the reference's own evaluation mode (test.py:56 BATCH_SIZE = 1, BASELINE configs[1] 'batch=1'); "
+                               "launches_per_registration: node census of the captured graph (dsir_graph_stats)"}
 
         # K single-pair registrations in flight (deepsir_amd/serve.py): what a test.py-style caller that feeds one pair per call
         # AHEAD of the results gets - requests coalesced into hipGraph-replayed batches of K / engines on the engines in turn
@@ -589,6 +611,39 @@ def main():
                        "note": "BASELINE configs[3] on one GPU: the 1623-pair set walked in engine calls of at most "
                                f"{P} pairs (the last one ragged), results gathered once per pass; the 8-GPU form is bench.py --gpus 8 --total-pairs 1623"}
             del s4, r4, o4, b4
+
+        # BASELINE configs[2] / configs[4] at N = 1 (KITTI-shaped 16384-point pairs; 65536-point partial-overlap pairs): a few steps each on
+        # engines of their own, so that the large configurations are measured by whoever runs this file, not only by the builder
+        # (full runs: `bench.py --points 16384 --feat-len 4 --shape kitti --pairs 128 --streams 4`, `--points 65536 --partial-overlap --pairs 16`)
+        if not a.no_companion and not strong and world == 1 and N == 5000 and a.shape == "3dmatch" and not a.partial_overlap and P >= 64:
+            large_cfgs = {}
+            for key, (n_, fl_, shape_, part_, p_, s_, reps_) in {"c3_16384": (16384, 4, "kitti", False, 64, 2, 3),
+                                                                 "c5_65536": (65536, 3, "3dmatch", True, 8, 2, 2)}.items():
+                t_set = time.perf_counter()
+                cfg_ = NetConfig(feat_len=fl_)
+                eng_ = EnginePool(cfg_, dev_index, max_points=n_, max_pairs=p_, streams=s_)
+                eng_.load_state_dict(generate_state_dict(cfg_, 0, variant))
+                b_ = make_batch(n_, [70_000 + i for i in range(min(p_, 8))], fl_, shape_, part_)        # 8 distinct pairs, tiled: generation is host time
+                reps_p = (p_ + b_["points_src"].shape[0] - 1) // b_["points_src"].shape[0]
+                s_l = torch.from_numpy(np.concatenate([b_["points_src"]] * reps_p)[:p_]).to(dev)
+                r_l = torch.from_numpy(np.concatenate([b_["points_ref"]] * reps_p)[:p_]).to(dev)
+                o_l = torch.empty((p_, n_iter, 3, 4), dtype=torch.float32, device=dev)
+                eng_.register(s_l, r_l, n_iter, want_aux=False, sync=False, out={"transforms": o_l}); eng_.sync()
+                t1 = time.perf_counter()
+                for _ in range(reps_):
+                    eng_.register(s_l, r_l, n_iter, want_aux=False, sync=False, out={"transforms": o_l})
+                eng_.sync()
+                t1 = time.perf_counter() - t1
+                gt_ = torch.from_numpy(np.concatenate([b_["transform_gt"]] * reps_p)[:p_]).to(dev)
+                err_ = float((o_l[:, -1] - gt_).abs().max())
+                large_cfgs[key] = {"points": n_, "pairs_per_step": p_, "streams": s_, "steps": reps_, "pairs_per_s": round(p_ * reps_ / t1, 1),
+                                   "ms_per_step": round(t1 / reps_ * 1e3, 2), "finite": bool(torch.isfinite(o_l).all()),
+                                   "max_abs_pose_minus_gt": round(err_, 4), "setup_s": round(time.perf_counter() - t_set - t1, 1)}
+                eng_.close()
+                del s_l, r_l, o_l, eng_
+            large_cfgs["note"] = ("BASELINE configs[2] (KITTI-shaped, feat_len 4) and configs[4] (50 % overlap crops + jitter) on one GPU, short runs "
+                                  "beside the headline (never `value`); parity of these shapes: tests/test_gpu_large_configs.py; seeded random weights "
+                                  "do not register (max_abs_pose_minus_gt is informational)")
 
         # the training step of the same pipeline, reported beside the headline, never as `value`
         if world == 1 and not a.no_latency and not a.no_companion and N <= 16384:
@@ -680,15 +735,21 @@ def main():
                     "kernel": "screen_kernel<4,8> (csrc/nn_screen.hip): fp16-split MFMA screening of the 64-channel descriptor arg-min "
                               "under a rigorous bound; the exact fp32 decision among the survivors follows in exact_pick_kernel / nn_match_kernel",
                     "dtype": "f16 in, f32 accumulate (v_mfma_f32_16x16x32_f16)",
-                    "achieved": round(ex / (k_ms / 1e3) / 1e12, 3), "peak": PEAK_F16_MFMA_TFLOPS,
-                    "frac": round(ex / (k_ms / 1e3) / 1e12 / PEAK_F16_MFMA_TFLOPS, 4),
-                    "flops_per_launch": ex, "flops_note": "EXECUTED MFMA flops: (ah.bh + ah.bl + al.bh) x 2 x 64 per (row, column) = 384 J K per pair"
-                                                          + (" x the share of the products the launches visit (`pruned`)" if pruned else ""),
-                    "frac_algorithmic": round(match_flops(P_launch, N, N) / (k_ms / 1e3) / 1e12 / PEAK_F16_MFMA_TFLOPS, 4),
-                    "frac_algorithmic_note": "SURVEY 8d's rule: ALGORITHMIC flops of the operation this kernel serves (the reference formulation's "
-                                             "131 J K per pair) / the kernel's duration / the same fp16 peak: two thirds of the MFMA work the kernel "
-                                             "issues is the price of carrying fp32 operands as fp16 pairs.  Coarser screenings that would issue less "
-                                             "were measured and are not selective enough (profiles/README.md, tools/survivor_stats.py)",
+                    # SURVEY 8d's rule: `achieved` / `frac` price the ALGORITHMIC flops of the operation the kernel serves (the reference
+                    # formulation's 131 J K per pair) over the kernel's duration; what the kernel EXECUTES (three fp16 products per
+                    # fp32 product) is reported beside it as achieved_executed / frac_executed
+                    "achieved": round(match_flops(P_launch, N, N) / (k_ms / 1e3) / 1e12, 3), "peak": PEAK_F16_MFMA_TFLOPS,
+                    "frac": round(match_flops(P_launch, N, N) / (k_ms / 1e3) / 1e12 / PEAK_F16_MFMA_TFLOPS, 4),
+                    "flops_per_launch": match_flops(P_launch, N, N),
+                    "flops_note": "ALGORITHMIC flops (SURVEY 8d): the reference formulation's 131 J K per pair of the search this kernel serves",
+                    "achieved_executed": round(ex / (k_ms / 1e3) / 1e12, 3),
+                    "frac_executed": round(ex / (k_ms / 1e3) / 1e12 / PEAK_F16_MFMA_TFLOPS, 4),
+                    "flops_executed_per_launch": ex,
+                    "flops_executed_note": "EXECUTED MFMA flops: (ah.bh + ah.bl + al.bh) x 2 x 64 per (row, column) = 384 J K per pair"
+                                           + (" x the share of the products the launches visit (`pruned`)" if pruned else "")
+                                           + ": two thirds of the MFMA work the kernel issues is the price of carrying fp32 operands as fp16 pairs; "
+                                             "coarser screenings that would issue less were measured and are not selective enough "
+                                             "(profiles/README.md, tools/survivor_stats.py)",
                     "sustained_note": "the bare chain of this kernel's MFMAs (ablation build, no ranking / LDS reads / staging) sustains 1.35 PFLOP/s "
                                       "= 0.54 of `peak` on the same descriptor data: the chip lowers its clock under a dense matrix stream "
                                       "(profiles/README.md); `frac` is quoted against the spec peak all the same"})
@@ -724,9 +785,10 @@ def main():
                 "concurrent": {"streams": S, "launches": int(c_n), "avg_launch_ms": round(c_k_ms / max(c_n, 1), 5),
                                "avg_operation_ms": round(c_op_ms / max(c_n, 1), 5),
                                "note": "the same brackets inside the timed region, where `streams` engines share the GPU"},
-                "note": "achieved = flops the dominant kernel executes per launch / its average duration (HIP events on the engine's "
-                        "stream around that kernel alone, ONE engine registering its share of the batch; rocprofv3 --kernel-trace of "
-                        "this command agrees, profiles/), against the dense MFMA peak of the dtype it issues"})
+                "note": "achieved = ALGORITHMIC flops of the dominant kernel's operation per launch (SURVEY 8d) / the kernel's average duration "
+                        "(HIP events on the engine's stream around that kernel alone, ONE engine registering its share of the batch; rocprofv3 "
+                        "--kernel-trace of this command agrees, profiles/), against the dense MFMA peak of the dtype it issues; *_executed: "
+                        "the flops the kernel actually issues over the same duration"})
             if single_ex is not None:
                 op2, k2, n2 = single_ex[:3]
                 roof["exhaustive_kernel"] = {
@@ -750,8 +812,20 @@ def main():
                                         "bytes_per_step": j["hbm_bytes_per_step"], "source": j.get("method")}
             except Exception:
                 pass
+        # the timed step against BOTH rooflines: its algorithmic flops (the whole path) over the live step time against the fp16
+        # matrix peak most of them run on, and its HBM-side bytes (PMC passes of the same command) over the same time against 8 TB/s
+        ws = {"algorithmic_tflops": round(path_flops(N, n_iter) * total_pairs / dt / 1e12, 2),
+              "algorithmic_frac_of_fp16_mfma_peak": round(path_flops(N, n_iter) * total_pairs / dt / 1e12 / PEAK_F16_MFMA_TFLOPS, 4),
+              "hbm_tbps": None, "hbm_frac_of_8tbps": None,
+              "note": "the step as a whole sits far below either roofline: it is a chain of ~300 dependent launches per engine whose kernels "
+                      "run 2 - 3 waves per SIMD at the latency of their own load chains (profiles/README.md, round 5)"}
+        if "hbm_gbps" in roof:
+            ws["hbm_tbps"] = round(roof["hbm_gbps"]["value"] / 1e3, 3)
+            ws["hbm_frac_of_8tbps"] = roof["hbm_gbps"]["frac"]
+            ws["hbm_bytes_per_pair"] = round(roof["hbm_gbps"]["bytes_per_step"] / max(P, 1))
+        roof["whole_step"] = ws
         # the step's top kernels with their own rooflines (tools/kernel_table.py over the committed rocprofv3 summaries of this build)
-        kt = os.path.join(ROOT, "profiles", "r04_kernel_table.json")
+        kt = os.path.join(ROOT, "profiles", "kernel_table.json")
         if os.path.exists(kt) and (P_launch, N, n_iter) == (128, 5000, 5):
             try:
                 with open(kt) as f:
@@ -783,6 +857,8 @@ def main():
             line["config4_1623_pairs_n1"] = config4
         if training is not None:
             line["training_step"] = training
+        if large_cfgs is not None:
+            line["large_configs_n1"] = large_cfgs
         if world == 1 and not a.no_cpu_baseline:
             base, parity = cpu_leg(cfg, sd, N, n_iter, checks)
             line["cpu_baseline"] = base
