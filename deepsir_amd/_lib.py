@@ -105,6 +105,7 @@ SYMBOLS = {
     "dsir_enable_graph": (C.c_int, [C.c_void_p, C.c_int]),
     "dsir_graph_stats": (C.c_int, [C.c_void_p, c_i64_p]),
     "dsir_enable_walk": (C.c_int, [C.c_void_p, C.c_int]),
+    "dsir_enable_fork": (C.c_int, [C.c_void_p, C.c_int]),
     "dsir_walk_trace": (C.c_int, [C.c_void_p, C.c_int, c_i64_p, c_i64_p]),
     "dsir_screen_stats": (C.c_int, [C.c_void_p, C.c_int, c_i64_p]),
     "dsir_prune_stats": (C.c_int, [C.c_void_p, C.c_int, c_i64_p]),

@@ -124,6 +124,20 @@ struct dsir_ctx {
   // single-pair requests into one call replays K graphs in turn (deepsir_amd/serve.py); the oldest is evicted beyond kMaxGraphs
   struct Graph { std::vector<unsigned char> key; hipGraphExec_t exec; void* walk_block; };   // walk_block: the graph's walker programs (device)
   int64_t graph_nodes[4] = {0, 0, 0, 0};   // the latest captured registration: nodes in all, kernel / memset / memcpy nodes (dsir_graph_stats)
+  // ---- independent branches of the schedule on auxiliary streams (fork / join through events; captured into a registration's graph as
+  // parallel branches).  With a few clouds in flight the chip is nearly empty and a registration is one long chain of dependent
+  // launches; the KNN searches of the four levels, a level's position-encoding branch (lfa.mlp1 -> lfa.mlp2), its mlp_skip and the
+  // loop-invariant halves of the aggregation do not depend on the chain beside them and can run beside it.  Same kernels, same
+  // operands: same bits (tests/test_gpu_walk.py).  An experiment that did NOT pay (see fork_mode): kept as a switch.
+  static constexpr int kAux = 2;
+  static constexpr int kForkClouds = 16;
+  hipStream_t aux[kAux] = {nullptr, nullptr};
+  std::vector<hipEvent_t> fork_events;
+  size_t fork_events_used = 0;
+  int fork_mode = 0;                           // 1: fork (dsir_enable_fork / DSIR_FORK=1).  OFF by default: measured SLOWER - one pair replayed
+                                               // from its graph 3.08 ms on one stream, 3.37 - 4.06 ms with any of the branches forked (a
+                                               // captured graph with parallel branches leaves the runtime's single-queue fast path:
+                                               // even ONE fork / join costs 0.3 ms; profiles/README.md round 5)
   // ---- deep-level walker (walk.hip): the programs of one call's RandLA passes live in device memory
   static constexpr int kWalkSlots = 12;        // programs per call (1 extractor pass or 2, up to 10 inlier passes)
   static constexpr int kWalkClouds = 16;       // the walker serves launches of up to that many clouds
@@ -505,6 +519,7 @@ int walk_flush(dsir_ctx* c, WalkProgram& P, hipStream_t st) {
 // may still be queued) after making sure that set's own last copy has run
 int walk_begin_call(dsir_ctx* c) {
   c->walk_used = 0;
+  c->fork_events_used = 0;
   if (c->capturing || !c->walk_dev) return 0;
   c->walk_set ^= 1;
   if (c->walk_ev_armed[c->walk_set]) { HIP_OK(c, hipEventSynchronize(c->walk_ev[c->walk_set])); c->walk_ev_armed[c->walk_set] = false; }
@@ -515,6 +530,27 @@ int walk_end_call(dsir_ctx* c) {
   HIP_OK(c, hipEventRecord(c->walk_ev[c->walk_set], c->stream));
   c->walk_ev_armed[c->walk_set] = true;
   return 0;
+}
+
+// `to` continues after everything enqueued on `from` so far (fork: main -> auxiliary; join: auxiliary -> main).  Events are taken
+// from a per-context pool that restarts with every call; a wait binds to the event's latest record at the time it is enqueued.
+hipEvent_t fork_mark(dsir_ctx* c, hipStream_t from) {
+  if (c->fork_events_used == c->fork_events.size()) {
+    hipEvent_t e = nullptr;
+    hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    c->fork_events.push_back(e);
+  }
+  hipEvent_t e = c->fork_events[c->fork_events_used++];
+  hipEventRecord(e, from);
+  return e;
+}
+void fork_wait(hipStream_t to, hipEvent_t e) { hipStreamWaitEvent(to, e, 0); }
+void fork_to(dsir_ctx* c, hipStream_t from, hipStream_t to) { fork_wait(to, fork_mark(c, from)); }
+// what: 1 = the KNN pyramid's levels, 2 = a block's position-encoding branch, 4 = a block's mlp_skip, 8 = the aggregation's loop invariants
+// (DSIR_FORK_MASK: tuning hook - a dependency between streams has a price of its own, only the longer branches pay for it)
+bool fork_on(const dsir_ctx* c, int clouds, int what) {
+  static const int mask = (int)tuning_int("DSIR_FORK_MASK", 15);
+  return c->fork_mode && (mask & what) && c->aux[0] && clouds <= dsir_ctx::kForkClouds;
 }
 
 struct Sched {
@@ -843,19 +879,47 @@ int randla_forward(dsir_ctx* c, const RandlaW& w, const Seg& in0, const Seg* in1
     const int32_t* nb_l = py.neigh + (int64_t)py.off[l] * kKnn;
     const Seg xin = Sched::seg_of(x);
     Act f, skipb;
-    const bool paired = s.mlp2d_pair(b, xin, n, f, skipb);
-    if (!paired) f = s.mlp2d(b.mlp1, xin, nullptr, n, true);
     const bool ahead = walk && l >= walk_from;       // computed before the chain started (below)
-    Act enc = ahead ? enc_pre[l] : enc_of(l);
+    // Few clouds in flight: the block's independent branches leave the chain mlp1 -> pooling 1 -> pooling 2 -> mlp2 and run beside it
+    // on the auxiliary streams - the position-encoding branch (lfa.mlp1 -> lfa.mlp2: inputs the pyramid alone), joined where the two
+    // poolings read it, and mlp_skip (input the block's input), joined at the residual sum.
+    const bool fork_enc = fork_on(c, py.clouds, 2) && !walk && !reuse && !ahead, fork_skip = fork_on(c, py.clouds, 4) && !walk;
+    hipEvent_t ev_enc = nullptr, ev_enc2 = nullptr, ev_skip = nullptr;
+    const hipEvent_t block_in = (fork_enc || fork_skip) ? fork_mark(c, st) : nullptr;      // x (and everything before it) is in flight on the main stream
+    Act enc, enc2;
+    if (fork_enc) {
+      fork_wait(c->aux[0], block_in);
+      s.st = c->aux[0];
+      enc = enc_of(l); ev_enc = fork_mark(c, c->aux[0]);
+      enc2 = enc2_of(l, enc); ev_enc2 = fork_mark(c, c->aux[0]);
+      s.st = st;
+    }
+    const bool paired = s.mlp2d_pair(b, xin, n, f, skipb);
+    if (!paired) {
+      f = s.mlp2d(b.mlp1, xin, nullptr, n, true);
+      if (fork_skip) {
+        fork_wait(c->aux[1], block_in);
+        s.st = c->aux[1];
+        skipb = s.mlp2d(b.skip, xin, nullptr, n, false);
+        ev_skip = fork_mark(c, c->aux[1]);
+        s.st = st;
+      }
+    }
+    if (!ev_enc) enc = ahead ? enc_pre[l] : enc_of(l);
+    else fork_wait(st, ev_enc);
     const int s2_mode = reuse ? 2 : 1;      // iteration 0 stores the pyramid-only half of the scores, later iterations load it
     Act agg = s.att(b.att1, f, enc, nb_l, neigh_cs, n, cache ? cache->s2_buf[l][0] : nullptr, s2_mode);
     Act a1 = s.mlp2d(b.att1.mlp, Sched::seg_of(agg), nullptr, n, true);
-    Act enc2 = ahead ? enc2_pre[l] : enc2_of(l, enc);
+    if (!ev_enc2) enc2 = ahead ? enc2_pre[l] : enc2_of(l, enc);
+    else fork_wait(st, ev_enc2);
     if (cache && !reuse) { cache->enc[l] = enc; cache->enc2[l] = enc2; }
     Act agg2 = s.att(b.att2, a1, enc2, nb_l, neigh_cs, n, cache ? cache->s2_buf[l][1] : nullptr, s2_mode);
     Act a2 = s.mlp2d(b.att2.mlp, Sched::seg_of(agg2), nullptr, n, true);
     Act mainb = s.mlp2d(b.mlp2, Sched::seg_of(a2), nullptr, n, false);
-    if (!paired) skipb = s.mlp2d(b.skip, xin, nullptr, n, false);
+    if (!paired) {
+      if (ev_skip) fork_wait(st, ev_skip);
+      else skipb = s.mlp2d(b.skip, xin, nullptr, n, false);
+    }
     Act enc_out;
     enc_out.C = 2 * b.d; enc_out.rows = n;
     Act samp;
@@ -1000,6 +1064,39 @@ int build_pyramid(dsir_ctx* c, const float* points, int stride, int clouds, int 
   // interpolation search (in cell order: a wave's lanes walk neighbouring cells)
   const size_t mark = c->ws.mark();
   const void* prev_scratch = nullptr;
+  bool any_nn1_grid = false;
+  for (int l = 0; l < g.num_layers; ++l) any_nn1_grid = any_nn1_grid || nn1_by_grid(l);
+  if (fork_on(c, clouds, 1) && !any_nn1_grid && g.num_layers == 4) {
+    // few clouds: the searches of the four levels (and the four interpolation searches) read the input points alone - three branches
+    // of about equal length instead of a chain of eight launches: {level 0} | {level 1, its interpolation search} | {the rest}
+    hipStream_t a0 = c->aux[0], a1 = c->aux[1];
+    const hipEvent_t start = fork_mark(c, st);
+    fork_wait(a0, start); fork_wait(a1, start);
+    auto knn_level = [&](int l, hipStream_t s_) -> bool {
+      if (p.nl[l] >= grid_min && !no_grid) {
+        void* scratch = c->ws.raw(knn_grid_scratch_bytes(clouds, p.nl[l]));
+        if (c->ws.overflow) return false;
+        launch_knn16_grid(points, (int64_t)n * stride, stride, p.nl[l], clouds, neigh + (int64_t)p.off[l] * kKnn, neigh_cs, scratch, s_);
+      } else {
+        launch_knn16(points, (int64_t)n * stride, stride, p.nl[l], clouds, neigh + (int64_t)p.off[l] * kKnn, neigh_cs, s_);
+      }
+      return true;
+    };
+    auto nn1_level = [&](int l, hipStream_t s_) {
+      launch_nn1(points, (int64_t)n * stride, stride, p.nl[l], p.nl[l + 1], clouds, interp + p.off[l], p.S, s_);
+    };
+    bool ok = knn_level(0, st);
+    ok = ok && knn_level(1, a0);
+    nn1_level(1, a0);
+    nn1_level(0, a1);
+    ok = ok && knn_level(2, a1) && knn_level(3, a1);
+    nn1_level(2, a1); nn1_level(3, a1);
+    fork_to(c, a0, st); fork_to(c, a1, st);          // join before anything re-uses the scratch or reads the lists
+    if (!ok) return fail(c, "workspace exhausted in the KNN pyramid");
+    c->ws.release(mark);
+    launch_copy_sub_levels(neigh, neigh_cs, lv, clouds, sub, sub_cs, st);
+    return 0;
+  }
   for (int l = 0; l < g.num_layers; ++l) {
     if (p.nl[l] >= grid_min && !no_grid) {
       // large levels: exact grid-pruned search (knn_grid.hip); same bits as the brute force
@@ -1088,6 +1185,10 @@ int dsir_create(int device, const dsir_cfg* cfg, dsir_ctx** out) {
     return fail(nullptr, "cannot initialise device %d", device);
   }
   c->own_stream = c->stream;
+  for (int k = 0; k < dsir_ctx::kAux; ++k)
+    if (hipStreamCreateWithFlags(&c->aux[k], hipStreamNonBlocking) != hipSuccess) c->aux[k] = nullptr;
+  if (!c->aux[0] || !c->aux[1]) { for (int k = 0; k < dsir_ctx::kAux; ++k) { if (c->aux[k]) hipStreamDestroy(c->aux[k]); c->aux[k] = nullptr; } }
+  c->fork_mode = tuning_flag("DSIR_FORK") ? 1 : 0;
   // which sub-networks exist follows args.pipeline (model.py:131-193)
   add_randla(c, "feat_extractor", cfg->feat_len, cfg->num_classes);
   if (cfg->pipeline != DSIR_PIPELINE_LABEL) {
@@ -1173,6 +1274,8 @@ void dsir_destroy(dsir_ctx* c) {
   if (c->walk_trace) hipFree(c->walk_trace);
   if (c->stats) hipFree(c->stats);
   if (c->ws.base) hipFree(c->ws.base);
+  for (int k = 0; k < dsir_ctx::kAux; ++k) if (c->aux[k]) { hipStreamSynchronize(c->aux[k]); hipStreamDestroy(c->aux[k]); }
+  for (hipEvent_t e : c->fork_events) hipEventDestroy(e);
   hipStreamDestroy(c->own_stream);     // a caller's stream (dsir_set_stream) is the caller's to destroy
   delete c;
 }
@@ -1326,6 +1429,7 @@ int dsir_knn_pyramid(dsir_ctx* c, const float* points, int stride, int clouds, i
   HIP_OK(c, hipSetDevice(c->device));
   if (clouds < 1 || stride < 3) return fail(c, "dsir_knn_pyramid: bad arguments");
   c->ws.top = 0; c->ws.overflow = false;
+  c->fork_events_used = 0;
   if (int r = build_pyramid(c, points, stride, clouds, n, xyz, neigh, sub, interp)) return r;
   return post(c);
 }
@@ -1697,19 +1801,25 @@ static int register_enqueue(dsir_ctx* c, const dsir_pair_batch* in, int n_iter, 
   if (ws.overflow) return fail(c, "workspace exhausted (raise max_points / max_pairs)");
   const size_t mark1 = ws.mark();
   {
+    // the two loop-invariant halves are independent of each other: with few clouds in flight mlp_feat(feat_src) (and the copy of the
+    // src coordinates) runs on an auxiliary stream beside the ref side's chain; its temporaries keep their own arena space until the join
+    const bool forked = fork_on(c, 2 * P, 8);
+    hipStream_t side = forked ? c->aux[0] : st;
+    if (forked) fork_to(c, st, side);
+    c->stream = side;                         // run_mlp_feat launches on the context's stream
+    run_mlp_feat(c, feat_s, P, J, F_s);       // straight into the storage that outlives the iterations
+    c->stream = st;
+    launch_copy_xyz(pxyz, (int64_t)ps.S * 3, 3, J, P, xyz_cur, (int64_t)J * 3, side);      // xyz_cur = level-0 src coordinates
     float* F_r = run_mlp_feat(c, feat_r, P, K);
     run_att_proj(c, rxyz, (int64_t)pr.S * 3, score_r, F_r, P, K, desc_r);
-    ws.release(mark1);
     if (out->desc_ref) HIP_OK(c, hipMemcpyAsync(out->desc_ref, desc_r, sizeof(float) * P * K * 64, hipMemcpyDeviceToDevice, st));
     if (screen) {
       launch_split16_norm(desc_r, (int64_t)P * K, sc_bh, sc_bl, sc_sb, st);
     }
     if (prune && launch_prune_ref(rxyz, (int64_t)pr.S * 3, desc_r, sc_bh, sc_bl, sc_sb, P, J, K, pr_scratch, st)) return fail(c, "pruned search: sorting the ref side failed");
-    run_mlp_feat(c, feat_s, P, J, F_s);       // straight into the storage that outlives the iterations
+    if (forked) fork_to(c, side, st);
     ws.release(mark1);
   }
-  // xyz_cur = level-0 src coordinates
-  launch_copy_xyz(pxyz, (int64_t)ps.S * 3, 3, J, P, xyz_cur, (int64_t)J * 3, st);
 
   for (int it = 0; it < n_iter; ++it) {
     int32_t* idx_out = out->idx ? out->idx + (size_t)it * P * J : idx_it;
@@ -2188,6 +2298,14 @@ int dsir_walk_trace(dsir_ctx* c, int reset, int64_t* out, int64_t* clock_khz) {
     if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device) != hipSuccess || khz <= 0) khz = 100000;
     *clock_khz = khz;
   }
+  return 0;
+}
+
+int dsir_enable_fork(dsir_ctx* c, int enable) {
+  if (!c) return 1;
+  c->fork_mode = enable != 0;
+  // a captured registration has the choice baked in
+  c->drop_graphs();
   return 0;
 }
 

@@ -510,6 +510,11 @@ class Engine:
         self._call(self.lib.dsir_graph_stats(self.h, out))
         return {"nodes": int(out[0]), "kernels": int(out[1]), "memsets": int(out[2]), "memcpys": int(out[3])}
 
+    def enable_fork(self, on=True):
+        """A/B switch: independent branches of a small launch's schedule on auxiliary streams, or (default: measured faster) everything
+        on one stream.  Same bits either way (include/dsir.h, dsir_enable_fork)."""
+        self._call(self.lib.dsir_enable_fork(self.h, 1 if on else 0))
+
     def enable_walk(self, on=True):
         """A/B switch: the deep pyramid levels of a RandLA pass as one persistent launch (csrc/walk.hip; up to 16 clouds per launch;
         OFF by default - fewer launches, but measured slower) or every layer its own launch.  Same bits either way (include/dsir.h)."""

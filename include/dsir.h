@@ -310,6 +310,13 @@ int dsir_graph_stats(dsir_ctx* ctx, int64_t* out);
  * latency chains - what the time is made of - are the same).  Same kernels' code on the same operands, statistics in exact atomics:
  * same bits either way (tests/test_gpu_walk.py). */
 int dsir_enable_walk(dsir_ctx* ctx, int enable);
+/* A/B switch (measurement / test): launches of up to 16 clouds run the independent branches of the schedule - the KNN searches of the
+ * four pyramid levels (data_base.py:153-183), a block's position-encoding branch and its mlp_skip (RandLANet.py:176-186, :229), the
+ * loop-invariant halves of the aggregation (model.py:552) - on auxiliary streams beside the main chain, joined through events
+ * (parallel branches of a captured registration).  OFF by default: measured slower on this runtime (a replayed graph with parallel
+ * branches costs 0.3 - 1.0 ms more per single-pair registration than the linear chain, whatever the branches save).  Same kernels on
+ * the same operands: same bits either way (tests/test_gpu_walk.py). */
+int dsir_enable_fork(dsir_ctx* ctx, int enable);
 /* Measurement: with DSIR_TUNING=1 DSIR_WALK_TRACE=1 in the environment at dsir_create the walker stamps, per program of a call
  * (12 slots) and phase (32), the device clock of cloud 0's earliest tile picked up, earliest tile past its wait, latest tile body
  * end and latest publish: out (HOST, 12 x 32 x 4 i64), clock_khz the clock's rate.  reset: re-arm the stamps.  Synchronises. */

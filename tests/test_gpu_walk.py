@@ -113,3 +113,56 @@ def test_two_engines_walking_at_once():
             _same(o, w)
     for e in engs:
         e.close()
+
+
+# ------------------------------------------------------------------------------------------- independent branches on auxiliary streams
+@pytest.mark.parametrize("pairs,n_src,n_ref", [(1, 5000, 5000), (3, 2048, 1800), (8, 5000, 5000), (5, 1357, 1357)])
+def test_forked_schedule_equals_the_single_stream(pairs, n_src, n_ref):
+    """`Engine.enable_fork`: launches of up to 16 clouds run the KNN searches of the four levels, every block's position-encoding branch and
+    mlp_skip, and the loop-invariant halves of the aggregation on auxiliary streams beside the main chain (csrc/engine.hip, fork_on).
+    Same kernels, same operands: the results equal the single-stream schedule's bit for bit, eager and replayed from a graph."""
+    from deepsir_amd.engine import Engine
+    cfg, sd, src, ref = _setup(pairs, n_src, n_ref, seed0=1300)
+    eng = Engine(cfg, 0, max_points=max(n_src, n_ref), max_pairs=pairs)
+    eng.load_state_dict(sd)
+    eng.enable_fork(False)
+    want = {k: v.clone() for k, v in eng.register(src, ref, 5).items() if k != "_keep"}
+    pyr0 = [t.clone() for t in eng.knn_pyramid(torch.cat([src[:, :min(n_src, n_ref)], ref[:, :min(n_src, n_ref)]], 0))]
+    eng.enable_fork(True)
+    for rep in range(3):
+        _same(eng.register(src, ref, 5), want)
+    pyr1 = eng.knn_pyramid(torch.cat([src[:, :min(n_src, n_ref)], ref[:, :min(n_src, n_ref)]], 0))
+    assert all(torch.equal(a, b) for a, b in zip(pyr0, pyr1))
+    out = {k: torch.empty_like(v) for k, v in want.items()}
+    eng.enable_graph(True)
+    for rep in range(5):
+        for k, v in out.items():
+            if k != "_keep":
+                v.fill_(-1) if v.dtype != torch.float32 else v.fill_(float("nan"))
+        eng.register(src, ref, 5, out=out)
+        torch.cuda.synchronize()
+        _same(out, want)
+    eng.close()
+
+
+def test_forked_schedules_of_two_engines_at_once():
+    """Two engines with forked schedules (six streams in all) registering at the same time, again and again: every result equals the
+    quiet single-stream run."""
+    from deepsir_amd.engine import Engine
+    cfg, sd, src, ref = _setup(6, 3000, 3000, seed0=1700)
+    engs = [Engine(cfg, 0, max_points=3000, max_pairs=4) for _ in range(2)]
+    parts = [(src[:4], ref[:4]), (src[4:], ref[4:])]
+    want = []
+    for e, (s, r) in zip(engs, parts):
+        e.load_state_dict(sd)
+        e.enable_fork(False)
+        want.append({k: v.clone() for k, v in e.register(s, r, 5).items() if k != "_keep"})
+        e.enable_fork(True)
+    for rep in range(25):
+        outs = [e.register(s, r, 5, sync=False) for e, (s, r) in zip(engs, parts)]
+        for e in engs:
+            e.sync()
+        for o, w in zip(outs, want):
+            _same(o, w)
+    for e in engs:
+        e.close()
