@@ -67,7 +67,10 @@ __global__ __launch_bounds__(256, 2) void agg_chain_h_kernel(const AggArgs p) {
       else { layer = 3; ld = 256; col0 = 0; k0 = 64 * j; nk = 64; }
     }
   };
-  h8 rwh[2], rwl[2];
+  // Two register sets: chunk i travels in set i & 1 and is fetched TWO chunks before it is staged.  A chunk's 48 - 96 MFMAs (0.3 - 0.6 us
+  // with two workgroups per CU) hide a fraction of one L2 round trip: with one chunk of lookahead (round 3) the sixteen chunks of a
+  // workgroup each waited for their weights (1.8 us per chunk, matrix pipe 36 % busy).
+  h8 rwh[2][2], rwl[2][2];
   auto gload = [&](int i) {
     int layer, ld, col0, k0, nk;
     chunk_src(i, layer, ld, col0, k0, nk);
@@ -78,31 +81,33 @@ __global__ __launch_bounds__(256, 2) void agg_chain_h_kernel(const AggArgs p) {
       const int f = tid + 256 * u;
       const int piece = min(f & 7, nk / 8 - 1);
       const int64_t o = (int64_t)(col0 + (f >> 3)) * ld + k0 + 8 * piece;
-      rwh[u] = *reinterpret_cast<const h8*>(Wh + o);
-      rwl[u] = *reinterpret_cast<const h8*>(Wl + o);
+      rwh[i & 1][u] = *reinterpret_cast<const h8*>(Wh + o);
+      rwl[i & 1][u] = *reinterpret_cast<const h8*>(Wl + o);
     }
   };
-  auto lstore = [&](int buf) {
+  auto lstore = [&](int buf, int i) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int f = tid + 256 * u;
-      *reinterpret_cast<h8*>(&Bs[buf][0][(f >> 3) * SRS + 8 * (f & 7)]) = rwh[u];
-      *reinterpret_cast<h8*>(&Bs[buf][1][(f >> 3) * SRS + 8 * (f & 7)]) = rwl[u];
+      *reinterpret_cast<h8*>(&Bs[buf][0][(f >> 3) * SRS + 8 * (f & 7)]) = rwh[i & 1][u];
+      *reinterpret_cast<h8*>(&Bs[buf][1][(f >> 3) * SRS + 8 * (f & 7)]) = rwl[i & 1][u];
     }
   };
   int buf = 0, ci = 0;
-  // finish chunk ci: stage chunk ci + 1 (already in registers) into the other buffer, barrier, flip, fetch chunk ci + 2
+  // finish chunk ci: stage chunk ci + 1 (in registers since the chunk before) into the other buffer, barrier, flip, fetch chunk ci + 3
+  // into the set that has just been staged
   auto next_chunk = [&]() {
-    if (ci + 1 < 16) lstore(buf ^ 1);
+    if (ci + 1 < 16) lstore(buf ^ 1, ci + 1);
     __syncthreads();
     buf ^= 1;
     ++ci;
-    if (ci + 1 < 16) gload(ci + 1);
+    if (ci + 2 < 16) gload(ci + 2);
   };
 
   gload(0);
-  lstore(0);
+  lstore(0, 0);
   gload(1);
+  gload(2);
 
   // ---- layer 1: [xyz ; score] (4) -> 32 in exact fp32 (one MFMA k-step, as agg_chain_kernel)
   {
@@ -212,10 +217,22 @@ __global__ __launch_bounds__(256, 2) void agg_chain_h_kernel(const AggArgs p) {
   // ---- layers 4 + 5 interleaved: column chunk j of 128 -> 256 (two K chunks), activated, becomes K chunk j of 256 -> 64
   f32x4 acc5[RT][4];
   zero(acc5);
+  float fpre[RT][4][4];      // the mlp_feat rows the epilogue adds (model.py:226): fetched during the last column chunk, not in front of their use
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     f32x4 acc[RT][4];
     zero(acc);
+    if (j == 3) {
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = min(r0 + 16 * rt + 4 * fq + r, p.n - 1);
+          const float* f = p.F + ((int64_t)cloud * p.n + row) * 64 + fr;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) fpre[rt][r][t] = f[16 * t];
+        }
+    }
     mma(acc, a4[0], 2);
     next_chunk();
     mma(acc, a4[1], 2);
@@ -239,10 +256,8 @@ __global__ __launch_bounds__(256, 2) void agg_chain_h_kernel(const AggArgs p) {
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = min(r0 + 16 * rt + 4 * fq + r, p.n - 1);
-        const float* f = p.F + ((int64_t)cloud * p.n + row) * 64 + fr;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) T[(4 * fq + r) * LDT + 16 * t + fr] = (acc5[rt][t][r] + p.b5[16 * t + fr]) + f[16 * t];
+        for (int t = 0; t < 4; ++t) T[(4 * fq + r) * LDT + 16 * t + fr] = (acc5[rt][t][r] + p.b5[16 * t + fr]) + fpre[rt][r][t];
       }
       __builtin_amdgcn_wave_barrier();
       read_frag(T, a6[rt], true);
@@ -265,15 +280,48 @@ __global__ __launch_bounds__(256, 2) void agg_chain_h_kernel(const AggArgs p) {
           v[t][r] = acc[rt][t][r] + bv[t];
           ss[r] += v[t][r] * v[t][r];
         }
+      const bool extras = p.sq || p.hi || p.packed_init;      // block-uniform
+      float* T = Ts[w][rt];
+      if (extras) __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         ss[r] += __shfl_xor(ss[r], 1); ss[r] += __shfl_xor(ss[r], 2);
         ss[r] += __shfl_xor(ss[r], 4); ss[r] += __shfl_xor(ss[r], 8);
         const float den = fmaxf(__fsqrt_rn(ss[r]), 1e-12f);
         const int row = r0 + 16 * rt + 4 * fq + r;
-        if (row < p.n) {
+        if (extras) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) T[(4 * fq + r) * LDT + 16 * t + fr] = v[t][r] / den;
+        } else if (row < p.n) {
 #pragma unroll
           for (int t = 0; t < 4; ++t) Y[(int64_t)row * 64 + 16 * t + fr] = v[t][r] / den;
+        }
+      }
+      if (extras) {
+        // The descriptors go back through the wave's LDS tile into the row layout the search's preparation kernels read them in (16
+        // lanes per row, four consecutive channels each): |desc|^2 in THEIR summation order (sqnorm_row16: the value enters the
+        // distance every arg-min is decided on), the screening's fp16 operand pair by THEIR split - same bits, one pass less over
+        // the descriptors (and 16-byte descriptor stores instead of 4-byte ones).
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int lr = 4 * q + fq, row = r0 + 16 * rt + lr;           // lane group fq takes row 4 q + fq, lane fr its channels 4 fr ..
+          const float4 d4 = *reinterpret_cast<const float4*>(T + lr * LDT + 4 * fr);
+          const float s2 = sqnorm_row16(d4);
+          if (row < p.n) {
+            const int64_t gr = (int64_t)cloud * p.n + row;
+            *reinterpret_cast<float4*>(Y + (int64_t)row * 64 + 4 * fr) = d4;
+            if (p.hi) {
+              dsir_h4 hh, ll;
+              screen_split4(d4, hh, ll, nullptr);
+              *reinterpret_cast<dsir_h4*>(reinterpret_cast<_Float16*>(p.hi) + gr * 64 + 4 * fr) = hh;
+              *reinterpret_cast<dsir_h4*>(reinterpret_cast<_Float16*>(p.lo) + gr * 64 + 4 * fr) = ll;
+            }
+            if (fr == 0) {
+              if (p.sq) p.sq[gr] = s2;
+              if (p.packed_init) p.packed_init[gr] = ~0ull;
+            }
+          }
         }
       }
     }

@@ -125,12 +125,19 @@ __device__ __forceinline__ double gn_rstd(double var) {
   r = fma(r, fma(-0.5 * v * r, r, 0.5), r);
   return r;
 }
-// The two limbs are read with agent-scope (sc1) loads: they are produced by memory-side atomics, and inside the deep-level walker
-// (walk.hip) their producers may run in the same launch as the reader - the same pattern as polling a counter.
+// Inside the deep-level walker (walk.hip defines DSIR_GN_STATS_COHERENT before it includes the tile bodies) the producers of a
+// statistic may run in the SAME launch as its reader: the two limbs - results of memory-side atomics - are then read with agent-scope
+// (sc1) loads, the pattern of polling a counter.  Everywhere else the producers belong to an earlier launch and plain loads serve
+// every workgroup of a cloud from its CU's cache (with sc1 loads the split attentive pooling of level 3, whose prologue decodes 256
+// channels' statistics, took 106 us per launch instead of 72).
 __device__ __forceinline__ double gn_stat_get(const double* slot) {
+#ifdef DSIR_GN_STATS_COHERENT
   const double l1 = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const double l0 = __hip_atomic_load(slot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return fma(l1, 0x1p24, l0 * 0x1p-16);
+#else
+  return fma(slot[0], 0x1p24, slot[1] * 0x1p-16);
+#endif
 }
 
 // Butterfly steps across the four 16-lane rows of a wave with the gfx950 VALU lane swaps instead of ds_bpermute
@@ -188,6 +195,24 @@ __device__ __forceinline__ float sqnorm_row16(const float4 v) {
   float s = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
   s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
   return s;
+}
+
+// Four channels fp32 -> the fp16 operand pair of the screened descriptor search (nn_screen.hip, header: x = xh + 2^-11 xl with BOTH
+// parts stored pre-scaled by 2^11, no fp16 subnormals in the high part); *bad is raised when a value is outside the domain of the
+// screening's error bound (|x| > 16 or not finite).  Shared by split_norm_kernel and the aggregation chain's epilogue.
+typedef _Float16 dsir_h4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void screen_split4(const float4 v, dsir_h4& h, dsir_h4& l, int32_t* __restrict__ bad) {
+  const float f[4] = {v.x, v.y, v.z, v.w};
+  if (bad && !(fmaxf(fmaxf(fabsf(f[0]), fabsf(f[1])), fmaxf(fabsf(f[2]), fabsf(f[3]))) <= 16.f &&
+               f[0] == f[0] && f[1] == f[1] && f[2] == f[2] && f[3] == f[3]))
+    *bad = 1;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    _Float16 t = (_Float16)f[k];
+    if (fabsf((float)t) < 6.103515625e-05f) t = (_Float16)0.f;          // no fp16 subnormals in the high part
+    h[k] = t * (_Float16)2048.f;                                         // exact: |t| <= 16 and t is 0 or normal
+    l[k] = (_Float16)((f[k] - (float)t) * 2048.0f);
+  }
 }
 
 }  // namespace dsir

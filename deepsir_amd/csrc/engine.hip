@@ -1007,8 +1007,11 @@ float* run_mlp_feat(dsir_ctx* c, const float* feat0, int clouds, int n, float* o
   return h.p;
 }
 // normalize(mlp_proj(F + mlp_att([xyz; score])))   (model.py:223-234)
-void run_att_proj(dsir_ctx* c, const float* xyz, int64_t xyz_cs, const float* score, const float* F, int clouds, int n,
-                  float* desc) {
+// what the descriptor search needs of the descriptors besides their values (AggArgs: sq, hi / lo, packed_init); the fp16-split chain
+// writes them in its epilogue and returns true, any other path leaves them to the search's own preparation kernels
+struct AggExtras { float* sq = nullptr; void* hi = nullptr; void* lo = nullptr; unsigned long long* packed_init = nullptr; };
+bool run_att_proj(dsir_ctx* c, const float* xyz, int64_t xyz_cs, const float* score, const float* F, int clouds, int n,
+                  float* desc, const AggExtras* ex = nullptr) {
   Sched s{c, c->stream, clouds};
   const NetW& w = c->net;
   static const bool no_agg = tuning_flag("DSIR_NO_AGG");   // A/B switch
@@ -1022,11 +1025,14 @@ void run_att_proj(dsir_ctx* c, const float* xyz, int64_t xyz_cs, const float* sc
     a.desc = desc; a.n = n; a.clouds = clouds;
     // default: the chain's wide layers as fp16-split products on the fp16 matrix pipe (agg_chain_h.hip: fp32 accuracy, not the
     // fp32 kernel's bits); dsir_enable_agg_split(0) / DSIR_AGG_F32: the exact-fp32 chain, bit-identical to the unfused launches below
+    static const bool no_fuse = tuning_flag("DSIR_NO_AGG_EXTRAS");   // A/B switch: the search prepares its operands itself
     if (c->agg_split) {
       for (int k = 0; k < 5; ++k) { a.Wh[k] = c->agg_wh[k]; a.Wl[k] = c->agg_wl[k]; }
-      if (launch_agg_chain_h(a, c->stream)) return;
+      if (ex && !no_fuse) { a.sq = ex->sq; a.hi = ex->hi; a.lo = ex->lo; a.packed_init = ex->packed_init; }
+      if (launch_agg_chain_h(a, c->stream)) return ex && !no_fuse;
+      a.sq = nullptr; a.hi = a.lo = nullptr; a.packed_init = nullptr;
     }
-    if (launch_agg_chain(a, c->stream)) return;
+    if (launch_agg_chain(a, c->stream)) return false;
   }
   const Seg sx = plain_seg(xyz, xyz_cs, 3, 3);
   const Seg ss = plain_seg(score, n, 1, 1);
@@ -1034,6 +1040,7 @@ void run_att_proj(dsir_ctx* c, const float* xyz, int64_t xyz_cs, const float* sc
   for (int k = 1; k < 4; ++k) h = s.linear(w.mlp_att[k], Sched::seg_of(h), nullptr, n, EPI_ACT);
   h = s.linear(w.mlp_att[4], Sched::seg_of(h), nullptr, n, EPI_LINEAR, nullptr, F);
   s.linear(w.mlp_proj, Sched::seg_of(h), nullptr, n, EPI_L2NORM, desc);
+  return false;
 }
 
 int build_pyramid(dsir_ctx* c, const float* points, int stride, int clouds, int n, float* xyz, int32_t* neigh,
@@ -1811,9 +1818,11 @@ static int register_enqueue(dsir_ctx* c, const dsir_pair_batch* in, int n_iter, 
     c->stream = st;
     launch_copy_xyz(pxyz, (int64_t)ps.S * 3, 3, J, P, xyz_cur, (int64_t)J * 3, side);      // xyz_cur = level-0 src coordinates
     float* F_r = run_mlp_feat(c, feat_r, P, K);
-    run_att_proj(c, rxyz, (int64_t)pr.S * 3, score_r, F_r, P, K, desc_r);
+    AggExtras exr;
+    if (screen) { exr.sq = sc_sb; exr.hi = sc_bh; exr.lo = sc_bl; }
+    const bool ref_prepared = run_att_proj(c, rxyz, (int64_t)pr.S * 3, score_r, F_r, P, K, desc_r, screen ? &exr : nullptr);
     if (out->desc_ref) HIP_OK(c, hipMemcpyAsync(out->desc_ref, desc_r, sizeof(float) * P * K * 64, hipMemcpyDeviceToDevice, st));
-    if (screen) {
+    if (screen && !ref_prepared) {
       launch_split16_norm(desc_r, (int64_t)P * K, sc_bh, sc_bl, sc_sb, st);
     }
     if (prune && launch_prune_ref(rxyz, (int64_t)pr.S * 3, desc_r, sc_bh, sc_bl, sc_sb, P, J, K, pr_scratch, st)) return fail(c, "pruned search: sorting the ref side failed");
@@ -1825,7 +1834,14 @@ static int register_enqueue(dsir_ctx* c, const dsir_pair_batch* in, int n_iter, 
     int32_t* idx_out = out->idx ? out->idx + (size_t)it * P * J : idx_it;
     float* logit_out = out->logits ? out->logits + (size_t)it * P * J : logits_it;
     // aggregation of the (transformed) src cloud
-    run_att_proj(c, xyz_cur, (int64_t)J * 3, score_s, F_s, P, J, desc_s);
+    // aggregation of the (transformed) src cloud; its epilogue also leaves what this iteration's search needs of the descriptors
+    // (screened search: the fp16 operand pair + norms; exhaustive search: norms + preset result slots)
+    AggExtras exs;
+    if (!in->forced_idx) {
+      if (screen) { exs.sq = sc_sa; exs.hi = sc_ah; exs.lo = sc_al; }
+      else nn_match_scratch_layout(match_scratch, P, J, K, &exs.sq, &exs.packed_init);
+    }
+    const bool src_prepared = run_att_proj(c, xyz_cur, (int64_t)J * 3, score_s, F_s, P, J, desc_s, in->forced_idx ? nullptr : &exs);
     ws.release(mark1);
     if (out->desc_src)
       HIP_OK(c, hipMemcpyAsync(out->desc_src + (size_t)it * P * J * 64, desc_s, sizeof(float) * P * J * 64, hipMemcpyDeviceToDevice, st));
@@ -1839,7 +1855,7 @@ static int register_enqueue(dsir_ctx* c, const dsir_pair_batch* in, int n_iter, 
       dsir_ctx::MatchEvents* ev = match_event_slot(c);
       if (ev) hipEventRecord(ev->op0, st);
       if (screen) {
-        launch_split16_norm(desc_s, (int64_t)P * J, sc_ah, sc_al, sc_sa, st);
+        if (!src_prepared) launch_split16_norm(desc_s, (int64_t)P * J, sc_ah, sc_al, sc_sa, st);
         ScreenOrder ord;
         if (prune) {
           // an actual distance of every row - to its previous match, to the columns of its nearest tile - bounds its minimum from
@@ -1853,7 +1869,7 @@ static int register_enqueue(dsir_ctx* c, const dsir_pair_batch* in, int n_iter, 
       } else {
         ++c->exhaustive_searches;
         launch_nn_match_ws(desc_s, desc_r, P, J, K, idx_out, match_scratch, st, ev ? ev->k0 : nullptr, ev ? ev->k1 : nullptr,
-                           /*ref_norms_cached=*/it > 0, match_ts_slot(c));
+                           /*ref_norms_cached=*/it > 0, match_ts_slot(c), /*src_norms_ready=*/src_prepared);
       }
       if (ev) hipEventRecord(ev->op1, st);
     }

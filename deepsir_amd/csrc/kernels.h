@@ -196,6 +196,14 @@ struct AggArgs {
   const float *W6 = nullptr, *b6 = nullptr;         // mlp_proj [64][64]
   float* desc = nullptr;                            // [clouds][n][64]
   int n = 0, clouds = 0;
+  // agg_chain_h.hip only, optional: what the descriptor search needs of the descriptors, written by the same epilogue instead of a
+  // second pass over them (nn_screen.hip split_norm_kernel / nn_match.hip sqnorm_kernel: same arithmetic, same bits) -
+  // sq [clouds * n] = |desc|^2; hi / lo [clouds * n][64] fp16 = the screening's operand pair; packed_init [clouds * n] u64 = all ones
+  // (the exhaustive search's result slots); each may be nullptr
+  float* sq = nullptr;
+  void* hi = nullptr;
+  void* lo = nullptr;
+  unsigned long long* packed_init = nullptr;
   // agg_chain_h.hip only: the fp16 split (high, low part; same [Cout][Cin] layout) of W2 .. W6, made at weight load
   const void* Wh[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   const void* Wl[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -341,7 +349,10 @@ void launch_score(const float* feat, const float* logits, int ncls, const float*
 size_t nn_match_scratch_bytes(int pairs, int J, int K);
 void launch_nn_match_ws(const float* a, const float* b, int pairs, int J, int K, int32_t* idx, void* scratch,
                         hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, bool ref_norms_cached = false,
-                        unsigned long long* tstamp = nullptr);   // tstamp: {min start, max end} device-clock slot or nullptr
+                        unsigned long long* tstamp = nullptr,    // tstamp: {min start, max end} device-clock slot or nullptr
+                        bool src_norms_ready = false);           // the src norms and the preset result slots are already in the scratch
+// where launch_nn_match_ws keeps the src norms and the packed result slots inside its scratch (a producer may fill them: AggArgs)
+void nn_match_scratch_layout(void* scratch, int pairs, int J, int K, float** sa, unsigned long long** packed);
 // exhaustive search of all rows of the pairs with gate[pair] >= gate_min and of the rows rowlist[pair][0 .. gate[pair]) of
 // the others; results left in `packed` (preset to all ones)
 void launch_nn_match_gated(const float* a, const float* b, const float* sa, const float* sb, int pairs, int J, int K,

@@ -282,14 +282,22 @@ static void launch_core(const float* a, const float* b, const float* sa, const f
   if (ev1) hipEventRecord(ev1, st);
 }
 
+void nn_match_scratch_layout(void* scratch, int pairs, int J, int K, float** sa, unsigned long long** packed) {
+  float* s = reinterpret_cast<float*>(scratch);
+  const size_t f = ((size_t)pairs * J + (size_t)pairs * K + 3) & ~(size_t)3;
+  *sa = s;
+  *packed = reinterpret_cast<unsigned long long*>(s + f);
+}
+
 void launch_nn_match_ws(const float* a, const float* b, int pairs, int J, int K, int32_t* idx, void* scratch,
-                        hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, bool ref_norms_cached, unsigned long long* tstamp) {
+                        hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, bool ref_norms_cached, unsigned long long* tstamp,
+                        bool src_norms_ready) {
   float* sa = reinterpret_cast<float*>(scratch);
   float* sb = sa + (size_t)pairs * J;
   size_t f = ((size_t)pairs * J + (size_t)pairs * K + 3) & ~(size_t)3;
   unsigned long long* packed = reinterpret_cast<unsigned long long*>(sa + f);
   const int64_t ra = (int64_t)pairs * J, rb = (int64_t)pairs * K;
-  hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)((ra + 15) / 16)), dim3(256), 0, st, a, ra, sa, packed);
+  if (!src_norms_ready) hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)((ra + 15) / 16)), dim3(256), 0, st, a, ra, sa, packed);
   // the ref descriptors are loop invariant in dsir_register: their norms stay in the (persistent) scratch
   if (!ref_norms_cached) hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)((rb + 15) / 16)), dim3(256), 0, st, b, rb, sb, nullptr);
   launch_core(a, b, sa, sb, pairs, J, K, packed, st, ev0, ev1, tstamp, nullptr, 0);

@@ -85,21 +85,8 @@ __device__ __forceinline__ float unorder_bits(unsigned int b) {
   return __uint_as_float((b & 0x80000000u) ? (b & 0x7fffffffu) : ~b);
 }
 
-// four channels fp32 -> fp16 high / low parts (see the header); *bad is raised when one of them is outside the domain of
-// the error bound (|x| > 16 or not finite)
-__device__ __forceinline__ void split4(const float4 v, h4& h, h4& l, int32_t* __restrict__ bad) {
-  const float f[4] = {v.x, v.y, v.z, v.w};
-  if (bad && !(fmaxf(fmaxf(fabsf(f[0]), fabsf(f[1])), fmaxf(fabsf(f[2]), fabsf(f[3]))) <= 16.f &&
-               f[0] == f[0] && f[1] == f[1] && f[2] == f[2] && f[3] == f[3]))
-    *bad = 1;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    _Float16 t = (_Float16)f[k];
-    if (fabsf((float)t) < 6.103515625e-05f) t = (_Float16)0.f;          // no fp16 subnormals in the high part
-    h[k] = t * (_Float16)2048.f;                                         // exact: |t| <= 16 and t is 0 or normal
-    l[k] = (_Float16)((f[k] - (float)t) * 2048.0f);
-  }
-}
+// four channels fp32 -> fp16 high / low parts (see the header): device_utils.h, screen_split4 (shared with agg_chain_h.hip's epilogue)
+__device__ __forceinline__ void split4(const float4 v, h4& h, h4& l, int32_t* __restrict__ bad) { screen_split4(v, h, l, bad); }
 
 // x [rows][64] fp32 -> hi, lo [rows][64] fp16; one thread per 4 channels
 __global__ __launch_bounds__(256) void split16_kernel(const float* __restrict__ x, int64_t n4, _Float16* __restrict__ hi,

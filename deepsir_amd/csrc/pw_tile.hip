@@ -26,7 +26,7 @@ namespace {
 
 template <int RT, int EPI, int SC = 0, bool H = false>
 __global__ __launch_bounds__(256) void pw_tile_kernel(const GemmArgs p) {
-  __shared__ __attribute__((aligned(16))) char smem[pw_tile_smem_bytes<RT, EPI, H>()];
+  __shared__ __attribute__((aligned(16))) char smem[pw_tile_smem_bytes<RT, EPI, H, SC>()];
   pw_tile_body<RT, EPI, SC, H>(p, blockIdx.x, blockIdx.y, blockIdx.z, smem);
 }
 

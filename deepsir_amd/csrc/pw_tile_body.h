@@ -60,11 +60,14 @@ __device__ __forceinline__ RowOff row_off(const GemmArgs& p, int cloud, int row)
 }
 
 // LDS of one pw_tile workgroup (bytes), in the order the body carves it
-template <int RT, int EPI, bool H>
+// SC = 2 (cached scores: no contraction) stages no operand tile at all: its workgroups keep the few KB of scale / shift tables and
+// with them the occupancy a latency-bound gather kernel lives on (with the tiles' 60 KB reserved it ran 106 us instead of 72)
+template <int RT, int EPI, bool H, int SC = 0>
 constexpr size_t pw_tile_smem_bytes() {
   constexpr int BM = 64 * RT;
-  return smem_pad(sizeof(float) * (H ? 1 : 2) * (H ? 4 : BM * LDS_LD)) + smem_pad(sizeof(float) * (H ? 1 : 2) * (H ? 4 : BN * LDS_LD)) +
-         smem_pad(sizeof(_Float16) * (H ? 2 : 1) * 2 * (H ? BM * LDH : 8)) + smem_pad(sizeof(_Float16) * (H ? 2 : 1) * 2 * (H ? BN * LDH : 8)) +
+  constexpr int NB = SC == 2 ? 0 : 1;     // tile buffers present?
+  return NB * (smem_pad(sizeof(float) * (H ? 1 : 2) * (H ? 4 : BM * LDS_LD)) + smem_pad(sizeof(float) * (H ? 1 : 2) * (H ? 4 : BN * LDS_LD)) +
+               smem_pad(sizeof(_Float16) * (H ? 2 : 1) * 2 * (H ? BM * LDH : 8)) + smem_pad(sizeof(_Float16) * (H ? 2 : 1) * 2 * (H ? BN * LDH : 8))) +
          2 * smem_pad(sizeof(float) * MAXC) + 2 * smem_pad(sizeof(float) * (EPI == EPI_ATT2 ? 128 : 1)) +
          smem_pad(sizeof(float) * (EPI == EPI_GN ? 4 * BN * 2 : 1));
 }
@@ -75,10 +78,11 @@ template <int RT, int EPI, int SC = 0, bool H = false>   // SC: GemmArgs::s2_mod
 __device__ __forceinline__ void pw_tile_body(const GemmArgs& p, const int bx, const int by, const int cloud, char* smem) {
   constexpr int BM = 64 * RT;
   constexpr int AV = BM / 32;     // float4 A loads per thread per chunk (BM*32/4/256)
-  auto As = smem_carve<float[H ? 4 : BM * LDS_LD]>(smem, H ? 1 : 2);
-  auto Ws = smem_carve<float[H ? 4 : BN * LDS_LD]>(smem, H ? 1 : 2);
-  auto AsH = smem_carve<_Float16[2][H ? BM * LDH : 8]>(smem, H ? 2 : 1);      // [buffer][high | low]
-  auto WsH = smem_carve<_Float16[2][H ? BN * LDH : 8]>(smem, H ? 2 : 1);
+  constexpr int NB = SC == 2 ? 0 : 1;     // SC = 2 never stages a tile (pw_tile_smem_bytes)
+  auto As = smem_carve<float[H ? 4 : BM * LDS_LD]>(smem, NB * (H ? 1 : 2));
+  auto Ws = smem_carve<float[H ? 4 : BN * LDS_LD]>(smem, NB * (H ? 1 : 2));
+  auto AsH = smem_carve<_Float16[2][H ? BM * LDH : 8]>(smem, NB * (H ? 2 : 1));      // [buffer][high | low]
+  auto WsH = smem_carve<_Float16[2][H ? BN * LDH : 8]>(smem, NB * (H ? 2 : 1));
   float* s_sc = smem_carve<float>(smem, MAXC);
   float* s_sh = smem_carve<float>(smem, MAXC);
   float* s_fsc = smem_carve<float>(smem, EPI == EPI_ATT2 ? 128 : 1);   // EPI_ATT2: GroupNorm scale/shift of the gathered-feature half

@@ -32,6 +32,7 @@
 // Bits: a phase's tiles are computed by the same code on the same operands, each output element by the same chain of operations,
 // the statistics meet in exact atomics (device_utils.h) - the walker's results equal the separate launches' bit for bit
 // (tests/test_gpu_walk.py), so it may be switched per launch size without changing a pair's result.
+#define DSIR_GN_STATS_COHERENT 1      // device_utils.h, gn_stat_get: statistics produced inside this launch are read with sc1 loads
 #include "kernels.h"
 #include "device_utils.h"
 #include "pw_tile_body.h"

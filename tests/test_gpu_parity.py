@@ -751,6 +751,28 @@ def test_register_screened_equals_exhaustive(tmp_path):
         assert np.array_equal(a[k], b[k]), f"{k} differs between the screened and the exhaustive arg-min"
 
 
+@pytest.mark.parametrize("pairs,points", [(10, 5000), (1, 2048), (3, 1357)])
+def test_search_operands_from_the_aggregation_epilogue_are_the_same_bits(tmp_path, pairs, points):
+    """Round 5: the aggregation chain's epilogue writes what the descriptor search needs of the descriptors - |desc|^2, the screening's
+    fp16 operand pair, the exhaustive search's preset slots - instead of a second pass over them (split_norm_kernel / sqnorm_kernel).
+    Same arithmetic in the same order: a registration equals, bit for bit, the one whose search prepares its operands itself
+    (DSIR_NO_AGG_EXTRAS=1; read once per process, hence two processes) - in the screened regime (10 x 5000) and in the exhaustive
+    one (small launches), ragged row counts included."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for name, extra in (("fused", {}), ("separate", {"DSIR_TUNING": "1", "DSIR_NO_AGG_EXTRAS": "1"})):
+        out = str(tmp_path / f"{name}.npz")
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "register_dump.py"), out, str(pairs), str(points), "4"],
+                           env=dict(os.environ, **extra), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(out))
+    a, b = outs
+    assert int(a["screened_searches"]) == int(b["screened_searches"]) == (4 if pairs == 10 else 0)
+    for k in ("idx", "logits", "transforms"):
+        assert np.array_equal(a[k], b[k]), f"{k} differs"
+
+
 def test_screened_argmin_out_of_domain_inputs():
     """Elements beyond the fp16 range or not finite void the screening bound: split16 raises its flag and every pair is
     searched by the exhaustive kernel, so the result still equals dsir_nn_match."""
