@@ -1104,6 +1104,36 @@ int build_pyramid(dsir_ctx* c, const float* points, int stride, int clouds, int 
     launch_copy_sub_levels(neigh, neigh_cs, lv, clouds, sub, sub_cs, st);
     return 0;
   }
+  // Few clouds in flight (one pair: the reference's evaluation mode, test.py:56): every level's searches read the input points alone,
+  // so the pyramid is THREE launches instead of a chain of ten - the grids of the large levels, their searches, and everything
+  // else (the interpolation searches of all levels, the 16-NN of the small levels).  The same kernels' bodies: same bits.
+  static const bool no_merge = tuning_flag("DSIR_NO_PYRAMID_MERGE");   // A/B switch
+  if (!no_merge && !any_nn1_grid && g.num_layers <= KnnSmallJobs::kMax / 2) {
+    int ngrid = 0, gn[4];
+    int32_t* gout[4];
+    KnnSmallJobs jobs{};
+    bool ok = true;
+    for (int l = 0; l < g.num_layers && ok; ++l) {
+      if (p.nl[l] >= grid_min && !no_grid) {
+        ok = knn16_grid_is_small(p.nl[l], clouds) && ngrid < 4;
+        if (ok) { gn[ngrid] = p.nl[l]; gout[ngrid] = neigh + (int64_t)p.off[l] * kKnn; ++ngrid; }
+      } else {
+        ok = knn16_takes_wave_kernel(p.nl[l], clouds);
+        if (ok) jobs.job[jobs.njobs++] = {1, p.nl[l], 0, neigh + (int64_t)p.off[l] * kKnn, neigh_cs, 0};
+      }
+      jobs.job[jobs.njobs++] = {0, p.nl[l], p.nl[l + 1], interp + p.off[l], (int64_t)p.S, 0};
+    }
+    if (ok) {
+      void* gscr[4];
+      for (int k = 0; k < ngrid; ++k) gscr[k] = c->ws.raw(knn_grid_scratch_bytes(clouds, gn[k]));
+      if (c->ws.overflow) return fail(c, "workspace exhausted in the KNN pyramid");
+      if (ngrid) launch_knn16_grid_levels(points, (int64_t)n * stride, stride, ngrid, gn, clouds, gout, neigh_cs, gscr, st);
+      launch_knn_small_levels(points, (int64_t)n * stride, stride, clouds, jobs, st);
+      c->ws.release(mark);
+      launch_copy_sub_levels(neigh, neigh_cs, lv, clouds, sub, sub_cs, st);
+      return 0;
+    }
+  }
   for (int l = 0; l < g.num_layers; ++l) {
     if (p.nl[l] >= grid_min && !no_grid) {
       // large levels: exact grid-pruned search (knn_grid.hip); same bits as the brute force

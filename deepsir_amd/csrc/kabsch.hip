@@ -209,6 +209,116 @@ __global__ __launch_bounds__(NTHR) void kabsch_kernel(const KabschArgs a) {
   }
 }
 
+// ---- clouds of up to TR x 1024 points: the same kernel with the points HELD IN REGISTERS between the passes.  With one pair in
+// flight (the reference's evaluation mode) the solve sits in the dependent chain of every iteration, and each pass of kabsch_kernel
+// opens with its own weight -> index -> ref-point load chain (three round trips to L2 plus the apply step's fourth); here the chain
+// is paid once.  A thread owns the same points i = tid, tid + 1024, .. and adds them in the same order: same bits as kabsch_kernel.
+template <int TR>
+__global__ __launch_bounds__(NTHR) void kabsch_reg_kernel(const KabschArgs a) {
+  __shared__ double sh[NWAVE * 9 + 9];
+  __shared__ float sT[12];
+  const int pair = blockIdx.x;
+  const int m = a.m;
+  if (a.skip && a.skip[pair]) {   // block-uniform: frozen pair (ICP converged): identity step, cumulative transform carried over
+    if (threadIdx.x == 0) {
+      const float I[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+      for (int k = 0; k < 12; ++k) a.T[(int64_t)pair * 12 + k] = I[k];
+      if (a.T_cum) {
+        float* out = a.T_cum + pair * a.T_stride;
+        const float* P = a.T_prev ? a.T_prev + pair * a.T_stride : I;
+        for (int k = 0; k < 12; ++k) out[k] = P[k];
+      }
+    }
+    return;
+  }
+  const int ld = a.ref_ld ? a.ref_ld : 3;
+  const float* src = a.src + pair * a.src_stride;
+  const float* ref = a.ref + pair * a.ref_stride;
+  const int32_t* idx = a.idx ? a.idx + (int64_t)pair * m : nullptr;
+  const float* wl = a.w + (int64_t)pair * m;
+
+  float w[TR], s[TR][3], t[TR][3];
+#pragma unroll
+  for (int k = 0; k < TR; ++k) {
+    const int i = threadIdx.x + k * NTHR;
+    w[k] = 0.f;
+    s[k][0] = s[k][1] = s[k][2] = t[k][0] = t[k][1] = t[k][2] = 0.f;
+    if (i < m) {
+      const int64_t j = idx ? idx[i] : i;
+      w[k] = wl[i];
+      t[k][0] = ref[j * ld]; t[k][1] = ref[j * ld + 1]; t[k][2] = ref[j * ld + 2];
+      s[k][0] = src[(int64_t)i * 3]; s[k][1] = src[(int64_t)i * 3 + 1]; s[k][2] = src[(int64_t)i * 3 + 2];
+    }
+  }
+  if (a.sigmoid) {
+#pragma unroll
+    for (int k = 0; k < TR; ++k) w[k] = 1.f / (1.f + expf(-w[k]));
+  }
+
+  // pass 1: S = sum |w|
+  double v1[1] = {0.0};
+#pragma unroll
+  for (int k = 0; k < TR; ++k)
+    if (threadIdx.x + k * NTHR < m) v1[0] += (double)fabsf(w[k]);
+  block_sum<1>(v1, sh);
+  const float den = (float)v1[0] + 1e-16f;   // model.py:35 (fp32 sum + _EPS)
+
+  // pass 2: weighted centroids
+  double v6[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int k = 0; k < TR; ++k)
+    if (threadIdx.x + k * NTHR < m) {
+      w[k] = w[k] / den;          // wn: the same quotient both passes of kabsch_kernel form
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        v6[c] += (double)__fmul_rn(s[k][c], w[k]);
+        v6[3 + c] += (double)__fmul_rn(t[k][c], w[k]);
+      }
+    }
+  block_sum<6>(v6, sh);
+  const float cs[3] = {(float)v6[0], (float)v6[1], (float)v6[2]};
+  const float ct[3] = {(float)v6[3], (float)v6[4], (float)v6[5]};
+
+  // pass 3: covariance H[a][b] = sum (s_a - cs_a) * ((t_b - ct_b) * wn)
+  double v9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int k = 0; k < TR; ++k)
+    if (threadIdx.x + k * NTHR < m) {
+      float sc[3], tw[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        sc[c] = __fsub_rn(s[k][c], cs[c]);
+        tw[c] = __fmul_rn(__fsub_rn(t[k][c], ct[c]), w[k]);
+      }
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v9[r * 3 + c] += (double)__fmul_rn(sc[r], tw[c]);
+    }
+  block_sum<9>(v9, sh);
+
+  if (threadIdx.x == 0) kabsch_solve(a, pair, v9, cs, ct, sT);
+  __syncthreads();
+  // apply: p' = p R^T + t (se3_torch.py:60-77); the matched ref points
+  if (a.src_out || a.matched_out) {
+    float* so = a.src_out ? a.src_out + pair * a.src_out_stride : nullptr;
+    float* mo = a.matched_out ? a.matched_out + (int64_t)pair * m * 3 : nullptr;
+#pragma unroll
+    for (int k = 0; k < TR; ++k) {
+      const int i = threadIdx.x + k * NTHR;
+      if (i >= m) continue;
+      if (mo) { mo[(int64_t)i * 3] = t[k][0]; mo[(int64_t)i * 3 + 1] = t[k][1]; mo[(int64_t)i * 3 + 2] = t[k][2]; }
+      if (so) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          const float d = fmaf(s[k][2], sT[r * 4 + 2], fmaf(s[k][1], sT[r * 4 + 1], __fmul_rn(s[k][0], sT[r * 4 + 0])));
+          so[(int64_t)i * 3 + r] = __fadd_rn(d, sT[r * 4 + 3]);
+        }
+      }
+    }
+  }
+}
+
 // ---- large clouds: the same three passes over CHUNKS of 4096 points, one workgroup per (chunk, pair) and pass, partial sums
 // in fp64 in a.part [pairs][chunks][16] = {S, c_s, c_t, H}; every pass adds the chunks' partials in chunk order (every
 // workgroup for itself: a few dozen doubles), so the result does not depend on the grid.  One workgroup per pair walks
@@ -369,7 +479,11 @@ void launch_kabsch(const KabschArgs& a, hipStream_t st) {
     if (a.src_out || a.matched_out) hipLaunchKernelGGL(kabsch_apply_kernel, dim3((a.m + 255) / 256, a.pairs), dim3(256), 0, st, a);
     return;
   }
-  hipLaunchKernelGGL(kabsch_kernel, dim3(a.pairs), dim3(NTHR), 0, st, a);
+  // (the choice depends on the cloud size alone, and the two kernels give the same bits)
+  static const bool no_reg = tuning_flag("DSIR_KABSCH_STREAM");      // A/B switch: the streaming kernel for every size
+  if (a.m <= 5 * NTHR && !no_reg) hipLaunchKernelGGL(kabsch_reg_kernel<5>, dim3(a.pairs), dim3(NTHR), 0, st, a);
+  else if (a.m <= 8 * NTHR && !no_reg) hipLaunchKernelGGL(kabsch_reg_kernel<8>, dim3(a.pairs), dim3(NTHR), 0, st, a);
+  else hipLaunchKernelGGL(kabsch_kernel, dim3(a.pairs), dim3(NTHR), 0, st, a);
 }
 
 }  // namespace dsir

@@ -310,10 +310,28 @@ void launch_copy_pyramid_idx(const PyramidIdxCopy& a, int clouds, hipStream_t st
 // KNN (data_base.py:153-183): one level.  support = first n_support points of `pts`.
 void launch_knn16(const float* pts, int64_t cloud_stride, int stride, int n, int clouds, int32_t* out,
                   int64_t out_cloud_stride, hipStream_t st);
+// few clouds in flight: the interpolation searches of all levels and the 16-NN searches of the small levels in ONE launch (knn.hip)
+struct KnnSmallJobs {
+  static constexpr int kMax = 8;
+  struct Job {
+    int kind;            // 0: nearest support point (launch_nn1), 1: 16-NN, one wave per query (launch_knn16 for small levels)
+    int n, n_support;    // queries (= the level's points); kind 0: support = the first n_support points
+    int32_t* out;        // cloud 0's output
+    int64_t ocs;         // ints between clouds in out
+    int b0;              // first workgroup (filled by the launcher)
+  } job[kMax];
+  int njobs;
+};
+bool knn16_takes_wave_kernel(int n, int clouds);      // launch_knn16 would run the one-wave-per-query kernel
+void launch_knn_small_levels(const float* pts, int64_t cloud_stride, int stride, int clouds, KnnSmallJobs& jobs, hipStream_t st);
 // exact grid-pruned variant for large levels (knn_grid.hip); scratch from knn_grid_scratch_bytes
 size_t knn_grid_scratch_bytes(int clouds, int n);
 void launch_knn16_grid(const float* pts, int64_t cloud_stride, int stride, int n, int clouds, int32_t* out,
                        int64_t out_cloud_stride, void* scratch, hipStream_t st);
+// few clouds in flight: several levels (each knn16_grid_is_small) in two launches - all grids, all searches; GridLevelsArgs::kMax = 4 levels
+bool knn16_grid_is_small(int n, int clouds);
+void launch_knn16_grid_levels(const float* pts, int64_t cloud_stride, int stride, int nlev, const int* n, int clouds, int32_t* const* out,
+                              int64_t out_cloud_stride, void* const* scratch, hipStream_t st);
 void launch_nn1(const float* pts, int64_t cloud_stride, int stride, int n_query, int n_support, int clouds,
                 int32_t* out, int64_t out_cloud_stride, hipStream_t st);
 // the same search through the grid launch_knn16_grid has just built over the first n_support points (its scratch); same bits

@@ -158,13 +158,11 @@ __global__ __launch_bounds__(QB * NW) void knn16_kernel(const float* __restrict_
 // of the wave are extracted by 16 rounds of a wave-wide minimum (keys are unique, so each round removes exactly one).
 // Same keys, same order as Top16 / oracle/knn.py: distance, then lower index - bit-identical output.
 constexpr int WQ_MAX = 16;    // support points per lane: n <= 1024
-__global__ __launch_bounds__(256) void knn16_wave_kernel(const float* __restrict__ pts, int64_t cs, int stride, int n,
-                                                         int32_t* __restrict__ out, int64_t ocs) {
+// body: query block bx of one cloud (P its points, out its lists); no LDS, no barrier
+__device__ __forceinline__ void knn16_wave_body(const float* __restrict__ P, int stride, int n, int32_t* __restrict__ out, int bx) {
   const int lane = threadIdx.x & 63;
-  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int cloud = blockIdx.y;
+  const int q = bx * 4 + (threadIdx.x >> 6);
   if (q >= n) return;                                  // wave-uniform
-  const float* P = pts + cloud * cs;
   const float qx = P[(int64_t)q * stride], qy = P[(int64_t)q * stride + 1], qz = P[(int64_t)q * stride + 2];
   unsigned long long key[WQ_MAX];
 #pragma unroll
@@ -193,19 +191,27 @@ __global__ __launch_bounds__(256) void knn16_wave_kernel(const float* __restrict
 #pragma unroll
     for (int i = 0; i < WQ_MAX; ++i) key[i] = key[i] == w ? ~0ull : key[i];      // unique keys: removes exactly the winner
   }
-  if (lane < kKnn) out[cloud * ocs + (int64_t)q * kKnn + lane] = mine;
+  if (lane < kKnn) out[(int64_t)q * kKnn + lane] = mine;
+}
+__global__ __launch_bounds__(256) void knn16_wave_kernel(const float* __restrict__ pts, int64_t cs, int stride, int n,
+                                                         int32_t* __restrict__ out, int64_t ocs) {
+  knn16_wave_body(pts + blockIdx.y * cs, stride, n, out + blockIdx.y * ocs, blockIdx.x);
 }
 
 // nearest support point (support = first n_support points) of every query point
-__global__ __launch_bounds__(QB * NW) void nn1_kernel(const float* __restrict__ pts, int64_t cs, int stride, int n_query,
-                                                      int n_support, int32_t* __restrict__ out, int64_t ocs) {
-  __shared__ float4 tile[NW][TILE];
-  __shared__ float md[NW][QB];
-  __shared__ int mi[NW][QB];
+struct Nn1Smem {
+  float4 tile[NW][TILE];
+  float md[NW][QB];
+  int mi[NW][QB];
+};
+// body: query block bx of one cloud (P its points, out its list); all QB * NW threads of the workgroup
+__device__ __forceinline__ void nn1_body(const float* __restrict__ P, int stride, int n_query, int n_support, int32_t* __restrict__ out, int bx,
+                                         Nn1Smem& sm) {
+  auto& tile = sm.tile;
+  auto& md = sm.md;
+  auto& mi = sm.mi;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int cloud = blockIdx.y;
-  const float* P = pts + cloud * cs;
-  const int q = blockIdx.x * QB + lane;
+  const int q = bx * QB + lane;
   float qx = 0.f, qy = 0.f, qz = 0.f;
   if (q < n_query) { qx = P[(int64_t)q * stride]; qy = P[(int64_t)q * stride + 1]; qz = P[(int64_t)q * stride + 2]; }
   const int slice = (n_support + NW - 1) / NW;
@@ -237,20 +243,54 @@ __global__ __launch_bounds__(QB * NW) void nn1_kernel(const float* __restrict__ 
       const float d = md[s][lane];
       if (d < bd) { bd = d; bi = mi[s][lane]; }
     }
-    out[cloud * ocs + q] = bi < 0 ? 0 : bi;   // no finite distance (non-finite coordinates): stay in range
+    out[q] = bi < 0 ? 0 : bi;   // no finite distance (non-finite coordinates): stay in range
   }
+}
+__global__ __launch_bounds__(QB * NW) void nn1_kernel(const float* __restrict__ pts, int64_t cs, int stride, int n_query,
+                                                      int n_support, int32_t* __restrict__ out, int64_t ocs) {
+  __shared__ Nn1Smem sm;
+  nn1_body(pts + blockIdx.y * cs, stride, n_query, n_support, out + blockIdx.y * ocs, blockIdx.x, sm);
+}
+
+// Few clouds in flight (one pair: the reference's evaluation mode): every level's points are a prefix of the input cloud
+// (data_base.py:166-172), so the interpolation searches of ALL levels and the 16-NN searches of the small levels read the input
+// alone and are independent of one another - ONE launch for what were six dependent ones in the pair's chain.  Job j of the table =
+// (kind, level sizes, output, first workgroup); a workgroup finds its job by its index and runs the unchanged body: same bits.
+__global__ __launch_bounds__(256) void knn_small_levels_kernel(const float* __restrict__ pts, int64_t cs, int stride, const KnnSmallJobs J) {
+  static_assert(QB * NW == 256, "both bodies run 256 threads");
+  __shared__ Nn1Smem sm;
+  int j = 0;
+#pragma unroll
+  for (int k = 1; k < KnnSmallJobs::kMax; ++k) j += (k < J.njobs && (int)blockIdx.x >= J.job[k].b0) ? 1 : 0;
+  const KnnSmallJobs::Job& jb = J.job[j];
+  const int bx = (int)blockIdx.x - jb.b0;
+  const float* P = pts + blockIdx.y * cs;
+  if (jb.kind == 0) nn1_body(P, stride, jb.n, jb.n_support, jb.out + blockIdx.y * jb.ocs, bx, sm);
+  else knn16_wave_body(P, stride, jb.n, jb.out + blockIdx.y * jb.ocs, bx);
 }
 
 }  // namespace
 
 void launch_knn16(const float* pts, int64_t cs, int stride, int n, int clouds, int32_t* out, int64_t ocs, hipStream_t st) {
   // small level, few clouds: one wave per query (same bits); otherwise one lane per query
-  if (n <= 64 * WQ_MAX && (int64_t)clouds * n <= 4096) {
+  if (knn16_takes_wave_kernel(n, clouds)) {
     hipLaunchKernelGGL(knn16_wave_kernel, dim3((n + 3) / 4, clouds), dim3(256), 0, st, pts, cs, stride, n, out, ocs);
     return;
   }
   dim3 grid((n + QB - 1) / QB, clouds);
   hipLaunchKernelGGL(knn16_kernel, grid, dim3(QB * NW), 0, st, pts, cs, stride, n, out, ocs);
+}
+
+bool knn16_takes_wave_kernel(int n, int clouds) { return n <= 64 * WQ_MAX && (int64_t)clouds * n <= 4096; }
+
+void launch_knn_small_levels(const float* pts, int64_t cs, int stride, int clouds, KnnSmallJobs& J, hipStream_t st) {
+  int b = 0;
+  for (int k = 0; k < J.njobs; ++k) {
+    J.job[k].b0 = b;
+    b += J.job[k].kind == 0 ? (J.job[k].n + QB - 1) / QB : (J.job[k].n + 3) / 4;
+  }
+  if (b == 0 || clouds <= 0) return;
+  hipLaunchKernelGGL(knn_small_levels_kernel, dim3(b, clouds), dim3(256), 0, st, pts, cs, stride, J);
 }
 
 void launch_nn1(const float* pts, int64_t cs, int stride, int n_query, int n_support, int clouds, int32_t* out,

@@ -160,16 +160,15 @@ __global__ __launch_bounds__(256) void grid_scatter_kernel(const float* __restri
 // order through LDS cursors.  The order of the points inside a cell follows the arrival of the atomics - as in the five-launch form;
 // the searches do not depend on it (lexicographic top-16 / top-1).  kBuildMaxCells ints of LDS twice.
 constexpr int kBuildMaxCells = 8256;      // n <= 16384
-__global__ __launch_bounds__(1024) void grid_build_kernel(const float* __restrict__ pts, int64_t cs, int stride, int n, int max_cells,
-                                                          GridParams* __restrict__ gp, int* __restrict__ starts,
-                                                          float4* __restrict__ sorted) {
+// body: one 1024-thread workgroup builds the grid of one cloud
+__device__ __forceinline__ void grid_build_body(const float* __restrict__ pts, int64_t cs, int stride, int n, int max_cells,
+                                                GridParams* __restrict__ gp, int* __restrict__ starts, float4* __restrict__ sorted, const int cloud) {
   __shared__ float red[6][16];
   __shared__ GridParams s_g;
   __shared__ int s_cnt[kBuildMaxCells];
   __shared__ int s_cur[kBuildMaxCells];
   __shared__ int wsum[16];
   __shared__ int carry_s;
-  const int cloud = blockIdx.x;
   const float* P = pts + cloud * cs;
   // ---- bounding box and grid (grid_setup_kernel, verbatim)
   float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -259,6 +258,21 @@ __global__ __launch_bounds__(1024) void grid_build_kernel(const float* __restric
     const int pos = atomicAdd(&s_cur[cell_of_pt(i)], 1);
     SO[pos] = make_float4(P[(int64_t)i * stride], P[(int64_t)i * stride + 1], P[(int64_t)i * stride + 2], __int_as_float(i));
   }
+}
+__global__ __launch_bounds__(1024) void grid_build_kernel(const float* __restrict__ pts, int64_t cs, int stride, int n, int max_cells,
+                                                          GridParams* __restrict__ gp, int* __restrict__ starts,
+                                                          float4* __restrict__ sorted) {
+  grid_build_body(pts, cs, stride, n, max_cells, gp, starts, sorted, blockIdx.x);
+}
+// the grids of SEVERAL levels of the same clouds in one launch (few clouds in flight: launch_knn16_grid_levels); blockIdx.y = level
+struct GridLevelsArgs {
+  static constexpr int kMax = 4;
+  struct Lev { int n, max_cells; GridParams* gp; int* starts; float4* sorted; int32_t* out; int b0; } lev[kMax];
+  int nlev;
+};
+__global__ __launch_bounds__(1024) void grid_build_levels_kernel(const float* __restrict__ pts, int64_t cs, int stride, const GridLevelsArgs A) {
+  const GridLevelsArgs::Lev& L = A.lev[blockIdx.y];
+  grid_build_body(pts, cs, stride, L.n, L.max_cells, L.gp, L.starts, L.sorted, blockIdx.x);
 }
 
 // Sorted top-16 under the lexicographic order (distance, index).  A squared distance is a non-negative float, whose
@@ -444,15 +458,15 @@ __global__ __launch_bounds__(KB) __attribute__((amdgpu_waves_per_eu(3, 3))) void
 // little longer.  At the end the four sorted lists meet in a 4-way merge by lane 0 of the quad.  Keys are unique
 // (distance bits << 32 | index), so the 16 smallest keys - hence the output - are the one-lane kernel's, bit for bit.
 constexpr int KB4 = 64;      // threads per block = 16 queries
-__global__ __launch_bounds__(KB4) void grid_knn4_kernel(const float4* __restrict__ sorted, const int* __restrict__ starts,
-                                                        const GridParams* __restrict__ gp, int max_cells, int n,
-                                                        int32_t* __restrict__ out, int64_t ocs) {
+// body: query block bx (16 queries) of one cloud
+__device__ __forceinline__ void grid_knn4_body(const float4* __restrict__ sorted, const int* __restrict__ starts,
+                                               const GridParams* __restrict__ gp, int max_cells, int n,
+                                               int32_t* __restrict__ out, int64_t ocs, const int bx, const int cloud) {
   __shared__ float qd[QCAP][KB4];
   __shared__ int qi[QCAP][KB4];
   __shared__ unsigned long long mk[KB4][kKnn + 1];      // the quads' lists for the merge (+1: bank spread)
-  const int cloud = blockIdx.y;
   const int tid = threadIdx.x, sub = tid & 3;
-  const int t = blockIdx.x * (KB4 / 4) + (tid >> 2);
+  const int t = bx * (KB4 / 4) + (tid >> 2);
   const bool live = t < n;
   const GridParams g = gp[cloud];
   const float4* S = sorted + (int64_t)cloud * n;
@@ -554,6 +568,19 @@ __global__ __launch_bounds__(KB4) void grid_knn4_kernel(const float4* __restrict
       o[k] = (m == sentinel || i == 0x7fffffff) ? qidx : i;
     }
   }
+}
+__global__ __launch_bounds__(KB4) void grid_knn4_kernel(const float4* __restrict__ sorted, const int* __restrict__ starts,
+                                                        const GridParams* __restrict__ gp, int max_cells, int n,
+                                                        int32_t* __restrict__ out, int64_t ocs) {
+  grid_knn4_body(sorted, starts, gp, max_cells, n, out, ocs, blockIdx.x, blockIdx.y);
+}
+// the searches of several levels in one launch: workgroup -> (level, query block) by the levels' first workgroups
+__global__ __launch_bounds__(KB4) void grid_knn4_levels_kernel(const GridLevelsArgs A, int64_t ocs) {
+  int l = 0;
+#pragma unroll
+  for (int k = 1; k < GridLevelsArgs::kMax; ++k) l += (k < A.nlev && (int)blockIdx.x >= A.lev[k].b0) ? 1 : 0;
+  const GridLevelsArgs::Lev& L = A.lev[l];
+  grid_knn4_body(L.sorted, L.starts, L.gp, L.max_cells, L.n, L.out, ocs, (int)blockIdx.x - L.b0, blockIdx.y);
 }
 
 }  // namespace
@@ -670,6 +697,37 @@ void launch_knn16_grid(const float* pts, int64_t cs, int stride, int n, int clou
     hipLaunchKernelGGL(grid_knn_kernel, dim3((n + KB - 1) / KB, clouds), dim3(KB), 0, st, sorted, starts, gp, max_cells, n, out, ocs);
   else
     hipLaunchKernelGGL(grid_knn4_kernel, dim3((n + KB4 / 4 - 1) / (KB4 / 4), clouds), dim3(KB4), 0, st, sorted, starts, gp, max_cells, n, out, ocs);
+}
+
+// would launch_knn16_grid take the one-launch construction and the four-lanes-per-query search for this level?
+bool knn16_grid_is_small(int n, int clouds) {
+  static const bool no_build = tuning_flag("DSIR_GRID_NO_BUILD");
+  return !no_build && n / 2 + 64 <= kBuildMaxCells && (int64_t)((n + KB - 1) / KB) * clouds < 1024;
+}
+
+// Few clouds in flight: the grid-pruned searches of several levels (each knn16_grid_is_small) in TWO launches - all the grids, then all
+// the searches - instead of two per level in the pair's dependent chain.  Same kernels' bodies on the same operands: same bits.
+void launch_knn16_grid_levels(const float* pts, int64_t cs, int stride, int nlev, const int* n, int clouds, int32_t* const* out, int64_t ocs,
+                              void* const* scratch, hipStream_t st) {
+  GridLevelsArgs A{};
+  A.nlev = nlev;
+  int b = 0;
+  for (int l = 0; l < nlev; ++l) {
+    const int max_cells = n[l] / 2 + 64;
+    char* p = reinterpret_cast<char*>(scratch[l]);
+    auto take = [&](size_t bytes) { char* r = p; p += (bytes + 255) & ~(size_t)255; return r; };
+    GridLevelsArgs::Lev& L = A.lev[l];
+    L.n = n[l]; L.max_cells = max_cells; L.out = out[l]; L.b0 = b;
+    L.gp = reinterpret_cast<GridParams*>(take((size_t)clouds * sizeof(GridParams)));
+    take((size_t)clouds * n[l] * sizeof(int));                   // cell_of   (the carving of launch_knn16_grid)
+    take((size_t)clouds * max_cells * sizeof(int));              // counts
+    L.starts = reinterpret_cast<int*>(take((size_t)clouds * (max_cells + 1) * sizeof(int)));
+    take((size_t)clouds * max_cells * sizeof(int));              // cursor
+    L.sorted = reinterpret_cast<float4*>(take((size_t)clouds * n[l] * sizeof(float4)));
+    b += (n[l] + KB4 / 4 - 1) / (KB4 / 4);
+  }
+  hipLaunchKernelGGL(grid_build_levels_kernel, dim3(clouds, nlev), dim3(1024), 0, st, pts, cs, stride, A);
+  hipLaunchKernelGGL(grid_knn4_levels_kernel, dim3(b, clouds), dim3(KB4), 0, st, A, ocs);
 }
 
 // nn1 through the grid launch_knn16_grid(.., n = n_support, .., scratch) has left in `scratch` (same carving)

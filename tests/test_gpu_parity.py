@@ -773,6 +773,27 @@ def test_search_operands_from_the_aggregation_epilogue_are_the_same_bits(tmp_pat
         assert np.array_equal(a[k], b[k]), f"{k} differs"
 
 
+@pytest.mark.parametrize("pairs,points", [(1, 5000), (2, 2048), (1, 1357), (3, 4100), (9, 1357)])
+def test_few_clouds_launch_merges_are_the_same_bits(tmp_path, pairs, points):
+    """Round 5, one pair in flight: the KNN pyramid as three launches (the grids of the large levels; their searches; the interpolation
+    searches of all levels with the 16-NN of the small ones) instead of a chain of ten, and the pose solve with its points held in
+    registers between its passes.  Same kernel bodies, same per-thread order: the pyramid and the whole registration equal, bit for
+    bit, those of the separate launches / the streaming solve (DSIR_NO_PYRAMID_MERGE=1, DSIR_KABSCH_STREAM=1; read once per
+    process, hence two processes).  (9 x 1357: level 1 of 18 clouds falls outside the few-clouds forms and the chain is taken.)"""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for name, extra in (("merged", {}), ("separate", {"DSIR_TUNING": "1", "DSIR_NO_PYRAMID_MERGE": "1", "DSIR_KABSCH_STREAM": "1"})):
+        out = str(tmp_path / f"{name}.npz")
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "register_dump.py"), out, str(pairs), str(points), "4"],
+                           env=dict(os.environ, **extra), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(out))
+    a, b = outs
+    for k in ("neigh", "sub", "interp", "idx", "logits", "transforms"):
+        assert np.array_equal(a[k], b[k]), f"{k} differs"
+
+
 def test_screened_argmin_out_of_domain_inputs():
     """Elements beyond the fp16 range or not finite void the screening bound: split16 raises its flag and every pair is
     searched by the exhaustive kernel, so the result still equals dsir_nn_match."""

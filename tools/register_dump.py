@@ -22,9 +22,11 @@ eng.load_state_dict(to_torch_state_dict(generate_state_dict(cfg, 3)))
 eng.set_prune_thresholds(8192, 1)     # the pruned search for every launch on clouds of 8192 points and more, however few rows it has
 b = make_batch(N, list(range(500, 500 + P)), feat_len, shape, partial)
 o = eng.register(torch.from_numpy(b["points_src"]).cuda(), torch.from_numpy(b["points_ref"]).cuda(), iters)
+pyr = eng.knn_pyramid(torch.from_numpy(b["points_src"]).cuda())      # the src clouds' pyramid as its own operator (same launches as inside register at P clouds)
 st = eng.screen_stats()
 kept, total = eng.prune_stats()
 np.savez(out, tiles_visited=np.int64(kept), tiles_unpruned=np.int64(total),
          screened_searches=np.int64(st["screened_searches"]), rows_undecided=np.int64(st["rows_undecided"]),
-         pairs_exhaustive=np.int64(st["pairs_exhaustive"]), **{k: o[k].cpu().numpy() for k in ("transforms", "idx", "logits")})
+         pairs_exhaustive=np.int64(st["pairs_exhaustive"]), neigh=pyr[1].cpu().numpy(), sub=pyr[2].cpu().numpy(), interp=pyr[3].cpu().numpy(),
+         **{k: o[k].cpu().numpy() for k in ("transforms", "idx", "logits")})
 eng.close()
