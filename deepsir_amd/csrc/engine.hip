@@ -1104,24 +1104,26 @@ int build_pyramid(dsir_ctx* c, const float* points, int stride, int clouds, int 
     launch_copy_sub_levels(neigh, neigh_cs, lv, clouds, sub, sub_cs, st);
     return 0;
   }
-  // Few clouds in flight (one pair: the reference's evaluation mode, test.py:56): every level's searches read the input points alone,
-  // so the pyramid is THREE launches instead of a chain of ten - the grids of the large levels, their searches, and everything
-  // else (the interpolation searches of all levels, the 16-NN of the small levels).  The same kernels' bodies: same bits.
+  // Every level's searches read the input points alone (the levels are prefixes of the cloud), so the pyramid is THREE launches instead
+  // of a chain of ten - the grids of the large levels, their searches, and everything else (the interpolation searches of all levels,
+  // the 16-NN of the levels without a grid) - plus one per interpolation search that walks a grid (large launches).  With one pair in
+  // flight (the reference's evaluation mode, test.py:56) the chain was 226 us of the registration's 3.05 ms, now 135; with eight, 373.
+  // The same kernels' bodies on the same operands: same bits (tests/test_gpu_parity.py, two-process A/B).
   static const bool no_merge = tuning_flag("DSIR_NO_PYRAMID_MERGE");   // A/B switch
-  if (!no_merge && !any_nn1_grid && g.num_layers <= KnnSmallJobs::kMax / 2) {
-    int ngrid = 0, gn[4];
+  if (!no_merge && g.num_layers <= KnnSmallJobs::kMax / 2) {
+    int ngrid = 0, gn[4], grid_of[8];
     int32_t* gout[4];
     KnnSmallJobs jobs{};
     bool ok = true;
     for (int l = 0; l < g.num_layers && ok; ++l) {
+      grid_of[l] = -1;
       if (p.nl[l] >= grid_min && !no_grid) {
-        ok = knn16_grid_is_small(p.nl[l], clouds) && ngrid < 4;
-        if (ok) { gn[ngrid] = p.nl[l]; gout[ngrid] = neigh + (int64_t)p.off[l] * kKnn; ++ngrid; }
+        ok = knn16_grid_can_merge(p.nl[l]) && ngrid < 4;
+        if (ok) { gn[ngrid] = p.nl[l]; gout[ngrid] = neigh + (int64_t)p.off[l] * kKnn; grid_of[l] = ngrid++; }
       } else {
-        ok = knn16_takes_wave_kernel(p.nl[l], clouds);
-        if (ok) jobs.job[jobs.njobs++] = {1, p.nl[l], 0, neigh + (int64_t)p.off[l] * kKnn, neigh_cs, 0};
+        jobs.job[jobs.njobs++] = {knn16_takes_wave_kernel(p.nl[l], clouds) ? 1 : 2, p.nl[l], 0, neigh + (int64_t)p.off[l] * kKnn, neigh_cs, 0};
       }
-      jobs.job[jobs.njobs++] = {0, p.nl[l], p.nl[l + 1], interp + p.off[l], (int64_t)p.S, 0};
+      if (!nn1_by_grid(l)) jobs.job[jobs.njobs++] = {0, p.nl[l], p.nl[l + 1], interp + p.off[l], (int64_t)p.S, 0};
     }
     if (ok) {
       void* gscr[4];
@@ -1129,6 +1131,10 @@ int build_pyramid(dsir_ctx* c, const float* points, int stride, int clouds, int 
       if (c->ws.overflow) return fail(c, "workspace exhausted in the KNN pyramid");
       if (ngrid) launch_knn16_grid_levels(points, (int64_t)n * stride, stride, ngrid, gn, clouds, gout, neigh_cs, gscr, st);
       launch_knn_small_levels(points, (int64_t)n * stride, stride, clouds, jobs, st);
+      for (int l = 0; l + 1 < g.num_layers; ++l)
+        if (nn1_by_grid(l))      // level l + 1 has a grid (nn1_by_grid): the search walks it, its queries in level l's cell order when that has one
+          launch_nn1_grid(points, (int64_t)n * stride, stride, p.nl[l], p.nl[l + 1], clouds, interp + p.off[l], p.S, gscr[grid_of[l + 1]], st,
+                          grid_of[l] >= 0 ? gscr[grid_of[l]] : nullptr);
       c->ws.release(mark);
       launch_copy_sub_levels(neigh, neigh_cs, lv, clouds, sub, sub_cs, st);
       return 0;

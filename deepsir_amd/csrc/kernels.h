@@ -310,11 +310,11 @@ void launch_copy_pyramid_idx(const PyramidIdxCopy& a, int clouds, hipStream_t st
 // KNN (data_base.py:153-183): one level.  support = first n_support points of `pts`.
 void launch_knn16(const float* pts, int64_t cloud_stride, int stride, int n, int clouds, int32_t* out,
                   int64_t out_cloud_stride, hipStream_t st);
-// few clouds in flight: the interpolation searches of all levels and the 16-NN searches of the small levels in ONE launch (knn.hip)
+// the interpolation searches of all levels and the 16-NN searches of the levels without a grid in ONE launch (knn.hip)
 struct KnnSmallJobs {
   static constexpr int kMax = 8;
   struct Job {
-    int kind;            // 0: nearest support point (launch_nn1), 1: 16-NN, one wave per query (launch_knn16 for small levels)
+    int kind;            // 0: nearest support point (launch_nn1); 16-NN (launch_knn16): 1 one wave per query (small levels), 2 one lane per query
     int n, n_support;    // queries (= the level's points); kind 0: support = the first n_support points
     int32_t* out;        // cloud 0's output
     int64_t ocs;         // ints between clouds in out
@@ -328,8 +328,9 @@ void launch_knn_small_levels(const float* pts, int64_t cloud_stride, int stride,
 size_t knn_grid_scratch_bytes(int clouds, int n);
 void launch_knn16_grid(const float* pts, int64_t cloud_stride, int stride, int n, int clouds, int32_t* out,
                        int64_t out_cloud_stride, void* scratch, hipStream_t st);
-// few clouds in flight: several levels (each knn16_grid_is_small) in two launches - all grids, all searches; GridLevelsArgs::kMax = 4 levels
-bool knn16_grid_is_small(int n, int clouds);
+// several levels (each knn16_grid_can_merge: its grid is built in one launch) in two launches - all grids, all searches; at most
+// GridLevelsArgs::kMax = 4 levels; scratch[l] from knn_grid_scratch_bytes(clouds, n[l]), left as launch_knn16_grid leaves it
+bool knn16_grid_can_merge(int n);
 void launch_knn16_grid_levels(const float* pts, int64_t cloud_stride, int stride, int nlev, const int* n, int clouds, int32_t* const* out,
                               int64_t out_cloud_stride, void* const* scratch, hipStream_t st);
 void launch_nn1(const float* pts, int64_t cloud_stride, int stride, int n_query, int n_support, int clouds,

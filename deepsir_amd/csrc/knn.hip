@@ -70,17 +70,22 @@ struct Top16 {
   }
 };
 
-__global__ __launch_bounds__(QB * NW) void knn16_kernel(const float* __restrict__ pts, int64_t cs, int stride, int n,
-                                                        int32_t* __restrict__ out, int64_t ocs) {
-  __shared__ float4 tile[NW][TILE];
-  __shared__ float md[NW - 1][kKnn][QB];
-  __shared__ int mi[NW - 1][kKnn][QB];
-  __shared__ float qd[NW][QCAP][QB];
-  __shared__ int qi[NW][QCAP][QB];
+struct Knn16Smem {
+  float4 tile[NW][TILE];
+  float md[NW - 1][kKnn][QB];
+  int mi[NW - 1][kKnn][QB];
+  float qd[NW][QCAP][QB];
+  int qi[NW][QCAP][QB];
+};
+// body: query block bx of one cloud (P its points, out its lists); all QB * NW threads of the workgroup
+__device__ __forceinline__ void knn16_body(const float* __restrict__ P, int stride, int n, int32_t* __restrict__ out, int bx, Knn16Smem& sm) {
+  auto& tile = sm.tile;
+  auto& md = sm.md;
+  auto& mi = sm.mi;
+  auto& qd = sm.qd;
+  auto& qi = sm.qi;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int cloud = blockIdx.y;
-  const float* P = pts + cloud * cs;
-  const int q = blockIdx.x * QB + lane;
+  const int q = bx * QB + lane;
   float qx = 0.f, qy = 0.f, qz = 0.f;
   if (q < n) { qx = P[(int64_t)q * stride]; qy = P[(int64_t)q * stride + 1]; qz = P[(int64_t)q * stride + 2]; }
   const int slice = (n + NW - 1) / NW;
@@ -143,13 +148,18 @@ __global__ __launch_bounds__(QB * NW) void knn16_kernel(const float* __restrict_
       for (int t = 0; t < kKnn; ++t) { ld[t] = md[s][t][lane]; li[t] = mi[s][t][lane]; }
       top.merge_sorted(ld, li);
     }
-    int32_t* o = out + cloud * ocs + (int64_t)q * kKnn;
+    int32_t* o = out + (int64_t)q * kKnn;
     // fewer than 16 finite distances (non-finite coordinates): the empty slots point at the query itself, never out of range
 #pragma unroll
     for (int t = 0; t < kKnn; ++t) top.i[t] = top.i[t] < 0 ? q : top.i[t];
 #pragma unroll
     for (int t = 0; t < kKnn; t += 4) *reinterpret_cast<int4*>(o + t) = make_int4(top.i[t], top.i[t + 1], top.i[t + 2], top.i[t + 3]);
   }
+}
+__global__ __launch_bounds__(QB * NW) void knn16_kernel(const float* __restrict__ pts, int64_t cs, int stride, int n,
+                                                        int32_t* __restrict__ out, int64_t ocs) {
+  __shared__ Knn16Smem sm;
+  knn16_body(pts + blockIdx.y * cs, stride, n, out + blockIdx.y * ocs, blockIdx.x, sm);
 }
 
 // One WAVE per query, for the small pyramid levels when few clouds are in flight (312 and 78 points per cloud at N = 5000:
@@ -252,21 +262,28 @@ __global__ __launch_bounds__(QB * NW) void nn1_kernel(const float* __restrict__ 
   nn1_body(pts + blockIdx.y * cs, stride, n_query, n_support, out + blockIdx.y * ocs, blockIdx.x, sm);
 }
 
-// Few clouds in flight (one pair: the reference's evaluation mode): every level's points are a prefix of the input cloud
-// (data_base.py:166-172), so the interpolation searches of ALL levels and the 16-NN searches of the small levels read the input
-// alone and are independent of one another - ONE launch for what were six dependent ones in the pair's chain.  Job j of the table =
-// (kind, level sizes, output, first workgroup); a workgroup finds its job by its index and runs the unchanged body: same bits.
+// Every level's points are a prefix of the input cloud (data_base.py:166-172), so the interpolation searches of ALL levels and the
+// 16-NN searches of the levels without a grid read the input alone and are independent of one another - ONE launch for what were up
+// to six dependent ones in a registration's chain (one pair in flight: 62 -> 29 us; eight: the 55 us lane-per-query search of level 2
+// runs beside the others).  Job j of the table = (kind, level sizes, output, first workgroup); a workgroup finds its job by its
+// index and runs the unchanged body: same bits.  K16: the table holds a lane-per-query search (its 72 KB of LDS).
+template <bool K16>
+struct SmallSmem { union { Nn1Smem nn1; Knn16Smem k16; }; };
+template <>
+struct SmallSmem<false> { Nn1Smem nn1; };
+template <bool K16>
 __global__ __launch_bounds__(256) void knn_small_levels_kernel(const float* __restrict__ pts, int64_t cs, int stride, const KnnSmallJobs J) {
-  static_assert(QB * NW == 256, "both bodies run 256 threads");
-  __shared__ Nn1Smem sm;
+  static_assert(QB * NW == 256, "the bodies run 256 threads");
+  __shared__ SmallSmem<K16> sm;
   int j = 0;
 #pragma unroll
   for (int k = 1; k < KnnSmallJobs::kMax; ++k) j += (k < J.njobs && (int)blockIdx.x >= J.job[k].b0) ? 1 : 0;
   const KnnSmallJobs::Job& jb = J.job[j];
   const int bx = (int)blockIdx.x - jb.b0;
   const float* P = pts + blockIdx.y * cs;
-  if (jb.kind == 0) nn1_body(P, stride, jb.n, jb.n_support, jb.out + blockIdx.y * jb.ocs, bx, sm);
-  else knn16_wave_body(P, stride, jb.n, jb.out + blockIdx.y * jb.ocs, bx);
+  if (jb.kind == 0) nn1_body(P, stride, jb.n, jb.n_support, jb.out + blockIdx.y * jb.ocs, bx, sm.nn1);
+  else if (jb.kind == 1) knn16_wave_body(P, stride, jb.n, jb.out + blockIdx.y * jb.ocs, bx);
+  else if constexpr (K16) knn16_body(P, stride, jb.n, jb.out + blockIdx.y * jb.ocs, bx, sm.k16);
 }
 
 }  // namespace
@@ -284,13 +301,22 @@ void launch_knn16(const float* pts, int64_t cs, int stride, int n, int clouds, i
 bool knn16_takes_wave_kernel(int n, int clouds) { return n <= 64 * WQ_MAX && (int64_t)clouds * n <= 4096; }
 
 void launch_knn_small_levels(const float* pts, int64_t cs, int stride, int clouds, KnnSmallJobs& J, hipStream_t st) {
+  // the longest bodies first (the lane-per-query searches, then one wave per query, then the interpolation searches)
+  KnnSmallJobs S{};
+  for (int kind = 2; kind >= 0; --kind)
+    for (int k = 0; k < J.njobs; ++k)
+      if (J.job[k].kind == kind) S.job[S.njobs++] = J.job[k];
   int b = 0;
-  for (int k = 0; k < J.njobs; ++k) {
-    J.job[k].b0 = b;
-    b += J.job[k].kind == 0 ? (J.job[k].n + QB - 1) / QB : (J.job[k].n + 3) / 4;
+  bool k16 = false;
+  for (int k = 0; k < S.njobs; ++k) {
+    S.job[k].b0 = b;
+    b += S.job[k].kind == 1 ? (S.job[k].n + 3) / 4 : (S.job[k].n + QB - 1) / QB;
+    k16 = k16 || S.job[k].kind == 2;
   }
+  J = S;
   if (b == 0 || clouds <= 0) return;
-  hipLaunchKernelGGL(knn_small_levels_kernel, dim3(b, clouds), dim3(256), 0, st, pts, cs, stride, J);
+  if (k16) hipLaunchKernelGGL(knn_small_levels_kernel<true>, dim3(b, clouds), dim3(256), 0, st, pts, cs, stride, S);
+  else hipLaunchKernelGGL(knn_small_levels_kernel<false>, dim3(b, clouds), dim3(256), 0, st, pts, cs, stride, S);
 }
 
 void launch_nn1(const float* pts, int64_t cs, int stride, int n_query, int n_support, int clouds, int32_t* out,

@@ -343,14 +343,14 @@ constexpr int KB = 64;     // threads per query block (queue = QCAP * KB * 8 byt
 // threshold (its 16th best distance at the last flush) are therefore parked in a per-lane LDS queue and inserted in
 // bursts — all lanes together — when some lane's queue is full and at the end of every shell.  insert() re-checks
 // exactly, and TopLex is order independent, so the result is unchanged.
-__global__ __launch_bounds__(KB) __attribute__((amdgpu_waves_per_eu(3, 3))) void grid_knn_kernel(const float4* __restrict__ sorted, const int* __restrict__ starts,
-                                                       const GridParams* __restrict__ gp, int max_cells, int n,
-                                                       int32_t* __restrict__ out, int64_t ocs) {
+// body: query block bx (KB queries) of one cloud
+__device__ __forceinline__ void grid_knn_body(const float4* __restrict__ sorted, const int* __restrict__ starts,
+                                              const GridParams* __restrict__ gp, int max_cells, int n,
+                                              int32_t* __restrict__ out, int64_t ocs, const int bx, const int cloud) {
   __shared__ float qd[QCAP][KB];
   __shared__ int qi[QCAP][KB];
-  const int cloud = blockIdx.y;
   const int tid = threadIdx.x;
-  const int t = blockIdx.x * blockDim.x + tid;
+  const int t = bx * KB + tid;
   const bool live = t < n;
   const GridParams g = gp[cloud];
   const float4* S = sorted + (int64_t)cloud * n;
@@ -448,6 +448,20 @@ __global__ __launch_bounds__(KB) __attribute__((amdgpu_waves_per_eu(3, 3))) void
 #pragma unroll
     for (int k = 0; k < kKnn; k += 4) *reinterpret_cast<int4*>(o + k) = make_int4(top.index(k, qidx), top.index(k + 1, qidx), top.index(k + 2, qidx), top.index(k + 3, qidx));
   }
+}
+
+__global__ __launch_bounds__(KB) __attribute__((amdgpu_waves_per_eu(3, 3))) void grid_knn_kernel(const float4* __restrict__ sorted, const int* __restrict__ starts,
+                                                       const GridParams* __restrict__ gp, int max_cells, int n,
+                                                       int32_t* __restrict__ out, int64_t ocs) {
+  grid_knn_body(sorted, starts, gp, max_cells, n, out, ocs, blockIdx.x, blockIdx.y);
+}
+// the searches of several levels in one launch: workgroup -> (level, query block) by the levels' first workgroups
+__global__ __launch_bounds__(KB) __attribute__((amdgpu_waves_per_eu(3, 3))) void grid_knn_levels_kernel(const GridLevelsArgs A, int64_t ocs) {
+  int l = 0;
+#pragma unroll
+  for (int k = 1; k < GridLevelsArgs::kMax; ++k) l += (k < A.nlev && (int)blockIdx.x >= A.lev[k].b0) ? 1 : 0;
+  const GridLevelsArgs::Lev& L = A.lev[l];
+  grid_knn_body(L.sorted, L.starts, L.gp, L.max_cells, L.n, L.out, ocs, (int)blockIdx.x - L.b0, blockIdx.y);
 }
 
 // Four lanes per query, for launches too small to fill the chip with one lane per query (one or two clouds in flight:
@@ -699,18 +713,24 @@ void launch_knn16_grid(const float* pts, int64_t cs, int stride, int n, int clou
     hipLaunchKernelGGL(grid_knn4_kernel, dim3((n + KB4 / 4 - 1) / (KB4 / 4), clouds), dim3(KB4), 0, st, sorted, starts, gp, max_cells, n, out, ocs);
 }
 
-// would launch_knn16_grid take the one-launch construction and the four-lanes-per-query search for this level?
-bool knn16_grid_is_small(int n, int clouds) {
+// does launch_knn16_grid build this level's grid in one launch (the form the several-levels launch below takes)?
+bool knn16_grid_can_merge(int n) {
   static const bool no_build = tuning_flag("DSIR_GRID_NO_BUILD");
-  return !no_build && n / 2 + 64 <= kBuildMaxCells && (int64_t)((n + KB - 1) / KB) * clouds < 1024;
+  return !no_build && n / 2 + 64 <= kBuildMaxCells;
 }
 
-// Few clouds in flight: the grid-pruned searches of several levels (each knn16_grid_is_small) in TWO launches - all the grids, then all
-// the searches - instead of two per level in the pair's dependent chain.  Same kernels' bodies on the same operands: same bits.
+// The grid-pruned searches of several levels of the same clouds (each knn16_grid_can_merge) in TWO launches - all the grids, then all
+// the searches - instead of two per level in a registration's dependent chain.  One lane per query when the launch as a whole fills the
+// chip that way, else four (the rule of launch_knn16_grid on the sum of the levels).  The same kernels' bodies on the same operands,
+// and the two search forms give the same bits: the result equals the separate launches'.  `scratch[l]` as for launch_knn16_grid(n[l]).
 void launch_knn16_grid_levels(const float* pts, int64_t cs, int stride, int nlev, const int* n, int clouds, int32_t* const* out, int64_t ocs,
                               void* const* scratch, hipStream_t st) {
   GridLevelsArgs A{};
   A.nlev = nlev;
+  int64_t b1 = 0;
+  for (int l = 0; l < nlev; ++l) b1 += (n[l] + KB - 1) / KB;
+  const bool one_lane = b1 * clouds >= 1024;
+  const int per = one_lane ? KB : KB4 / 4;          // queries per workgroup
   int b = 0;
   for (int l = 0; l < nlev; ++l) {
     const int max_cells = n[l] / 2 + 64;
@@ -724,10 +744,11 @@ void launch_knn16_grid_levels(const float* pts, int64_t cs, int stride, int nlev
     L.starts = reinterpret_cast<int*>(take((size_t)clouds * (max_cells + 1) * sizeof(int)));
     take((size_t)clouds * max_cells * sizeof(int));              // cursor
     L.sorted = reinterpret_cast<float4*>(take((size_t)clouds * n[l] * sizeof(float4)));
-    b += (n[l] + KB4 / 4 - 1) / (KB4 / 4);
+    b += (n[l] + per - 1) / per;
   }
   hipLaunchKernelGGL(grid_build_levels_kernel, dim3(clouds, nlev), dim3(1024), 0, st, pts, cs, stride, A);
-  hipLaunchKernelGGL(grid_knn4_levels_kernel, dim3(b, clouds), dim3(KB4), 0, st, A, ocs);
+  if (one_lane) hipLaunchKernelGGL(grid_knn_levels_kernel, dim3(b, clouds), dim3(KB), 0, st, A, ocs);
+  else hipLaunchKernelGGL(grid_knn4_levels_kernel, dim3(b, clouds), dim3(KB4), 0, st, A, ocs);
 }
 
 // nn1 through the grid launch_knn16_grid(.., n = n_support, .., scratch) has left in `scratch` (same carving)

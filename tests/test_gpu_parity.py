@@ -773,13 +773,15 @@ def test_search_operands_from_the_aggregation_epilogue_are_the_same_bits(tmp_pat
         assert np.array_equal(a[k], b[k]), f"{k} differs"
 
 
-@pytest.mark.parametrize("pairs,points", [(1, 5000), (2, 2048), (1, 1357), (3, 4100), (9, 1357)])
-def test_few_clouds_launch_merges_are_the_same_bits(tmp_path, pairs, points):
-    """Round 5, one pair in flight: the KNN pyramid as three launches (the grids of the large levels; their searches; the interpolation
-    searches of all levels with the 16-NN of the small ones) instead of a chain of ten, and the pose solve with its points held in
-    registers between its passes.  Same kernel bodies, same per-thread order: the pyramid and the whole registration equal, bit for
-    bit, those of the separate launches / the streaming solve (DSIR_NO_PYRAMID_MERGE=1, DSIR_KABSCH_STREAM=1; read once per
-    process, hence two processes).  (9 x 1357: level 1 of 18 clouds falls outside the few-clouds forms and the chain is taken.)"""
+@pytest.mark.parametrize("pairs,points", [(1, 5000), (2, 2048), (1, 1357), (3, 4100), (9, 1357), (8, 5000), (20, 5000), (2, 16384)])
+def test_pyramid_launch_merges_are_the_same_bits(tmp_path, pairs, points):
+    """Round 5: the KNN pyramid as three launches (the grids of the large levels; their searches; the interpolation searches of all
+    levels with the 16-NN of the levels without a grid; plus one per interpolation search that walks a grid) instead of a chain of
+    ten, and the pose solve with its points held in registers between its passes.  Same kernel bodies, same per-thread order: the
+    pyramid and the whole registration equal, bit for bit, those of the separate launches / the streaming solve
+    (DSIR_NO_PYRAMID_MERGE=1, DSIR_KABSCH_STREAM=1; read once per process, hence two processes).  The cases cover every form a
+    level takes: four lanes / one lane per query on the grid, one wave / one lane per query without it, interpolation by brute force /
+    through the grid (20 x 5000, 2 x 16384), clouds beyond the register-resident solve (2 x 16384)."""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []

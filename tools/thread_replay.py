@@ -51,7 +51,9 @@ else:
         for e in range(E):
             with torch.cuda.stream(streams[e]):
                 engs[e].register(src, ref, 5, want_aux=False, sync=False, out=outs[e])
+    t_enq = time.perf_counter() - t
     torch.cuda.synchronize()
+    print(f"  host time in the {E * R} register() calls (graph launches): {t_enq / (E * R) * 1e3:.3f} ms each; {engs[0].graph_stats()}")
 t = time.perf_counter() - t
 same = all(torch.equal(outs[0]["transforms"], o["transforms"]) for o in outs)
 print(f"{'walker ' if os.environ.get('WALK') else ''}HWQ {os.environ.get('GPU_MAX_HW_QUEUES', 'dflt')} engines {E} batch {b} {'threads' if threaded else 'one thread'}: {E * R * b / t:8.1f} pairs/s  "
