@@ -2,7 +2,7 @@
 # One call on the GPU box (through gpurun): every number profiles/README.md quotes for the current build.
 #   bash tools/collect_evidence.sh <tag>          -> gpurun_out/<tag>_*  (copy what is to be judged into profiles/)
 set -o pipefail
-tag=${1:-r04}
+tag=${1:-r05}
 out=gpurun_out
 mkdir -p $out
 export TMPDIR=/tmp
