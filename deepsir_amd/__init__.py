@@ -10,11 +10,12 @@ import os as _os
 _FLAG = "DEBUG_CLR_GRAPH_PACKET_CAPTURE"
 _preset = _os.environ.get(_FLAG)
 _os.environ.setdefault(_FLAG, "0")
-# Streams -> hardware queues: the runtime spreads a process's streams over GPU_MAX_HW_QUEUES queues (4 unless told otherwise), and two
-# streams that land on one queue run their kernels one after the other.  The serving scheduler's engines (serve.py) sit on torch
-# streams; with 4 queues two engines' replayed registrations did not overlap at all (2 x 1 pair: 5.89 ms per round against 2.95 ms
-# for one; 3.24 ms with 8 queues - profiles/r05_serving_queues.txt).  Read at initialisation like the flag above; a caller's own
-# setting wins.  (More than two engines in flight are slower than two whatever the queue count: serve.py keeps to two.)
+# Streams -> hardware queues: every stream a process creates takes one of GPU_MAX_HW_QUEUES hardware queues in turn (4 unless told
+# otherwise), and two streams that land on one queue run their kernels one after the other.  Round 5 found the serving scheduler's two
+# engines (serve.py) on ONE queue - each context had begun to create two idle auxiliary streams, which shifted the second engine's stream
+# onto the first one's queue: 2 x 1 pair took 5.89 ms per round against 2.95 ms for one engine (profiles/r05_serving_queues.txt).  The
+# auxiliary streams are created on demand now (csrc/engine.hip, ensure_aux_streams); asking for 8 queues as well makes such a collision
+# less likely whatever else the process creates.  Read at initialisation like the flag above; a caller's own setting wins.
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 

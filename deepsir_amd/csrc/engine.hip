@@ -548,6 +548,16 @@ void fork_wait(hipStream_t to, hipEvent_t e) { hipStreamWaitEvent(to, e, 0); }
 void fork_to(dsir_ctx* c, hipStream_t from, hipStream_t to) { fork_wait(to, fork_mark(c, from)); }
 // what: 1 = the KNN pyramid's levels, 2 = a block's position-encoding branch, 4 = a block's mlp_skip, 8 = the aggregation's loop invariants
 // (DSIR_FORK_MASK: tuning hook - a dependency between streams has a price of its own, only the longer branches pay for it)
+// The auxiliary streams of the forked schedule exist only in a context that forks: every stream a process creates takes a hardware
+// queue in turn (GPU_MAX_HW_QUEUES of them), and two engines' main streams that land on one queue do not overlap - creating two idle
+// streams per context moved the serving scheduler's second engine onto the first one's queue (profiles/r05_serving_queues.txt).
+void ensure_aux_streams(dsir_ctx* c) {
+  if (c->aux[0]) return;
+  for (int k = 0; k < dsir_ctx::kAux; ++k)
+    if (hipStreamCreateWithFlags(&c->aux[k], hipStreamNonBlocking) != hipSuccess) c->aux[k] = nullptr;
+  if (!c->aux[0] || !c->aux[1]) { for (int k = 0; k < dsir_ctx::kAux; ++k) { if (c->aux[k]) hipStreamDestroy(c->aux[k]); c->aux[k] = nullptr; } }
+}
+
 bool fork_on(const dsir_ctx* c, int clouds, int what) {
   static const int mask = (int)tuning_int("DSIR_FORK_MASK", 15);
   return c->fork_mode && (mask & what) && c->aux[0] && clouds <= dsir_ctx::kForkClouds;
@@ -1228,10 +1238,8 @@ int dsir_create(int device, const dsir_cfg* cfg, dsir_ctx** out) {
     return fail(nullptr, "cannot initialise device %d", device);
   }
   c->own_stream = c->stream;
-  for (int k = 0; k < dsir_ctx::kAux; ++k)
-    if (hipStreamCreateWithFlags(&c->aux[k], hipStreamNonBlocking) != hipSuccess) c->aux[k] = nullptr;
-  if (!c->aux[0] || !c->aux[1]) { for (int k = 0; k < dsir_ctx::kAux; ++k) { if (c->aux[k]) hipStreamDestroy(c->aux[k]); c->aux[k] = nullptr; } }
   c->fork_mode = tuning_flag("DSIR_FORK") ? 1 : 0;
+  if (c->fork_mode) ensure_aux_streams(c);
   // which sub-networks exist follows args.pipeline (model.py:131-193)
   add_randla(c, "feat_extractor", cfg->feat_len, cfg->num_classes);
   if (cfg->pipeline != DSIR_PIPELINE_LABEL) {
@@ -2356,6 +2364,7 @@ int dsir_walk_trace(dsir_ctx* c, int reset, int64_t* out, int64_t* clock_khz) {
 int dsir_enable_fork(dsir_ctx* c, int enable) {
   if (!c) return 1;
   c->fork_mode = enable != 0;
+  if (c->fork_mode) ensure_aux_streams(c);
   // a captured registration has the choice baked in
   c->drop_graphs();
   return 0;
