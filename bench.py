@@ -22,7 +22,6 @@ import argparse
 import os
 
 os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")   # before the GPU is touched: deepsir_amd/__init__.py
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")                 # likewise: two serving engines need two hardware queues (deepsir_amd/__init__.py)
 import json
 import socket
 import subprocess

@@ -10,13 +10,10 @@ import os as _os
 _FLAG = "DEBUG_CLR_GRAPH_PACKET_CAPTURE"
 _preset = _os.environ.get(_FLAG)
 _os.environ.setdefault(_FLAG, "0")
-# Streams -> hardware queues: every stream a process creates takes one of GPU_MAX_HW_QUEUES hardware queues in turn (4 unless told
-# otherwise), and two streams that land on one queue run their kernels one after the other.  Round 5 found the serving scheduler's two
-# engines (serve.py) on ONE queue - each context had begun to create two idle auxiliary streams, which shifted the second engine's stream
-# onto the first one's queue: 2 x 1 pair took 5.89 ms per round against 2.95 ms for one engine (profiles/r05_serving_queues.txt).  The
-# auxiliary streams are created on demand now (csrc/engine.hip, ensure_aux_streams); asking for 8 queues as well makes such a collision
-# less likely whatever else the process creates.  Read at initialisation like the flag above; a caller's own setting wins.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# (Streams -> hardware queues: the runtime hands its GPU_MAX_HW_QUEUES queues - four by default - to streams in creation order, and two
+# streams on one queue do not overlap.  Nothing is set here: with eight queues three or more engines in flight run four times SLOWER than
+# one after the other, with four they overlap; what had put the serving scheduler's two engines on one queue in round 5 was a pair of idle
+# auxiliary streams per context, created on demand since - csrc/engine.hip, ensure_aux_streams; profiles/r05_serving_queues.txt.)
 
 
 def graph_replay_safe() -> bool:

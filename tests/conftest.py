@@ -3,7 +3,6 @@ import os
 import sys
 
 os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")   # before the GPU is touched: deepsir_amd/__init__.py
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")                 # likewise (two serving engines on two hardware queues)
 
 import numpy as np
 import pytest

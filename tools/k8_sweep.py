@@ -1,9 +1,8 @@
 """K = 8 single-pair requests in flight (deepsir_amd/serve.py) against the number of engines they are spread over.
-    [GPU_MAX_HW_QUEUES=4] python3 tools/k8_sweep.py [K]"""
+    [GPU_MAX_HW_QUEUES=8] python3 tools/k8_sweep.py [K]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")                 # likewise: two serving engines need two hardware queues (deepsir_amd/__init__.py)
 import torch
 import deepsir_amd  # noqa: F401
 from deepsir_amd.arch import NetConfig

@@ -1,9 +1,8 @@
 """Do graph replays issued from SEPARATE host threads (one per engine) overlap?  E engines x batch b, R replays each.
-    [GPU_MAX_HW_QUEUES=4] python3 tools/thread_replay.py E b [threads=1|0]        (8 queues unless the environment says otherwise; the runtime's own default is 4)"""
+    [GPU_MAX_HW_QUEUES=8] python3 tools/thread_replay.py E b [threads=1|0]"""
 import os, sys, time, threading
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")                 # likewise: two serving engines need two hardware queues (deepsir_amd/__init__.py)
 import torch
 import deepsir_amd  # noqa: F401
 from deepsir_amd.arch import NetConfig
