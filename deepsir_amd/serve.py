@@ -9,9 +9,10 @@ small scheduler instead:
 * requests of the same shape are coalesced, up to ``max_batch = K / engines`` of them, into one ``dsir_register`` call that
   is replayed from a captured hipGraph (one graph per batch size, ``include/dsir.h`` ``dsir_enable_graph``);
 * ``engines`` contexts on their own HIP streams take the batches in turn, so the launch chain of one batch fills the gaps of
-  the other's.  Measured (tools/serve_bench.py, 5000-point pairs): up to 8 requests in flight ONE engine with the whole window in
-  its batch is fastest (K = 8: 1620 pairs/s against 1575 as 2 x 4 - a batch of 8 costs little more than a batch of 4), from 16 on
-  two engines win (K = 16: 2500 against 2310, K = 32: 3300 against 3135); four never do.  ``engines=None`` picks by that rule;
+  the other's.  Measured (bench.py `concurrent_single_pairs`, tools/k8_sweep.py; 5000-point pairs, round 5): up to 8 requests in flight
+  ONE engine with the whole window in its batch is as fast as two (K = 8: 1720 - 1790 pairs/s either way - a batch of 8 costs little more
+  than a batch of 4), from 16 on two engines win (K = 16: 2530 - 2630 against 2310 - 2360); more than two never do - every replayed graph
+  holds the host ~1.4 ms, so E engines need E x 1.4 ms per round (profiles/r05_serving_queues.txt).  ``engines=None`` picks by that rule;
 * ``future.result()`` waits for that request's batch only.
 
 A pair's result does not depend on what shares its batch (every kernel's tiling is a function of the per-cloud shape alone,
