@@ -47,7 +47,8 @@ typedef struct dsir_cfg {
   int32_t d_out[DSIR_MAX_LEVELS];         /* 16,64,128,256                     */
   int32_t out_feat_dim;                   /* 64                                */
   int32_t num_classes;                    /* 19 (semantic head of feat_extractor) */
-  int32_t max_points;                     /* workspace sizing: points per cloud (1024 .. 2^20) */
+  int32_t max_points;                     /* workspace sizing: points per cloud (1024 .. dsir_max_points_limit(): 131072, the bound up
+                                           * to which the GroupNorm statistics are provably order independent) */
   int32_t max_pairs;                      /* workspace sizing: pairs per call   */
   int32_t pipeline;                       /* args.pipeline (network/model.py:122,131): DSIR_PIPELINE_*; selects
                                            * which sub-networks exist, i.e. which state-dict keys are expected  */
