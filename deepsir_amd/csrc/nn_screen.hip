@@ -567,11 +567,28 @@ __global__ __launch_bounds__(256) void exact_pick_kernel(const float* __restrict
   idx[row] = (int32_t)(best & 0xffffffffull);
 }
 
+// running totals of a context (dsir_screen_stats): searches, rows searched, rows left to the exhaustive kernel, pairs
+// searched exhaustively as a whole
+__device__ __forceinline__ void screen_account(const int32_t* __restrict__ ovf, int pairs, int ovf_min, int J,
+                                               unsigned long long* __restrict__ acc) {
+  unsigned long long rows = 0, full = 0;
+  for (int p = threadIdx.x; p < pairs; p += blockDim.x) {
+    const int g = ovf[p];
+    rows += (unsigned long long)(g >= ovf_min ? J : g);
+    full += g >= ovf_min ? 1ull : 0ull;
+  }
+  if (rows) atomicAdd(acc + 2, rows);
+  if (full) atomicAdd(acc + 3, full);
+  if (threadIdx.x == 0) { atomicAdd(acc, 1ull); atomicAdd(acc + 1, (unsigned long long)pairs * (unsigned long long)J); }
+}
+
 // results of the exhaustive kernel -> idx: every row of a pair with ovf_min or more listed rows, else the listed rows
+// (its first workgroup also adds the search to the context's running totals, acc - what screen_account_kernel did in a launch of
+// its own: the listed-row counts are final once the exhaustive kernel has been queued)
 __global__ __launch_bounds__(256) void unpack_listed_kernel(const unsigned long long* __restrict__ packed,
                                                             const int32_t* __restrict__ ovf, int ovf_min,
                                                             const int32_t* __restrict__ rowlist, int J,
-                                                            int32_t* __restrict__ idx) {
+                                                            int32_t* __restrict__ idx, unsigned long long* __restrict__ acc) {
   const int pair = blockIdx.y;
   const int g = ovf[pair];
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -582,6 +599,7 @@ __global__ __launch_bounds__(256) void unpack_listed_kernel(const unsigned long 
     const int r = rowlist[base + i];
     idx[base + r] = packed_index(packed[base + r]);
   }
+  if (acc && blockIdx.x == 0 && blockIdx.y == 0) screen_account(ovf, (int)gridDim.y, ovf_min, J, acc);
 }
 
 // diagnostics: out[0] = total entries, out[1] = rows left to the exhaustive kernel
@@ -610,21 +628,6 @@ __global__ void screen_reset_kernel(int32_t* __restrict__ ovf, int pairs, int ov
     cnt[i] = 0;
     packed[i] = ~0ull;
   }
-}
-
-// running totals of a context (dsir_screen_stats): searches, rows searched, rows left to the exhaustive kernel, pairs
-// searched exhaustively as a whole
-__global__ void screen_account_kernel(const int32_t* __restrict__ ovf, int pairs, int ovf_min, int J,
-                                      unsigned long long* __restrict__ acc) {
-  unsigned long long rows = 0, full = 0;
-  for (int p = threadIdx.x; p < pairs; p += blockDim.x) {
-    const int g = ovf[p];
-    rows += (unsigned long long)(g >= ovf_min ? J : g);
-    full += g >= ovf_min ? 1ull : 0ull;
-  }
-  if (rows) atomicAdd(acc + 2, rows);
-  if (full) atomicAdd(acc + 3, full);
-  if (threadIdx.x == 0) { atomicAdd(acc, 1ull); atomicAdd(acc + 1, (unsigned long long)pairs * (unsigned long long)J); }
 }
 
 // ---- diagnostics (dsir_screen_bounds): the screening's arithmetic laid bare for EVERY (row, column) of one small pair.
@@ -1142,9 +1145,8 @@ void launch_nn_screen(const float* a, const float* b, const void* ah, const void
   hipLaunchKernelGGL(exact_pick_kernel, dim3((J + 255) / 256, pairs), dim3(256), 0, st, a, b, sa, sb, J, K, umin, cnt, cand, ovf,
                      ovf_min, rowlist, idx);
   launch_nn_match_gated(a, b, sa, sb, pairs, J, K, packed, ovf, ovf_min, rowlist, st);
-  hipLaunchKernelGGL(unpack_listed_kernel, dim3((J + 255) / 256, pairs), dim3(256), 0, st, packed, ovf, ovf_min, rowlist, J, idx);
+  hipLaunchKernelGGL(unpack_listed_kernel, dim3((J + 255) / 256, pairs), dim3(256), 0, st, packed, ovf, ovf_min, rowlist, J, idx, acc);
   if (ev1) (void)hipEventRecord(ev1, st);
-  if (acc) hipLaunchKernelGGL(screen_account_kernel, dim3(1), dim3(256), 0, st, ovf, pairs, ovf_min, J, acc);
   static const bool debug = tuning_flag("DSIR_SCREEN_DEBUG");   // diagnostic: rows left to the exhaustive kernel (synchronises)
   if (debug) {
     std::vector<int32_t> h(pairs);
