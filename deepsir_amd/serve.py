@@ -11,7 +11,7 @@ small scheduler instead:
 * ``engines`` contexts on their own HIP streams take the batches in turn, so the launch chain of one batch fills the gaps of
   the other's.  Measured (bench.py `concurrent_single_pairs`, tools/k8_sweep.py; 5000-point pairs, round 5): up to 8 requests in flight
   ONE engine with the whole window in its batch is as fast as two (K = 8: 1720 - 1790 pairs/s either way - a batch of 8 costs little more
-  than a batch of 4), from 16 on two engines win (K = 16: 2530 - 2630 against 2310 - 2360); more than two never do - every replayed graph
+  than a batch of 4), from 16 on two engines win (K = 16: 2530 - 2710 against 2310 - 2510); more than two never do - every replayed graph
   holds the host ~1.4 ms, so E engines need E x 1.4 ms per round (profiles/r05_serving_queues.txt).  ``engines=None`` picks by that rule;
 * ``future.result()`` waits for that request's batch only.
 
@@ -178,6 +178,11 @@ class PairServer:
             if whole:
                 src.copy_(q[0][0], non_blocking=True)
                 ref.copy_(q[0][1], non_blocking=True)
+            elif len(q) > 1 and all(s.is_cuda and r.is_cuda and s.dtype == src.dtype and r.dtype == ref.dtype for s, r, _ in q):
+                # device-resident requests: ONE gather launch per side instead of one copy per request (16 launches of ~5 us in front
+                # of a batch of 8: 2 % of the batch's time)
+                torch.stack([s for s, _, _ in q], out=src)
+                torch.stack([r for _, r, _ in q], out=ref)
             else:
                 for j, (s, r, _) in enumerate(q):
                     src[j].copy_(s, non_blocking=True)
