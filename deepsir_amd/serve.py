@@ -1,7 +1,7 @@
 """Batch-1 SERVING: K independent single-pair registrations in flight.
 
 The reference evaluates one pair per ``model(data, opt)`` call (test.py:56 ``BATCH_SIZE = 1``, the loop at
-test.py:386-450, fed by DataLoader workers).  One pair alone leaves the GPU almost empty - its registration is ~360
+test.py:386-450, fed by DataLoader workers).  One pair alone leaves the GPU almost empty - its registration is ~290
 dependent kernel launches of a few microseconds each - so a caller that can keep K requests outstanding is served by a
 small scheduler instead:
 
